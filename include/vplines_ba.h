@@ -1,0 +1,230 @@
+/*
+ * vplines_ba.h -- C ABI of the MI355X-native sliding-window bundle-adjustment path.
+ *
+ * This header is the drop-in boundary for the back-end hot path of
+ * multiplefish/VPLines-SLAM (vins_estimator).  Every entry point names the
+ * reference interface it replaces (path:line relative to the reference tree).
+ * All signatures use plain pointers and sizes; no C++/torch types cross it.
+ *
+ * Conventions shared with the reference
+ *   - parameter blocks keep the reference's global layouts
+ *       pose        [7] = px,py,pz,qx,qy,qz,qw      (estimator.cpp:650-705)
+ *       speed/bias  [9] = v, ba, bg
+ *       inv. depth  [1]                             (feature_manager.cpp:277-293)
+ *       line orth   [4] = psi1,psi2,psi3,phi        (line_geometry.cpp:62-126)
+ *   - Jacobians are row-major  num_residuals x global_size, column 6 of every
+ *     7-sized pose block is written as zero (projection_factor.cpp:81-88)
+ *   - WINDOW_SIZE = 10  => 11 frames  (parameters.h:20)
+ *
+ * Error handling: every function returns 0 on success and a negative
+ * VPL_E_* code otherwise; nothing aborts, nothing falls back to a CPU path.
+ * Thread model: one vpl_ctx per host thread / GPU; functions on one context
+ * are not re-entrant (the reference calls its solve from exactly one thread,
+ * estimator_node.cpp:229).
+ */
+#ifndef VPLINES_BA_H
+#define VPLINES_BA_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPL_WINDOW_SIZE 10
+#define VPL_NFRAMES 11
+#define VPL_MAX_PRIOR_BLOCKS 23 /* 11 poses + 11 speed/bias + 1 extrinsic */
+#define VPL_MAX_PRIOR_DIM 171   /* 11*6 + 11*9 + 6 */
+
+#define VPL_OK 0
+#define VPL_E_INVALID -1   /* bad argument / shape mismatch */
+#define VPL_E_NODEVICE -2  /* no HIP device or kernel image for it */
+#define VPL_E_HIP -3       /* a HIP runtime call failed */
+#define VPL_E_CAPACITY -4  /* batch exceeds the capacity given at create */
+#define VPL_E_NUMERIC -5   /* non-finite value met where the reference would ROS_BREAK */
+
+/* marginalization_flag of Estimator (estimator.h MarginalizationFlag) */
+#define VPL_MARGIN_OLD 0
+#define VPL_MARGIN_SECOND_NEW 1
+#define VPL_MARGIN_NONE -1
+
+/* kind of a kept parameter block inside a prior */
+#define VPL_BLOCK_POSE 0
+#define VPL_BLOCK_SPEEDBIAS 1
+#define VPL_BLOCK_EXPOSE 2
+
+/* Solver / model constants the reference reads from YAML and parameters.h
+ * (parameters.cpp:58-154, estimator.cpp:18-20). */
+typedef struct vpl_ba_options {
+  int num_iterations;       /* NUM_ITERATIONS -> options.max_num_iterations (estimator.cpp:1211) */
+  int estimate_extrinsic;   /* ESTIMATE_EXTRINSIC; 0 => para_Ex_Pose constant (estimator.cpp:1060) */
+  int marginalization_flag; /* VPL_MARGIN_* */
+  int remove_line_outliers; /* run FeatureManager::removeLineOutlier between solve and marginalisation (0/1) */
+  double focal_length;      /* FOCAL_LENGTH; ProjectionFactor::sqrt_info = f/1.5 * I */
+  double line_factor;       /* lineProjectionFactor::sqrt_info = line_factor * I */
+  double vp_factor;         /* vpProjectionFactor::sqrt_info = vp_factor * I */
+  double g_norm;            /* G = (0,0,g_norm) */
+  double acc_n, gyr_n, acc_w, gyr_w; /* IMU noise densities (integration_base.h:21-27) */
+  double huber_delta;       /* ceres::HuberLoss(1.0) (estimator.cpp:1048) */
+} vpl_ba_options;
+
+/* Fills the EuRoC values (config/euroc/euroc_config.yaml:55-63,84-91) with
+ * num_iterations = 5 (the BASELINE metric), estimate_extrinsic = 1. */
+void vpl_ba_default_options(vpl_ba_options* opt);
+
+/* Result of IntegrationBase (integration_base.h:9-249) for one keyframe interval. */
+typedef struct vpl_preintegration {
+  double sum_dt;
+  double delta_p[3];
+  double delta_q[4];          /* x,y,z,w */
+  double delta_v[3];
+  double linearized_ba[3];
+  double linearized_bg[3];
+  double jacobian[15 * 15];   /* row-major, state order P,R,V,BA,BG (parameters.h:82-89) */
+  double covariance[15 * 15]; /* row-major */
+} vpl_preintegration;
+
+/* The linearised prior left by MarginalizationInfo (marginalization_factor.h:46-72):
+ * keep_block_{size,idx,data}, linearized_jacobians, linearized_residuals.
+ * Blocks are identified by (kind, frame) instead of by address; the order of
+ * blocks is deterministic (see DESIGN.md "prior ordering"). */
+typedef struct vpl_prior {
+  int n;                                   /* number of residuals = kept local dims */
+  int n_blocks;
+  int block_kind[VPL_MAX_PRIOR_BLOCKS];    /* VPL_BLOCK_* */
+  int block_frame[VPL_MAX_PRIOR_BLOCKS];   /* frame index in the window that will USE the prior */
+  int block_idx[VPL_MAX_PRIOR_BLOCKS];     /* keep_block_idx - m : first local column */
+  double x0[VPL_MAX_PRIOR_BLOCKS][9];      /* keep_block_data (global size 7 or 9) */
+  double J0[VPL_MAX_PRIOR_DIM * VPL_MAX_PRIOR_DIM]; /* linearized_jacobians, row-major n x n */
+  double r0[VPL_MAX_PRIOR_DIM];            /* linearized_residuals */
+} vpl_prior;
+
+/* One sliding window exactly as Estimator::optimizationwithLine() sees it
+ * (estimator.cpp:1043-1453): para_* arrays after vector2double(), the feature
+ * tracks of FeatureManager that pass the reference's filters, pre-integrations
+ * and the last prior.  All arrays are caller-owned host memory. */
+typedef struct vpl_window {
+  double pose[VPL_NFRAMES][7];       /* para_Pose        (in: initial, out: after double2vector2) */
+  double speed_bias[VPL_NFRAMES][9]; /* para_SpeedBias   (in/out) */
+  double ex_pose[7];                 /* para_Ex_Pose[0]  (in/out) */
+
+  /* point tracks: FeaturePerId with used_num>=2 && start_frame<WINDOW_SIZE-2
+   * (estimator.cpp:1100-1102), in f_manager.feature order */
+  int n_points;
+  const int* point_start;   /* [n_points] start_frame */
+  const int* point_nobs;    /* [n_points] feature_per_frame.size(), consecutive frames from start */
+  const double* point_obs;  /* [sum nobs][3]  FeaturePerFrame::point (x,y,1) */
+  double* inv_depth;        /* [n_points] para_Feature (in/out) = 1/estimated_depth */
+
+  /* line tracks: used_num>=LINE_MIN_OBS && start_frame<WINDOW_SIZE-2 && is_triangulation
+   * (estimator.cpp:1132-1133) */
+  int n_lines;
+  const int* line_start;    /* [n_lines] */
+  const int* line_nobs;     /* [n_lines] */
+  const double* line_obs;   /* [sum nobs][8] x1,y1,x2,y2, vp_x,vp_y,vp_z, vp_flag (estimator_node.cpp:375-407) */
+  double* line_plk;         /* [n_lines][6] lineFeaturePerId::line_plucker, start-CAMERA frame (in/out) */
+
+  /* pre_integrations[1..10]; entry 0 unused (estimator.cpp:1085-1093) */
+  vpl_preintegration preint[VPL_NFRAMES];
+
+  int has_prior;            /* last_marginalization_info != nullptr */
+  const vpl_prior* prior;   /* used when has_prior */
+} vpl_window;
+
+/* Per-window solve report (mirrors the fields of ceres::Solver::Summary the
+ * reference could log, plus what the marginalisation produced). */
+typedef struct vpl_solve_report {
+  int iterations;           /* trust-region iterations performed (successful + unsuccessful) */
+  int num_successful_steps;
+  int termination;          /* 0 no_convergence(max iters), 1 convergence, 2 failure */
+  double initial_cost;
+  double final_cost;
+  int n_lines_removed;      /* by removeLineOutlier */
+  int prior_m, prior_n;     /* MarginalizationInfo::m, n */
+} vpl_solve_report;
+
+typedef struct vpl_ctx vpl_ctx; /* opaque: device buffers + stream for one GPU */
+
+/* ---- context ------------------------------------------------------------ */
+/* Creates a context on HIP device `device` sized for up to `max_windows`
+ * windows of up to `max_points` point tracks, `max_point_obs` point
+ * observations, `max_lines` / `max_line_obs` likewise per window. */
+int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, int max_point_obs,
+                   int max_lines, int max_line_obs);
+void vpl_ctx_destroy(vpl_ctx* ctx);
+/* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = default stream). */
+int vpl_ctx_set_stream(vpl_ctx* ctx, void* hip_stream);
+const char* vpl_last_error(const vpl_ctx* ctx);
+
+/* ---- IMU pre-integration  (replaces IntegrationBase::push_back/propagate/
+ *      midPointIntegration, integration_base.h:30-36,54-198) --------------- */
+/* n intervals; interval k has nsamples[k] samples stored at samples + 7*offset[k]
+ * as (dt, ax,ay,az, gx,gy,gz); acc0/gyr0/ba/bg are [n][3]. Host in, host out. */
+int vpl_preintegrate_batch(vpl_ctx* ctx, int n, const int* offset, const int* nsamples,
+                           const double* samples, const double* acc0, const double* gyr0,
+                           const double* lin_ba, const double* lin_bg, const vpl_ba_options* opt,
+                           vpl_preintegration* out);
+
+/* ---- single-factor batch evaluators ------------------------------------- *
+ * Each replaces one CostFunction::Evaluate (signature
+ *   bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const )
+ * for n factors at once.  Parameter blocks are packed contiguously per factor
+ * in the reference's order; residuals [n][R]; jacobians may be NULL, otherwise
+ * row-major blocks concatenated per factor in parameter order.              */
+
+/* ProjectionFactor::Evaluate (projection_factor.cpp:26-126), SizedCostFunction<2,7,7,7,1>.
+ * params [n][22] = pose_i, pose_j, ex_pose, inv_dep ; pts [n][6] = pts_i, pts_j ;
+ * residuals [n][2] ; jac [n][44] = 2x7, 2x7, 2x7, 2x1.  Host pointers. */
+int vpl_projection_factor_evaluate(vpl_ctx* ctx, int n, const double* params, const double* pts,
+                                   double sqrt_info, double* residuals, double* jac);
+/* lineProjectionFactor::Evaluate (line_projection_factor.cpp:251-380), <2,7,7,4>.
+ * params [n][18] = pose, ex_pose, orth ; obs [n][4] ; jac [n][36] = 2x7,2x7,2x4. */
+int vpl_line_factor_evaluate(vpl_ctx* ctx, int n, const double* params, const double* obs,
+                             double sqrt_info, double* residuals, double* jac);
+/* vpProjectionFactor::Evaluate (line_projection_factor.cpp:11-153), <2,7,7,4>. obs [n][3]. */
+int vpl_vp_factor_evaluate(vpl_ctx* ctx, int n, const double* params, const double* vp,
+                           double sqrt_info, double* residuals, double* jac);
+/* IMUFactor::Evaluate (imu_factor.h:23-182), <15,7,9,7,9>.
+ * params [n][32] = pose_i, sb_i, pose_j, sb_j ; jac [n][480] = 15x7,15x9,15x7,15x9. */
+int vpl_imu_factor_evaluate(vpl_ctx* ctx, int n, const double* params, const vpl_preintegration* pre,
+                            double g_norm, double* residuals, double* jac);
+/* MarginalizationFactor::Evaluate (marginalization_factor.cpp:492-542).
+ * params: concatenated kept blocks in prior order (global sizes); residuals [prior->n];
+ * jac: for block b a row-major n x global_size matrix, concatenated in block order. */
+int vpl_prior_factor_evaluate(vpl_ctx* ctx, const vpl_prior* prior, const double* params,
+                              double* residuals, double* jac);
+
+/* PoseLocalParameterization::Plus (pose_local_parameterization.cpp:3-19): x[n][7], delta[n][6]. */
+int vpl_pose_plus(vpl_ctx* ctx, int n, const double* x, const double* delta, double* x_plus_delta);
+/* LineOrthParameterization::Plus (line_parameterization.cpp:7-93): x[n][4], delta[n][4]. */
+int vpl_line_orth_plus(vpl_ctx* ctx, int n, const double* x, const double* delta, double* x_plus_delta);
+
+/* ---- the window solve ---------------------------------------------------- *
+ * Replaces the body of Estimator::optimizationwithLine() (estimator.cpp:1043-1453):
+ * vector2double -> ceres::Solve(DENSE_SCHUR, DOGLEG, max_num_iterations) ->
+ * double2vector2 -> [removeLineOutlier] -> marginalisation -> new prior.
+ *
+ * Three-phase form so that a bench can keep inputs resident in HBM:
+ *   upload  : host windows -> device SoA        (PCIe, not in the timed region)
+ *   solve   : everything on device, no host round trip, asynchronous on the stream
+ *   download: device -> host windows / priors / reports
+ */
+int vpl_ba_upload(vpl_ctx* ctx, int n_windows, const vpl_window* windows, const vpl_ba_options* opt);
+int vpl_ba_solve(vpl_ctx* ctx);           /* enqueue one batched solve of the uploaded windows */
+int vpl_ba_reset_state(vpl_ctx* ctx);     /* restore the uploaded initial states on device (for repeated timing) */
+int vpl_ba_download(vpl_ctx* ctx, int n_windows, vpl_window* windows, vpl_prior* priors_out,
+                    vpl_solve_report* reports);
+int vpl_ctx_synchronize(vpl_ctx* ctx);
+
+/* Convenience: upload + solve + synchronize + download. */
+int vpl_ba_solve_windows(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt,
+                         vpl_prior* priors_out, vpl_solve_report* reports);
+
+/* ---- instrumentation (bench.py) ------------------------------------------ */
+/* Per-kernel device time of the last solve measured with hipEvents on the
+ * context's stream. names/ms arrays of length *count on input; count updated. */
+int vpl_ba_enable_kernel_timing(vpl_ctx* ctx, int enable);
+int vpl_ba_kernel_times(vpl_ctx* ctx, int* count, const char** names, double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPLINES_BA_H */

@@ -1,0 +1,504 @@
+// TEST INFRASTRUCTURE -- CPU oracle (see smallmat.h).
+// Restates the body of Estimator::optimizationwithLine()
+//   vins_estimator/src/estimator.cpp:1043-1453
+// with vector2double (:650-705), double2vector2 (:810-900),
+// FeatureManager::{getLineOrthVector,setLineOrth,removeLineOutlier}
+//   (feature_manager.cpp:341-388,702-798)
+// over the window container of include/vplines_ba.h (data format only; no
+// product code is linked here).
+#include <array>
+#include "../include/vplines_ba.h"
+#include "marginalization.h"
+#include "problem.h"
+
+namespace orc {
+
+namespace {
+
+struct LineTrack {
+  int start_frame;
+  std::vector<Mat<8, 1>> obs;  // lineobs (4) + lineobs_vp (4)
+  Vec6 line_plucker;           // start camera frame
+};
+struct PointTrack {
+  int start_frame;
+  std::vector<Vec3> obs;
+  double estimated_depth;
+  int solve_flag = 0;
+};
+
+// The slice of Estimator state that optimizationwithLine touches.  Member order
+// of the para_* arrays follows estimator.h:139-143 (it defines the block order
+// of the marginalisation, see marginalization.h).
+struct Est {
+  Vec3 Ps[VPL_NFRAMES], Vs[VPL_NFRAMES], Bas[VPL_NFRAMES], Bgs[VPL_NFRAMES];
+  Mat3 Rs[VPL_NFRAMES];
+  Vec3 tic;
+  Mat3 ric;
+  std::vector<PointTrack> feature;
+  std::vector<LineTrack> linefeature;
+  IntegrationBase* pre_integrations[VPL_NFRAMES] = {nullptr};
+  Vec3 G;
+
+  double para_Pose[VPL_NFRAMES][7];
+  double para_SpeedBias[VPL_NFRAMES][9];
+  std::vector<std::array<double, 1>> para_Feature;
+  std::vector<std::array<double, 4>> para_LineFeature;
+  double para_Ex_Pose[1][7];
+
+  MarginalizationInfo* last_marginalization_info = nullptr;
+  std::vector<double*> last_marginalization_parameter_blocks;
+
+  ~Est() {
+    for (auto* p : pre_integrations) delete p;
+    delete last_marginalization_info;
+  }
+
+  // estimator.cpp:650-705
+  void vector2double() {
+    for (int i = 0; i <= VPL_WINDOW_SIZE; i++) {
+      para_Pose[i][0] = Ps[i][0]; para_Pose[i][1] = Ps[i][1]; para_Pose[i][2] = Ps[i][2];
+      Quat q = Quat::fromRotationMatrix(Rs[i]);
+      para_Pose[i][3] = q.x; para_Pose[i][4] = q.y; para_Pose[i][5] = q.z; para_Pose[i][6] = q.w;
+      for (int k = 0; k < 3; ++k) {
+        para_SpeedBias[i][k] = Vs[i][k];
+        para_SpeedBias[i][3 + k] = Bas[i][k];
+        para_SpeedBias[i][6 + k] = Bgs[i][k];
+      }
+    }
+    para_Ex_Pose[0][0] = tic[0]; para_Ex_Pose[0][1] = tic[1]; para_Ex_Pose[0][2] = tic[2];
+    Quat q = Quat::fromRotationMatrix(ric);
+    para_Ex_Pose[0][3] = q.x; para_Ex_Pose[0][4] = q.y; para_Ex_Pose[0][5] = q.z; para_Ex_Pose[0][6] = q.w;
+    // getDepthVector (feature_manager.cpp:277-293)
+    for (size_t i = 0; i < feature.size(); ++i) para_Feature[i][0] = 1. / feature[i].estimated_depth;
+    // getLineOrthVector (feature_manager.cpp:341-365)
+    for (size_t i = 0; i < linefeature.size(); ++i) {
+      int imu_i = linefeature[i].start_frame;
+      Vec3 twc = Ps[imu_i] + Rs[imu_i] * tic;
+      Mat3 Rwc = Rs[imu_i] * ric;
+      Vec6 line_w = plk_to_pose(linefeature[i].line_plucker, Rwc, twc);
+      Vec4 o = plk_to_orth(line_w);
+      for (int k = 0; k < 4; ++k) para_LineFeature[i][k] = o[k];
+    }
+  }
+
+  // estimator.cpp:810-900
+  void double2vector2() {
+    Vec3 origin_R0 = R2ypr(Rs[0]);
+    Vec3 origin_P0 = Ps[0];
+    Vec3 origin_R00 = R2ypr(Quat(para_Pose[0][6], para_Pose[0][3], para_Pose[0][4], para_Pose[0][5]).toRotationMatrix());
+    double y_diff = origin_R0[0] - origin_R00[0];
+    Mat3 rot_diff = ypr2R(Vec3{y_diff, 0, 0});
+    for (int i = 0; i <= VPL_WINDOW_SIZE; i++) {
+      Rs[i] = rot_diff * Quat(para_Pose[i][6], para_Pose[i][3], para_Pose[i][4], para_Pose[i][5]).normalized().toRotationMatrix();
+      Ps[i] = rot_diff * Vec3{para_Pose[i][0] - para_Pose[0][0], para_Pose[i][1] - para_Pose[0][1], para_Pose[i][2] - para_Pose[0][2]} + origin_P0;
+      Vs[i] = rot_diff * Vec3{para_SpeedBias[i][0], para_SpeedBias[i][1], para_SpeedBias[i][2]};
+      Bas[i] = Vec3{para_SpeedBias[i][3], para_SpeedBias[i][4], para_SpeedBias[i][5]};
+      Bgs[i] = Vec3{para_SpeedBias[i][6], para_SpeedBias[i][7], para_SpeedBias[i][8]};
+    }
+    tic = Vec3{para_Ex_Pose[0][0], para_Ex_Pose[0][1], para_Ex_Pose[0][2]};
+    ric = Quat(para_Ex_Pose[0][6], para_Ex_Pose[0][3], para_Ex_Pose[0][4], para_Ex_Pose[0][5]).toRotationMatrix();
+
+    Mat3 Rwow1 = rot_diff;
+    Vec3 tw1b{para_Pose[0][0], para_Pose[0][1], para_Pose[0][2]};
+    Vec3 twow1 = -(Rwow1 * tw1b) + origin_P0;
+    for (size_t i = 0; i < linefeature.size(); ++i) {
+      Vec4 orth{para_LineFeature[i][0], para_LineFeature[i][1], para_LineFeature[i][2], para_LineFeature[i][3]};
+      Vec6 line_w1 = orth_to_plk(orth);
+      Vec6 line_wo = plk_to_pose(line_w1, Rwow1, twow1);
+      orth = plk_to_orth(line_wo);
+      // setLineOrth (feature_manager.cpp:367-388)
+      Vec6 line_w = orth_to_plk(orth);
+      int imu_i = linefeature[i].start_frame;
+      Vec3 twc = Ps[imu_i] + Rs[imu_i] * tic;
+      Mat3 Rwc = Rs[imu_i] * ric;
+      linefeature[i].line_plucker = plk_from_pose(line_w, Rwc, twc);
+    }
+    // setDepth (feature_manager.cpp:229-251)
+    for (size_t i = 0; i < feature.size(); ++i) {
+      feature[i].estimated_depth = 1.0 / para_Feature[i][0];
+      feature[i].solve_flag = feature[i].estimated_depth < 0 ? 2 : 1;
+    }
+  }
+
+  // feature_manager.cpp:390-411
+  static double reprojection_error(const Vec4& obs, const Mat3& Rwc, const Vec3& twc, const Vec6& line_w) {
+    Vec3 p1{obs[0], obs[1], 1}, p2{obs[2], obs[3], 1};
+    Vec6 line_c = plk_from_pose(line_w, Rwc, twc);
+    Vec3 nc{line_c[0], line_c[1], line_c[2]};
+    double sql = std::sqrt(nc[0] * nc[0] + nc[1] * nc[1]);
+    nc = nc / sql;
+    return (std::fabs(nc.dot(p1)) + std::fabs(nc.dot(p2))) / 2.0;
+  }
+
+  // feature_manager.cpp:702-798 ; returns the number of erased lines
+  int removeLineOutlier(std::vector<int>* removed_index) {
+    int removed = 0;
+    std::vector<LineTrack> kept;
+    for (size_t li = 0; li < linefeature.size(); ++li) {
+      LineTrack& L = linefeature[li];
+      int imu_i = L.start_frame, imu_j = imu_i - 1;
+      Vec3 twc = Ps[imu_i] + Rs[imu_i] * tic;
+      Mat3 Rwc = Rs[imu_i] * ric;
+      Vec3 nc{L.line_plucker[0], L.line_plucker[1], L.line_plucker[2]};
+      Vec3 vc{L.line_plucker[3], L.line_plucker[4], L.line_plucker[5]};
+      Mat<4, 4> Lc;
+      Lc.setBlock<3, 3>(0, 0, skew(nc));
+      for (int k = 0; k < 3; ++k) { Lc(k, 3) = vc[k]; Lc(3, k) = -vc[k]; }
+      const Mat<8, 1>& o0 = L.obs[0];
+      Vec3 p11{o0[0], o0[1], 1.0}, p21{o0[2], o0[3], 1.0};
+      Vec3 cr = cross(p11, p21);
+      Vec2 ln{cr[0], cr[1]};
+      ln = ln / ln.norm();
+      Vec3 p12{p11[0] + ln[0], p11[1] + ln[1], 1.0};
+      Vec3 p22{p21[0] + ln[0], p21[1] + ln[1], 1.0};
+      Vec3 cam{0, 0, 0};
+      Vec4 pi1 = pi_from_ppp(cam, p11, p12);
+      Vec4 pi2 = pi_from_ppp(cam, p21, p22);
+      Vec4 e1 = Lc * pi1, e2 = Lc * pi2;
+      e1 = e1 / e1[3];
+      e2 = e2 / e2[3];
+      bool erase = false;
+      if (e1[2] < 0 || e2[2] < 0) erase = true;
+      else if ((e1 - e2).norm() > 10) erase = true;
+      else {
+        Vec6 line_w = plk_to_pose(L.line_plucker, Rwc, twc);
+        double allerr = 0;
+        for (auto& ob : L.obs) {
+          imu_j++;
+          Vec4 obs{ob[0], ob[1], ob[2], ob[3]};
+          Vec3 t1 = Ps[imu_j] + Rs[imu_j] * tic;
+          Mat3 R1 = Rs[imu_j] * ric;
+          double err = reprojection_error(obs, R1, t1, line_w);
+          if (allerr < err) allerr = err;
+        }
+        if (allerr > 3.0 / 500.0) erase = true;
+      }
+      if (erase) { ++removed; if (removed_index) removed_index->push_back((int)li); }
+      else kept.push_back(L);
+    }
+    linefeature.swap(kept);
+    para_LineFeature.resize(linefeature.size());
+    return removed;
+  }
+};
+
+void load_window(const vpl_window& w, const vpl_ba_options& opt, Est& e) {
+  for (int i = 0; i < VPL_NFRAMES; ++i) {
+    e.Ps[i] = Vec3{w.pose[i][0], w.pose[i][1], w.pose[i][2]};
+    e.Rs[i] = Quat(w.pose[i][6], w.pose[i][3], w.pose[i][4], w.pose[i][5]).normalized().toRotationMatrix();
+    e.Vs[i] = Vec3{w.speed_bias[i][0], w.speed_bias[i][1], w.speed_bias[i][2]};
+    e.Bas[i] = Vec3{w.speed_bias[i][3], w.speed_bias[i][4], w.speed_bias[i][5]};
+    e.Bgs[i] = Vec3{w.speed_bias[i][6], w.speed_bias[i][7], w.speed_bias[i][8]};
+  }
+  e.tic = Vec3{w.ex_pose[0], w.ex_pose[1], w.ex_pose[2]};
+  e.ric = Quat(w.ex_pose[6], w.ex_pose[3], w.ex_pose[4], w.ex_pose[5]).normalized().toRotationMatrix();
+  e.G = Vec3{0, 0, opt.g_norm};
+  int off = 0;
+  for (int i = 0; i < w.n_points; ++i) {
+    PointTrack t;
+    t.start_frame = w.point_start[i];
+    for (int k = 0; k < w.point_nobs[i]; ++k, ++off)
+      t.obs.push_back(Vec3{w.point_obs[3 * off], w.point_obs[3 * off + 1], w.point_obs[3 * off + 2]});
+    t.estimated_depth = 1.0 / w.inv_depth[i];
+    e.feature.push_back(t);
+  }
+  off = 0;
+  for (int i = 0; i < w.n_lines; ++i) {
+    LineTrack t;
+    t.start_frame = w.line_start[i];
+    for (int k = 0; k < w.line_nobs[i]; ++k, ++off) {
+      Mat<8, 1> o;
+      for (int c = 0; c < 8; ++c) o[c] = w.line_obs[8 * off + c];
+      t.obs.push_back(o);
+    }
+    for (int c = 0; c < 6; ++c) t.line_plucker[c] = w.line_plk[6 * i + c];
+    e.linefeature.push_back(t);
+  }
+  e.para_Feature.resize(e.feature.size());
+  e.para_LineFeature.resize(e.linefeature.size());
+  ImuNoise nz{opt.acc_n, opt.gyr_n, opt.acc_w, opt.gyr_w};
+  for (int j = 1; j < VPL_NFRAMES; ++j) {
+    const vpl_preintegration& p = w.preint[j];
+    IntegrationBase* ib = new IntegrationBase(Vec3{}, Vec3{}, Vec3{p.linearized_ba[0], p.linearized_ba[1], p.linearized_ba[2]},
+                                              Vec3{p.linearized_bg[0], p.linearized_bg[1], p.linearized_bg[2]}, nz);
+    ib->sum_dt = p.sum_dt;
+    ib->delta_p = Vec3{p.delta_p[0], p.delta_p[1], p.delta_p[2]};
+    ib->delta_q = Quat(p.delta_q[3], p.delta_q[0], p.delta_q[1], p.delta_q[2]);
+    ib->delta_v = Vec3{p.delta_v[0], p.delta_v[1], p.delta_v[2]};
+    for (int k = 0; k < 225; ++k) { ib->jacobian.a[k] = p.jacobian[k]; ib->covariance.a[k] = p.covariance[k]; }
+    e.pre_integrations[j] = ib;
+  }
+  if (w.has_prior && w.prior) {
+    const vpl_prior& pr = *w.prior;
+    MarginalizationInfo* mi = new MarginalizationInfo();
+    mi->n = pr.n;
+    mi->m = 0;
+    mi->linearized_jacobians.resize(pr.n, pr.n);
+    for (int r = 0; r < pr.n; ++r)
+      for (int c = 0; c < pr.n; ++c) mi->linearized_jacobians(r, c) = pr.J0[(size_t)r * pr.n + c];
+    mi->linearized_residuals.assign(pr.r0, pr.r0 + pr.n);
+    mi->owned_keep_data.resize(pr.n_blocks);
+    for (int b = 0; b < pr.n_blocks; ++b) {
+      int size = pr.block_kind[b] == VPL_BLOCK_SPEEDBIAS ? 9 : 7;
+      mi->keep_block_size.push_back(size);
+      mi->keep_block_idx.push_back(pr.block_idx[b]);
+      mi->owned_keep_data[b].assign(pr.x0[b], pr.x0[b] + size);
+    }
+    for (int b = 0; b < pr.n_blocks; ++b) {
+      mi->keep_block_data.push_back(mi->owned_keep_data[b].data());
+      double* addr = pr.block_kind[b] == VPL_BLOCK_POSE ? e.para_Pose[pr.block_frame[b]]
+                     : pr.block_kind[b] == VPL_BLOCK_SPEEDBIAS ? e.para_SpeedBias[pr.block_frame[b]]
+                                                                : e.para_Ex_Pose[0];
+      e.last_marginalization_parameter_blocks.push_back(addr);
+    }
+    e.last_marginalization_info = mi;
+  }
+}
+
+void export_prior(Est& e, const std::vector<double*>& blocks, vpl_prior* out) {
+  MarginalizationInfo* mi = e.last_marginalization_info;
+  std::memset(out, 0, sizeof(*out));
+  out->n = mi->n;
+  out->n_blocks = (int)blocks.size();
+  for (size_t b = 0; b < blocks.size(); ++b) {
+    double* a = blocks[b];
+    int kind = -1, frame = 0;
+    for (int i = 0; i < VPL_NFRAMES; ++i) {
+      if (a == e.para_Pose[i]) { kind = VPL_BLOCK_POSE; frame = i; }
+      if (a == e.para_SpeedBias[i]) { kind = VPL_BLOCK_SPEEDBIAS; frame = i; }
+    }
+    if (a == e.para_Ex_Pose[0]) { kind = VPL_BLOCK_EXPOSE; frame = 0; }
+    out->block_kind[b] = kind;
+    out->block_frame[b] = frame;
+    out->block_idx[b] = mi->keep_block_idx[b] - mi->m;
+    for (int k = 0; k < mi->keep_block_size[b]; ++k) out->x0[b][k] = mi->keep_block_data[b][k];
+  }
+  for (int r = 0; r < mi->n; ++r) {
+    out->r0[r] = mi->linearized_residuals[r];
+    for (int c = 0; c < mi->n; ++c) out->J0[(size_t)r * mi->n + c] = mi->linearized_jacobians(r, c);
+  }
+}
+
+}  // namespace
+
+// Estimator::optimizationwithLine, estimator.cpp:1043-1453
+int solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_out, vpl_solve_report* rep,
+                 double* A_final_out /* optional n*n */, double* b_final_out /* optional n */) {
+  Est e;
+  load_window(*w, *opt, e);
+  ProjectionFactor::sqrt_info = opt->focal_length / 1.5;   // estimator.cpp:18
+  lineProjectionFactor::sqrt_info = opt->line_factor;      // :19
+  vpProjectionFactor::sqrt_info = opt->vp_factor;          // :20
+  vpl_solve_report report;
+  std::memset(&report, 0, sizeof(report));
+
+  LossFunction* loss_function = new HuberLoss(opt->huber_delta);
+  {
+    Problem problem;
+    for (int i = 0; i < VPL_WINDOW_SIZE + 1; i++) {
+      problem.AddParameterBlock(e.para_Pose[i], 7, new PoseLocalParameterization());
+      problem.AddParameterBlock(e.para_SpeedBias[i], 9);
+    }
+    problem.AddParameterBlock(e.para_Ex_Pose[0], 7, new PoseLocalParameterization());
+    if (!opt->estimate_extrinsic) problem.SetParameterBlockConstant(e.para_Ex_Pose[0]);
+
+    e.vector2double();
+
+    if (e.last_marginalization_info) {
+      MarginalizationFactor* mf = new MarginalizationFactor(e.last_marginalization_info);
+      problem.AddResidualBlock(mf, nullptr, e.last_marginalization_parameter_blocks);
+    }
+    for (int i = 0; i < VPL_WINDOW_SIZE; i++) {
+      int j = i + 1;
+      if (e.pre_integrations[j]->sum_dt > 10.0) continue;
+      problem.AddResidualBlock(new IMUFactor(e.pre_integrations[j], e.G), nullptr,
+                               {e.para_Pose[i], e.para_SpeedBias[i], e.para_Pose[j], e.para_SpeedBias[j]});
+    }
+    int feature_index = -1;
+    for (auto& it_per_id : e.feature) {
+      ++feature_index;
+      int imu_i = it_per_id.start_frame, imu_j = imu_i - 1;
+      Vec3 pts_i = it_per_id.obs[0];
+      for (auto& pts_j : it_per_id.obs) {
+        imu_j++;
+        if (imu_i == imu_j) continue;
+        problem.AddResidualBlock(new ProjectionFactor(pts_i, pts_j), loss_function,
+                                 {e.para_Pose[imu_i], e.para_Pose[imu_j], e.para_Ex_Pose[0], e.para_Feature[feature_index].data()});
+      }
+    }
+    int linefeature_index = -1;
+    for (auto& it_per_id : e.linefeature) {
+      ++linefeature_index;
+      problem.AddParameterBlock(e.para_LineFeature[linefeature_index].data(), 4, new LineOrthParameterization());
+      int imu_i = it_per_id.start_frame, imu_j = imu_i - 1;
+      for (auto& ob : it_per_id.obs) {
+        imu_j++;
+        Vec4 obs{ob[0], ob[1], ob[2], ob[3]};
+        problem.AddResidualBlock(new lineProjectionFactor(obs), loss_function,
+                                 {e.para_Pose[imu_j], e.para_Ex_Pose[0], e.para_LineFeature[linefeature_index].data()});
+        if (ob[7] == 1.0) {
+          Vec3 vp_obs{ob[4], ob[5], ob[6]};
+          problem.AddResidualBlock(new vpProjectionFactor(vp_obs), loss_function,
+                                   {e.para_Pose[imu_j], e.para_Ex_Pose[0], e.para_LineFeature[linefeature_index].data()});
+        }
+      }
+    }
+    SolverOptions options;
+    options.max_num_iterations = opt->num_iterations;
+    SolverSummary summary;
+    // the prior factor and the loss are owned elsewhere (marginalization info / below)
+    Solve(options, &problem, &summary);
+    report.iterations = (int)summary.iterations.size() - 1;
+    report.num_successful_steps = summary.num_successful_steps - 1;
+    report.termination = (int)summary.termination_type;
+    report.initial_cost = summary.initial_cost;
+    report.final_cost = summary.final_cost;
+    // detach objects the problem must not free
+    for (auto& rb : problem.residuals_) {
+      if (rb.loss == loss_function) rb.loss = nullptr;
+    }
+  }
+
+  e.double2vector2();
+  if (opt->remove_line_outliers) report.n_lines_removed = e.removeLineOutlier(nullptr);
+
+  if (opt->marginalization_flag == VPL_MARGIN_OLD) {
+    MarginalizationInfo* marginalization_info = new MarginalizationInfo();
+    e.vector2double();
+    if (e.last_marginalization_info) {
+      std::vector<int> drop_set;
+      for (int i = 0; i < (int)e.last_marginalization_parameter_blocks.size(); i++)
+        if (e.last_marginalization_parameter_blocks[i] == e.para_Pose[0] ||
+            e.last_marginalization_parameter_blocks[i] == e.para_SpeedBias[0])
+          drop_set.push_back(i);
+      MarginalizationFactor* mf = new MarginalizationFactor(e.last_marginalization_info);
+      marginalization_info->addResidualBlockInfo(
+          new ResidualBlockInfo(mf, nullptr, e.last_marginalization_parameter_blocks, drop_set));
+    }
+    if (e.pre_integrations[1]->sum_dt < 10.0) {
+      marginalization_info->addResidualBlockInfo(new ResidualBlockInfo(
+          new IMUFactor(e.pre_integrations[1], e.G), nullptr,
+          std::vector<double*>{e.para_Pose[0], e.para_SpeedBias[0], e.para_Pose[1], e.para_SpeedBias[1]},
+          std::vector<int>{0, 1}));
+    }
+    {
+      int feature_index = -1;
+      for (auto& it_per_id : e.feature) {
+        ++feature_index;
+        int imu_i = it_per_id.start_frame, imu_j = imu_i - 1;
+        if (imu_i != 0) continue;
+        Vec3 pts_i = it_per_id.obs[0];
+        for (auto& pts_j : it_per_id.obs) {
+          imu_j++;
+          if (imu_i == imu_j) continue;
+          marginalization_info->addResidualBlockInfo(new ResidualBlockInfo(
+              new ProjectionFactor(pts_i, pts_j), loss_function,
+              std::vector<double*>{e.para_Pose[imu_i], e.para_Pose[imu_j], e.para_Ex_Pose[0], e.para_Feature[feature_index].data()},
+              std::vector<int>{0, 3}));
+        }
+      }
+    }
+    {
+      int linefeature_index = -1;
+      for (auto& it_per_id : e.linefeature) {
+        ++linefeature_index;
+        int imu_i = it_per_id.start_frame, imu_j = imu_i - 1;
+        if (imu_i != 0) continue;
+        for (auto& ob : it_per_id.obs) {
+          imu_j++;
+          if (imu_i == imu_j) continue;
+          Vec4 obs{ob[0], ob[1], ob[2], ob[3]};
+          marginalization_info->addResidualBlockInfo(new ResidualBlockInfo(
+              new lineProjectionFactor(obs), loss_function,
+              std::vector<double*>{e.para_Pose[imu_j], e.para_Ex_Pose[0], e.para_LineFeature[linefeature_index].data()},
+              std::vector<int>{2}));
+          // estimator.cpp:1341-1353: the VP factor is added to the already solved ceres
+          // problem, NOT to marginalization_info -- it has no effect and is not restated.
+        }
+      }
+    }
+    marginalization_info->preMarginalize();
+    marginalization_info->marginalize();
+
+    std::map<long, double*> addr_shift;
+    for (int i = 1; i <= VPL_WINDOW_SIZE; i++) {
+      addr_shift[reinterpret_cast<long>(e.para_Pose[i])] = e.para_Pose[i - 1];
+      addr_shift[reinterpret_cast<long>(e.para_SpeedBias[i])] = e.para_SpeedBias[i - 1];
+    }
+    addr_shift[reinterpret_cast<long>(e.para_Ex_Pose[0])] = e.para_Ex_Pose[0];
+    std::vector<double*> parameter_blocks = marginalization_info->getParameterBlocks(addr_shift);
+    // the old info is referenced by the MarginalizationFactor just added: the reference
+    // deletes it here as well (estimator.cpp:1379-1381); safe because Evaluate already ran.
+    if (e.last_marginalization_info) {
+      // the new info owns a MarginalizationFactor pointing at the old info; null the pointer use
+      delete e.last_marginalization_info;
+    }
+    e.last_marginalization_info = marginalization_info;
+    e.last_marginalization_parameter_blocks = parameter_blocks;
+    report.prior_m = marginalization_info->m;
+    report.prior_n = marginalization_info->n;
+    if (prior_out) export_prior(e, parameter_blocks, prior_out);
+    if (A_final_out)
+      for (int r = 0; r < marginalization_info->n; ++r)
+        for (int c = 0; c < marginalization_info->n; ++c)
+          A_final_out[(size_t)r * marginalization_info->n + c] = marginalization_info->A_final(r, c);
+    if (b_final_out)
+      for (int r = 0; r < marginalization_info->n; ++r) b_final_out[r] = marginalization_info->b_final[r];
+  } else if (opt->marginalization_flag == VPL_MARGIN_SECOND_NEW) {
+    // estimator.cpp:1385-1447
+    bool has = false;
+    for (double* b : e.last_marginalization_parameter_blocks)
+      if (b == e.para_Pose[VPL_WINDOW_SIZE - 1]) has = true;
+    if (e.last_marginalization_info && has) {
+      MarginalizationInfo* marginalization_info = new MarginalizationInfo();
+      e.vector2double();
+      std::vector<int> drop_set;
+      for (int i = 0; i < (int)e.last_marginalization_parameter_blocks.size(); i++)
+        if (e.last_marginalization_parameter_blocks[i] == e.para_Pose[VPL_WINDOW_SIZE - 1]) drop_set.push_back(i);
+      MarginalizationFactor* mf = new MarginalizationFactor(e.last_marginalization_info);
+      marginalization_info->addResidualBlockInfo(
+          new ResidualBlockInfo(mf, nullptr, e.last_marginalization_parameter_blocks, drop_set));
+      marginalization_info->preMarginalize();
+      marginalization_info->marginalize();
+      std::map<long, double*> addr_shift;
+      for (int i = 0; i <= VPL_WINDOW_SIZE; i++) {
+        if (i == VPL_WINDOW_SIZE - 1) continue;
+        else if (i == VPL_WINDOW_SIZE) {
+          addr_shift[reinterpret_cast<long>(e.para_Pose[i])] = e.para_Pose[i - 1];
+          addr_shift[reinterpret_cast<long>(e.para_SpeedBias[i])] = e.para_SpeedBias[i - 1];
+        } else {
+          addr_shift[reinterpret_cast<long>(e.para_Pose[i])] = e.para_Pose[i];
+          addr_shift[reinterpret_cast<long>(e.para_SpeedBias[i])] = e.para_SpeedBias[i];
+        }
+      }
+      addr_shift[reinterpret_cast<long>(e.para_Ex_Pose[0])] = e.para_Ex_Pose[0];
+      std::vector<double*> parameter_blocks = marginalization_info->getParameterBlocks(addr_shift);
+      delete e.last_marginalization_info;
+      e.last_marginalization_info = marginalization_info;
+      e.last_marginalization_parameter_blocks = parameter_blocks;
+      report.prior_m = marginalization_info->m;
+      report.prior_n = marginalization_info->n;
+      if (prior_out) export_prior(e, parameter_blocks, prior_out);
+    } else if (prior_out) {
+      std::memset(prior_out, 0, sizeof(*prior_out));
+    }
+  }
+  delete loss_function;
+
+  // write the state back in para_* form (what the next vector2double() would produce)
+  e.vector2double();
+  for (int i = 0; i < VPL_NFRAMES; ++i) {
+    for (int k = 0; k < 7; ++k) w->pose[i][k] = e.para_Pose[i][k];
+    for (int k = 0; k < 9; ++k) w->speed_bias[i][k] = e.para_SpeedBias[i][k];
+  }
+  for (int k = 0; k < 7; ++k) w->ex_pose[k] = e.para_Ex_Pose[0][k];
+  for (size_t i = 0; i < e.feature.size(); ++i) w->inv_depth[i] = 1.0 / e.feature[i].estimated_depth;
+  if (!opt->remove_line_outliers)
+    for (size_t i = 0; i < e.linefeature.size(); ++i)
+      for (int c = 0; c < 6; ++c) w->line_plk[6 * i + c] = e.linefeature[i].line_plucker[c];
+  if (rep) *rep = report;
+  return 0;
+}
+
+}  // namespace orc
