@@ -43,7 +43,7 @@ def build_hip(force=False, verbose=False):
             deps.append(p)
     if not force and not _newer(HIP_LIB, deps):
         return HIP_LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_LIB] + srcs
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

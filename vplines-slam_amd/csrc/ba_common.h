@@ -1,0 +1,82 @@
+// Block / wave level helpers shared by the BA kernels (wave64, gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ba_types.h"
+#include "vpl_math.h"
+
+namespace vpl {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sum over the whole workgroup; `red` is LDS scratch of >= 17 doubles; result broadcast
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    red[16] = s;
+  }
+  __syncthreads();
+  return red[16];
+}
+
+// hardware LDS f64 add (ds_add_f64)
+__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// cam index -> vis index or -1
+__device__ __forceinline__ int cam2vis(int c) {
+  if (c >= 165) return 66 + (c - 165);
+  int o = c % 15;
+  return o < 6 ? 6 * (c / 15) + o : -1;
+}
+
+// decode a packed lower-triangular index into (r, c), r >= c
+__device__ __forceinline__ void tri_decode(int idx, int& r, int& c) {
+  int rr = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+  while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
+  while (rr * (rr + 1) / 2 > idx) --rr;
+  r = rr;
+  c = idx - rr * (rr + 1) / 2;
+}
+
+__device__ __forceinline__ PreInt load_preint(const DevPreint& d) {
+  PreInt p;
+  p.sum_dt = d.sum_dt;
+  p.dp = V3{d.dp[0], d.dp[1], d.dp[2]};
+  p.dv = V3{d.dv[0], d.dv[1], d.dv[2]};
+  p.dq = Q4{d.dq[3], d.dq[0], d.dq[1], d.dq[2]};
+  p.lba = V3{d.lba[0], d.lba[1], d.lba[2]};
+  p.lbg = V3{d.lbg[0], d.lbg[1], d.lbg[2]};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    p.dp_dba.m[k] = d.dp_dba[k];
+    p.dp_dbg.m[k] = d.dp_dbg[k];
+    p.dq_dbg.m[k] = d.dq_dbg[k];
+    p.dv_dba.m[k] = d.dv_dba[k];
+    p.dv_dbg.m[k] = d.dv_dbg[k];
+  }
+  return p;
+}
+
+// dx of one kept prior block (MarginalizationFactor::Evaluate, marginalization_factor.cpp:502-520)
+__device__ __forceinline__ void prior_block_dx(int kind, const double* x, const double* x0, double* dx) {
+  if (kind == 1) {  // speed/bias: plain difference
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dx[k] = x[k] - x0[k];
+  } else {
+    dx[0] = x[0] - x0[0]; dx[1] = x[1] - x0[1]; dx[2] = x[2] - x0[2];
+    Q4 dq = qmul(qinv(qpose(x0)), qpose(x));
+    double sgn = (dq.w >= 0) ? 2.0 : -2.0;
+    dx[3] = sgn * dq.x; dx[4] = sgn * dq.y; dx[5] = sgn * dq.z;
+  }
+}
+
+}  // namespace vpl

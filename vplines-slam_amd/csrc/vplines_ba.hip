@@ -1,0 +1,621 @@
+// C ABI of the MI355X-native bundle-adjustment path (include/vplines_ba.h).
+// Host side: packs caller-owned windows into the device SoA of ba_types.h, enqueues the
+// kernel sequence of one batched solve on the context's stream, unpacks results.
+// There is no CPU compute path in this library: every entry point that computes launches
+// HIP kernels and reports VPL_E_NODEVICE / VPL_E_HIP when that is impossible.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vplines_ba.h"
+#include "ba_types.h"
+#include "ba_lin.h"
+#include "ba_solve.h"
+#include "ba_marg.h"
+#include "ba_factors.h"
+
+using namespace vpl;
+
+struct vpl_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int maxW = 0, maxP = 0, maxPO = 0, maxL = 0, maxLO = 0;
+  DevBatch B;
+  std::vector<void*> allocs;
+  int nW = 0;
+  vpl_ba_options opt;
+  std::string err;
+  bool timing = false;
+  std::map<std::string, std::pair<double, int>> ktimes;
+  std::vector<std::string> kname_store;
+  // host-side marg structure of the uploaded windows
+  std::vector<int> h_mg_m;
+  std::vector<int> h_nP, h_nL;
+};
+
+static int fail(vpl_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+#define HIPCHK(ctx, call)                                                                         \
+  do {                                                                                            \
+    hipError_t e__ = (call);                                                                      \
+    if (e__ != hipSuccess) return fail(ctx, VPL_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+template <typename T>
+static hipError_t dalloc(vpl_ctx* c, T** p, size_t n) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, n * sizeof(T) + 64);
+  if (e != hipSuccess) return e;
+  e = hipMemset(q, 0, n * sizeof(T) + 64);
+  c->allocs.push_back(q);
+  *p = (T*)q;
+  return e;
+}
+
+// ---- helpers -----------------------------------------------------------------------------------
+static void to_dev_preint(const vpl_preintegration& p, DevPreint& d) {
+  d.sum_dt = p.sum_dt;
+  for (int k = 0; k < 3; ++k) { d.dp[k] = p.delta_p[k]; d.dv[k] = p.delta_v[k]; d.lba[k] = p.linearized_ba[k]; d.lbg[k] = p.linearized_bg[k]; }
+  for (int k = 0; k < 4; ++k) d.dq[k] = p.delta_q[k];
+  auto blk = [&](double* o, int r0, int c0) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) o[3 * i + j] = p.jacobian[(r0 + i) * 15 + c0 + j];
+  };
+  blk(d.dp_dba, 0, 9); blk(d.dp_dbg, 0, 12); blk(d.dq_dbg, 3, 12); blk(d.dv_dba, 6, 9); blk(d.dv_dbg, 6, 12);
+  std::memcpy(d.cov, p.covariance, sizeof(d.cov));
+  std::memset(d.sqrt_info, 0, sizeof(d.sqrt_info));
+}
+
+template <typename T>
+static hipError_t up(vpl_ctx* c, T* dst, const std::vector<T>& src) {
+  if (src.empty()) return hipSuccess;
+  return hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, c->stream);
+}
+
+struct KTimer {
+  vpl_ctx* c;
+  const char* name;
+  hipEvent_t a = nullptr, b = nullptr;
+  KTimer(vpl_ctx* c_, const char* n) : c(c_), name(n) {
+    if (c->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+  }
+  ~KTimer() {
+    if (c->timing) {
+      hipEventRecord(b, c->stream);
+      hipEventSynchronize(b);
+      float ms = 0;
+      hipEventElapsedTime(&ms, a, b);
+      auto& e = c->ktimes[name];
+      e.first += ms;
+      e.second += 1;
+      hipEventDestroy(a);
+      hipEventDestroy(b);
+    }
+  }
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  double* d() { return (double*)p; }
+};
+
+template <typename Launch>
+static int eval_generic(vpl_ctx* c, int n, const double* params, int psz, const double* consts, int csz, int nres,
+                        int njac, double* residuals, double* jac, Launch launch) {
+  if (!c || n < 0 || !params || !consts || !residuals) return VPL_E_INVALID;
+  if (n == 0) return VPL_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf dp, dc, dr, dj;
+  HIPCHK(c, dp.alloc((size_t)n * psz * 8));
+  HIPCHK(c, dc.alloc((size_t)n * csz * 8));
+  HIPCHK(c, dr.alloc((size_t)n * nres * 8));
+  if (jac) HIPCHK(c, dj.alloc((size_t)n * njac * 8));
+  HIPCHK(c, hipMemcpyAsync(dp.p, params, (size_t)n * psz * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dc.p, consts, (size_t)n * csz * 8, hipMemcpyHostToDevice, c->stream));
+  launch(dp.d(), dc.d(), dr.d(), jac ? dj.d() : nullptr);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(residuals, dr.p, (size_t)n * nres * 8, hipMemcpyDeviceToHost, c->stream));
+  if (jac) HIPCHK(c, hipMemcpyAsync(jac, dj.p, (size_t)n * njac * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VPL_OK;
+}
+
+extern "C" {
+
+void vpl_ba_default_options(vpl_ba_options* o) {
+  o->num_iterations = 5;
+  o->estimate_extrinsic = 1;
+  o->marginalization_flag = VPL_MARGIN_OLD;
+  o->remove_line_outliers = 0;
+  o->focal_length = 460.0;
+  o->line_factor = 306.666666667;
+  o->vp_factor = 10.0;
+  o->g_norm = 9.81007;
+  o->acc_n = 0.08; o->gyr_n = 0.004; o->acc_w = 0.00004; o->gyr_w = 2.0e-6;
+  o->huber_delta = 1.0;
+}
+
+int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, int max_point_obs, int max_lines,
+                   int max_line_obs) {
+  if (!out || max_windows < 1 || max_points < 0 || max_lines < 0) return VPL_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device >= ndev) return VPL_E_NODEVICE;
+  vpl_ctx* c = new vpl_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return VPL_E_NODEVICE; }
+  c->maxW = max_windows;
+  c->maxP = max_points > 0 ? max_points : 1;
+  c->maxPO = max_point_obs > 0 ? max_point_obs : 1;
+  c->maxL = max_lines > 0 ? max_lines : 1;
+  c->maxLO = max_line_obs > 0 ? max_line_obs : 1;
+  DevBatch& B = c->B;
+  std::memset(&B, 0, sizeof(B));
+  B.maxP = c->maxP; B.maxPO = c->maxPO; B.maxL = c->maxL; B.maxLO = c->maxLO;
+  B.nfull = NC + B.maxP + 4 * B.maxL;
+  const size_t W = max_windows;
+  hipError_t e = hipSuccess;
+#define AL(ptr, n) if (e == hipSuccess) e = dalloc(c, &B.ptr, (size_t)(n))
+  AL(pose, W * 77); AL(sb, W * 99); AL(ex, W * 7); AL(invd, W * B.maxP); AL(orth, W * B.maxL * 4);
+  AL(pose_c, W * 77); AL(sb_c, W * 99); AL(ex_c, W * 7); AL(invd_c, W * B.maxP); AL(orth_c, W * B.maxL * 4);
+  AL(pose_0, W * 77); AL(sb_0, W * 99); AL(ex_0, W * 7); AL(invd_0, W * B.maxP); AL(plk_0, W * B.maxL * 6);
+  AL(plk, W * B.maxL * 6); AL(gauge, W * 4);
+  AL(nP, W); AL(nL, W);
+  AL(pt_start, W * B.maxP); AL(pt_nobs, W * B.maxP); AL(pt_off, W * B.maxP); AL(pt_obs, W * B.maxPO * 3);
+  AL(ln_start, W * B.maxL); AL(ln_nobs, W * B.maxL); AL(ln_off, W * B.maxL); AL(ln_obs, W * B.maxLO * 8);
+  AL(pre, W * NF);
+  AL(pr_n, W); AL(pr_nb, W); AL(pr_kind, W * MAXPB); AL(pr_frame, W * MAXPB); AL(pr_idx, W * MAXPB);
+  AL(pr_x0, W * MAXPB * 9); AL(pr_J0, W * MAXPN * MAXPN); AL(pr_r0, W * MAXPN); AL(pr_H, W * MAXPN * MAXPN);
+  AL(pr_map, W * MAXPN);
+  AL(Hcc, W * NCP); AL(gc, W * NC); AL(Hpp, W * B.maxP); AL(gp, W * B.maxP); AL(Wp, W * B.maxP * NV);
+  AL(Hll, W * B.maxL * 16); AL(gl, W * B.maxL * 4); AL(Wl, W * B.maxL * 4 * NV);
+  AL(tr, W);
+  AL(scale, W * B.nfull); AL(diag, W * B.nfull); AL(grad, W * B.nfull); AL(gn, W * B.nfull); AL(delta, W * B.nfull);
+  AL(mg_n, W); AL(mg_nb, W); AL(mg_kind, W * MAXPB); AL(mg_frame, W * MAXPB); AL(mg_idx, W * MAXPB);
+  AL(mg_cam, W * MAXPB); AL(mg_x0, W * MAXPB * 9); AL(mg_J0, W * MAXKEEP * MAXKEEP); AL(mg_r0, W * MAXKEEP);
+  AL(mg_A, W * MAXKEEP * MAXKEEP); AL(mg_b, W * MAXKEEP); AL(mg_m, W);
+#undef AL
+  if (e != hipSuccess) {
+    for (void* p : c->allocs) hipFree(p);
+    delete c;
+    return VPL_E_HIP;
+  }
+  hipFuncSetAttribute((const void*)k_lin<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_SMEM);
+  hipFuncSetAttribute((const void*)k_lin<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_SMEM);
+  hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
+  hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_SMEM);
+  vpl_ba_default_options(&c->opt);
+  *out = c;
+  return VPL_OK;
+}
+
+void vpl_ctx_destroy(vpl_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (void* p : c->allocs) hipFree(p);
+  delete c;
+}
+
+int vpl_ctx_set_stream(vpl_ctx* c, void* s) {
+  if (!c) return VPL_E_INVALID;
+  c->stream = (hipStream_t)s;
+  return VPL_OK;
+}
+const char* vpl_last_error(const vpl_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int vpl_ctx_synchronize(vpl_ctx* c) {
+  if (!c) return VPL_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VPL_OK;
+}
+
+// ---- IMU pre-integration ---------------------------------------------------------------------------
+int vpl_preintegrate_batch(vpl_ctx* c, int n, const int* offset, const int* nsamples, const double* samples,
+                           const double* acc0, const double* gyr0, const double* lin_ba, const double* lin_bg,
+                           const vpl_ba_options* opt, vpl_preintegration* out) {
+  if (!c || n < 0 || !opt) return VPL_E_INVALID;
+  if (n == 0) return VPL_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total = std::max(total, (size_t)offset[i] + nsamples[i]);
+  int *d_off, *d_ns;
+  double *d_s, *d_a, *d_g, *d_ba, *d_bg, *d_scr;
+  DevPreint* d_out;
+  HIPCHK(c, hipMalloc(&d_off, n * sizeof(int)));
+  HIPCHK(c, hipMalloc(&d_ns, n * sizeof(int)));
+  HIPCHK(c, hipMalloc(&d_s, total * 7 * sizeof(double) + 8));
+  HIPCHK(c, hipMalloc(&d_a, n * 3 * sizeof(double)));
+  HIPCHK(c, hipMalloc(&d_g, n * 3 * sizeof(double)));
+  HIPCHK(c, hipMalloc(&d_ba, n * 3 * sizeof(double)));
+  HIPCHK(c, hipMalloc(&d_bg, n * 3 * sizeof(double)));
+  HIPCHK(c, hipMalloc(&d_scr, (size_t)n * 1170 * sizeof(double)));
+  HIPCHK(c, hipMalloc(&d_out, n * sizeof(DevPreint)));
+  HIPCHK(c, hipMemcpyAsync(d_off, offset, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_ns, nsamples, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_s, samples, total * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_a, acc0, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_g, gyr0, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_ba, lin_ba, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_bg, lin_bg, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_preintegrate, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, d_off, d_ns, d_s, d_a, d_g, d_ba,
+                     d_bg, opt->acc_n * opt->acc_n, opt->gyr_n * opt->gyr_n, opt->acc_w * opt->acc_w,
+                     opt->gyr_w * opt->gyr_w, d_out, d_scr);
+  HIPCHK(c, hipGetLastError());
+  std::vector<DevPreint> h(n);
+  HIPCHK(c, hipMemcpyAsync(h.data(), d_out, n * sizeof(DevPreint), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; ++i) {
+    vpl_preintegration& o = out[i];
+    o.sum_dt = h[i].sum_dt;
+    for (int k = 0; k < 3; ++k) { o.delta_p[k] = h[i].dp[k]; o.delta_v[k] = h[i].dv[k]; o.linearized_ba[k] = h[i].lba[k]; o.linearized_bg[k] = h[i].lbg[k]; }
+    for (int k = 0; k < 4; ++k) o.delta_q[k] = h[i].dq[k];
+    std::memcpy(o.jacobian, h[i].sqrt_info, sizeof(o.jacobian));   // k_preintegrate carries J out in this slot
+    std::memcpy(o.covariance, h[i].cov, sizeof(o.covariance));
+  }
+  hipFree(d_off); hipFree(d_ns); hipFree(d_s); hipFree(d_a); hipFree(d_g); hipFree(d_ba); hipFree(d_bg); hipFree(d_scr); hipFree(d_out);
+  return VPL_OK;
+}
+
+// ---- single-factor evaluators ------------------------------------------------------------------------
+int vpl_projection_factor_evaluate(vpl_ctx* c, int n, const double* params, const double* pts, double sqrt_info,
+                                   double* residuals, double* jac) {
+  return eval_generic(c, n, params, 22, pts, 6, 2, 44, residuals, jac, [&](double* p, double* k, double* r, double* j) {
+    hipLaunchKernelGGL(k_eval_projection, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, p, k, sqrt_info, r, j);
+  });
+}
+int vpl_line_factor_evaluate(vpl_ctx* c, int n, const double* params, const double* obs, double sqrt_info,
+                             double* residuals, double* jac) {
+  return eval_generic(c, n, params, 18, obs, 4, 2, 36, residuals, jac, [&](double* p, double* k, double* r, double* j) {
+    hipLaunchKernelGGL(k_eval_line<0>, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, p, k, sqrt_info, r, j);
+  });
+}
+int vpl_vp_factor_evaluate(vpl_ctx* c, int n, const double* params, const double* vp, double sqrt_info,
+                           double* residuals, double* jac) {
+  return eval_generic(c, n, params, 18, vp, 3, 2, 36, residuals, jac, [&](double* p, double* k, double* r, double* j) {
+    hipLaunchKernelGGL(k_eval_line<1>, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, p, k, sqrt_info, r, j);
+  });
+}
+int vpl_imu_factor_evaluate(vpl_ctx* c, int n, const double* params, const vpl_preintegration* pre, double g_norm,
+                            double* residuals, double* jac) {
+  if (!c || n < 0 || !params || !pre || !residuals) return VPL_E_INVALID;
+  if (n == 0) return VPL_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<DevPreint> h(n);
+  for (int i = 0; i < n; ++i) to_dev_preint(pre[i], h[i]);
+  DevBuf dp, dpre, dr, dj, ds;
+  HIPCHK(c, dp.alloc((size_t)n * 32 * 8));
+  HIPCHK(c, dpre.alloc((size_t)n * sizeof(DevPreint)));
+  HIPCHK(c, dr.alloc((size_t)n * 15 * 8));
+  HIPCHK(c, ds.alloc((size_t)n * 675 * 8));
+  if (jac) HIPCHK(c, dj.alloc((size_t)n * 480 * 8));
+  HIPCHK(c, hipMemcpyAsync(dp.p, params, (size_t)n * 32 * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dpre.p, h.data(), (size_t)n * sizeof(DevPreint), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_eval_imu, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, dp.d(), (const DevPreint*)dpre.p,
+                     g_norm, dr.d(), jac ? dj.d() : nullptr, ds.d());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(residuals, dr.p, (size_t)n * 15 * 8, hipMemcpyDeviceToHost, c->stream));
+  if (jac) HIPCHK(c, hipMemcpyAsync(jac, dj.p, (size_t)n * 480 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VPL_OK;
+}
+int vpl_prior_factor_evaluate(vpl_ctx* c, const vpl_prior* pr, const double* params, double* residuals, double* jac) {
+  if (!c || !pr || !params || !residuals || pr->n < 0 || pr->n > MAXPN || pr->n_blocks > MAXPB) return VPL_E_INVALID;
+  if (pr->n == 0) return VPL_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int n = pr->n, nb = pr->n_blocks;
+  int psz = 0;
+  for (int b = 0; b < nb; ++b) psz += pr->block_kind[b] == VPL_BLOCK_SPEEDBIAS ? 9 : 7;
+  DevBuf dk, di, dx0, dJ, dr0, dp, dr, dj;
+  HIPCHK(c, dk.alloc(nb * 4)); HIPCHK(c, di.alloc(nb * 4)); HIPCHK(c, dx0.alloc(nb * 9 * 8));
+  HIPCHK(c, dJ.alloc((size_t)n * n * 8)); HIPCHK(c, dr0.alloc(n * 8)); HIPCHK(c, dp.alloc(psz * 8));
+  HIPCHK(c, dr.alloc(n * 8));
+  if (jac) HIPCHK(c, dj.alloc((size_t)n * psz * 8));
+  HIPCHK(c, hipMemcpyAsync(dk.p, pr->block_kind, nb * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(di.p, pr->block_idx, nb * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dx0.p, pr->x0, nb * 9 * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dJ.p, pr->J0, (size_t)n * n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dr0.p, pr->r0, n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dp.p, params, psz * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_eval_prior, dim3(1), dim3(256), 0, c->stream, n, nb, (const int*)dk.p, (const int*)di.p, dx0.d(),
+                     dJ.d(), dr0.d(), dp.d(), dr.d(), jac ? dj.d() : nullptr);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(residuals, dr.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (jac) HIPCHK(c, hipMemcpyAsync(jac, dj.p, (size_t)n * psz * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VPL_OK;
+}
+int vpl_pose_plus(vpl_ctx* c, int n, const double* x, const double* delta, double* out) {
+  return eval_generic(c, n, x, 7, delta, 6, 7, 0, out, nullptr, [&](double* p, double* k, double* r, double*) {
+    hipLaunchKernelGGL(k_eval_pose_plus, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, p, k, r);
+  });
+}
+int vpl_line_orth_plus(vpl_ctx* c, int n, const double* x, const double* delta, double* out) {
+  return eval_generic(c, n, x, 4, delta, 4, 4, 0, out, nullptr, [&](double* p, double* k, double* r, double*) {
+    hipLaunchKernelGGL(k_eval_orth_plus, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, p, k, r);
+  });
+}
+
+// ---- window batch: upload / solve / download ------------------------------------------------------------
+int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt) {
+  if (!c || !win || !opt || nW < 1) return VPL_E_INVALID;
+  if (nW > c->maxW) return fail(c, VPL_E_CAPACITY, "more windows than max_windows");
+  if (opt->marginalization_flag == VPL_MARGIN_SECOND_NEW)
+    return fail(c, VPL_E_INVALID, "MARGIN_SECOND_NEW is not implemented on the device path yet");
+  if (opt->remove_line_outliers) return fail(c, VPL_E_INVALID, "remove_line_outliers is not implemented on the device path yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->opt = *opt;
+  c->nW = nW;
+  DevBatch& B = c->B;
+  B.nW = nW;
+  B.opt.num_iterations = opt->num_iterations;
+  B.opt.estimate_extrinsic = opt->estimate_extrinsic;
+  B.opt.marginalization_flag = opt->marginalization_flag;
+  B.opt.remove_line_outliers = opt->remove_line_outliers;
+  B.opt.sqrt_info_point = opt->focal_length / 1.5;
+  B.opt.sqrt_info_line = opt->line_factor;
+  B.opt.sqrt_info_vp = opt->vp_factor;
+  B.opt.g_norm = opt->g_norm;
+  B.opt.huber_delta = opt->huber_delta;
+
+  const size_t W = nW;
+  std::vector<double> pose(W * 77), sb(W * 99), ex(W * 7), invd(W * B.maxP, 1.0), plk(W * B.maxL * 6, 0.0);
+  std::vector<int> nP(W), nL(W), pt_start(W * B.maxP, 0), pt_nobs(W * B.maxP, 0), pt_off(W * B.maxP, 0);
+  std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0);
+  std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
+  std::vector<DevPreint> pre(W * NF);
+  std::vector<int> pr_n(W, 0), pr_nb(W, 0), pr_kind(W * MAXPB, 0), pr_frame(W * MAXPB, 0), pr_idx(W * MAXPB, 0);
+  std::vector<double> pr_x0(W * MAXPB * 9, 0.0), pr_r0(W * MAXPN, 0.0);
+  std::vector<int> mg_n(W, 0), mg_nb(W, 0), mg_kind(W * MAXPB, 0), mg_frame(W * MAXPB, 0), mg_idx(W * MAXPB, 0),
+      mg_cam(W * MAXPB, 0);
+  c->h_mg_m.assign(W, 0);
+  c->h_nP.assign(W, 0);
+  c->h_nL.assign(W, 0);
+
+  for (size_t w = 0; w < W; ++w) {
+    const vpl_window& v = win[w];
+    if (v.n_points > B.maxP || v.n_lines > B.maxL) return fail(c, VPL_E_CAPACITY, "too many tracks for the context");
+    std::memcpy(&pose[w * 77], v.pose, 77 * 8);
+    std::memcpy(&sb[w * 99], v.speed_bias, 99 * 8);
+    std::memcpy(&ex[w * 7], v.ex_pose, 7 * 8);
+    nP[w] = v.n_points; nL[w] = v.n_lines;
+    c->h_nP[w] = v.n_points; c->h_nL[w] = v.n_lines;
+    bool pose_touched[NF] = {false};
+    bool any_landmark0 = false;
+    int m = 0;
+    int off = 0;
+    for (int p = 0; p < v.n_points; ++p) {
+      const int s = v.point_start[p], no = v.point_nobs[p];
+      if (s < 0 || no < 2 || s + no > NF) return fail(c, VPL_E_INVALID, "point track outside the window");
+      if (off + no > B.maxPO) return fail(c, VPL_E_CAPACITY, "too many point observations");
+      pt_start[w * B.maxP + p] = s; pt_nobs[w * B.maxP + p] = no; pt_off[w * B.maxP + p] = off;
+      std::memcpy(&pt_obs[(w * B.maxPO + off) * 3], v.point_obs + (size_t)off * 3, (size_t)no * 3 * 8);
+      invd[w * B.maxP + p] = v.inv_depth[p];
+      if (s == 0) { for (int k = 1; k < no; ++k) pose_touched[k] = true; any_landmark0 = true; m += 1; }
+      off += no;
+    }
+    off = 0;
+    for (int l = 0; l < v.n_lines; ++l) {
+      const int s = v.line_start[l], no = v.line_nobs[l];
+      if (s < 0 || no < 1 || s + no > NF) return fail(c, VPL_E_INVALID, "line track outside the window");
+      if (off + no > B.maxLO) return fail(c, VPL_E_CAPACITY, "too many line observations");
+      ln_start[w * B.maxL + l] = s; ln_nobs[w * B.maxL + l] = no; ln_off[w * B.maxL + l] = off;
+      std::memcpy(&ln_obs[(w * B.maxLO + off) * 8], v.line_obs + (size_t)off * 8, (size_t)no * 8 * 8);
+      std::memcpy(&plk[(w * B.maxL + l) * 6], v.line_plk + (size_t)l * 6, 6 * 8);
+      if (s == 0 && no >= 2) { for (int k = 1; k < no; ++k) pose_touched[k] = true; any_landmark0 = true; m += 4; }
+      off += no;
+    }
+    for (int j = 0; j < NF; ++j) to_dev_preint(v.preint[j], pre[w * NF + j]);
+    bool sb_touched[NF] = {false};
+    bool ex_touched = any_landmark0;
+    bool frame0 = any_landmark0;
+    if (v.has_prior && v.prior) {
+      const vpl_prior& pr = *v.prior;
+      if (pr.n < 0 || pr.n > MAXPN || pr.n_blocks < 0 || pr.n_blocks > MAXPB) return fail(c, VPL_E_INVALID, "bad prior");
+      pr_n[w] = pr.n; pr_nb[w] = pr.n_blocks;
+      for (int b = 0; b < pr.n_blocks; ++b) {
+        pr_kind[w * MAXPB + b] = pr.block_kind[b];
+        pr_frame[w * MAXPB + b] = pr.block_frame[b];
+        pr_idx[w * MAXPB + b] = pr.block_idx[b];
+        std::memcpy(&pr_x0[(w * MAXPB + b) * 9], pr.x0[b], 9 * 8);
+        if (pr.block_kind[b] == VPL_BLOCK_POSE) pose_touched[pr.block_frame[b]] = true;
+        else if (pr.block_kind[b] == VPL_BLOCK_SPEEDBIAS) sb_touched[pr.block_frame[b]] = true;
+        else ex_touched = true;
+      }
+      std::memcpy(&pr_r0[w * MAXPN], pr.r0, (size_t)pr.n * 8);
+      HIPCHK(c, hipMemcpyAsync(B.pr_J0 + w * MAXPN * MAXPN, pr.J0, (size_t)pr.n * pr.n * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (v.preint[1].sum_dt < 10.0) { pose_touched[1] = true; sb_touched[1] = true; sb_touched[0] = true; pose_touched[0] = true; }
+    // kept blocks in the canonical (address) order of the reference's para_* layout
+    if (opt->marginalization_flag == VPL_MARGIN_OLD) {
+      int nb = 0, idx = 0;
+      auto add = [&](int kind, int frame, int cam, int ls) {
+        mg_kind[w * MAXPB + nb] = kind; mg_frame[w * MAXPB + nb] = frame; mg_idx[w * MAXPB + nb] = idx;
+        mg_cam[w * MAXPB + nb] = cam;
+        idx += ls; ++nb;
+      };
+      for (int f = 1; f < NF; ++f) if (pose_touched[f]) add(VPL_BLOCK_POSE, f - 1, 15 * f, 6);
+      for (int f = 1; f < NF; ++f) if (sb_touched[f]) add(VPL_BLOCK_SPEEDBIAS, f - 1, 15 * f + 6, 9);
+      if (ex_touched) add(VPL_BLOCK_EXPOSE, 0, 165, 6);
+      if (idx > MAXKEEP) return fail(c, VPL_E_CAPACITY, "marginalisation keeps more than MAXKEEP dims");
+      mg_n[w] = idx; mg_nb[w] = nb;
+      m += (pose_touched[0] || frame0 ? 6 : 0) + (sb_touched[0] ? 9 : 0);
+      c->h_mg_m[w] = m;
+    }
+  }
+  HIPCHK(c, up(c, B.pose, pose)); HIPCHK(c, up(c, B.sb, sb)); HIPCHK(c, up(c, B.ex, ex)); HIPCHK(c, up(c, B.invd, invd));
+  HIPCHK(c, up(c, B.plk, plk));
+  HIPCHK(c, up(c, B.pose_0, pose)); HIPCHK(c, up(c, B.sb_0, sb)); HIPCHK(c, up(c, B.ex_0, ex)); HIPCHK(c, up(c, B.invd_0, invd));
+  HIPCHK(c, up(c, B.plk_0, plk));
+  HIPCHK(c, up(c, B.nP, nP)); HIPCHK(c, up(c, B.nL, nL));
+  HIPCHK(c, up(c, B.pt_start, pt_start)); HIPCHK(c, up(c, B.pt_nobs, pt_nobs)); HIPCHK(c, up(c, B.pt_off, pt_off));
+  HIPCHK(c, up(c, B.pt_obs, pt_obs));
+  HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
+  HIPCHK(c, up(c, B.ln_obs, ln_obs));
+  HIPCHK(c, up(c, B.pre, pre));
+  HIPCHK(c, up(c, B.pr_n, pr_n)); HIPCHK(c, up(c, B.pr_nb, pr_nb)); HIPCHK(c, up(c, B.pr_kind, pr_kind));
+  HIPCHK(c, up(c, B.pr_frame, pr_frame)); HIPCHK(c, up(c, B.pr_idx, pr_idx)); HIPCHK(c, up(c, B.pr_x0, pr_x0));
+  HIPCHK(c, up(c, B.pr_r0, pr_r0));
+  HIPCHK(c, up(c, B.mg_n, mg_n)); HIPCHK(c, up(c, B.mg_nb, mg_nb)); HIPCHK(c, up(c, B.mg_kind, mg_kind));
+  HIPCHK(c, up(c, B.mg_frame, mg_frame)); HIPCHK(c, up(c, B.mg_idx, mg_idx)); HIPCHK(c, up(c, B.mg_cam, mg_cam));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // host staging vectors die here
+  return VPL_OK;
+}
+
+int vpl_ba_reset_state(vpl_ctx* c) {
+  if (!c || c->nW < 1) return VPL_E_INVALID;
+  DevBatch& B = c->B;
+  const size_t W = c->nW;
+  HIPCHK(c, hipMemcpyAsync(B.pose, B.pose_0, W * 77 * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(B.sb, B.sb_0, W * 99 * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(B.ex, B.ex_0, W * 7 * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(B.invd, B.invd_0, W * B.maxP * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(B.plk, B.plk_0, W * B.maxL * 6 * 8, hipMemcpyDeviceToDevice, c->stream));
+  return VPL_OK;
+}
+
+int vpl_ba_solve(vpl_ctx* c) {
+  if (!c || c->nW < 1) return VPL_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBatch& B = c->B;
+  const dim3 grid(c->nW);
+  hipStream_t s = c->stream;
+  { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, B); }
+  { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<false>, grid, dim3(LIN_THREADS), LIN_SMEM, s, B); }
+  for (int it = 0; it < c->opt.num_iterations; ++it) {
+    { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), SOLVE_SMEM, s, B); }
+    { KTimer t(c, "k_cost"); hipLaunchKernelGGL(k_cost, grid, dim3(COST_THREADS), 0, s, B); }
+    if (it + 1 < c->opt.num_iterations) {
+      KTimer t(c, "k_lin");
+      hipLaunchKernelGGL(k_lin<false>, grid, dim3(LIN_THREADS), LIN_SMEM, s, B);
+    }
+  }
+  { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
+  if (c->opt.marginalization_flag == VPL_MARGIN_OLD) {
+    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<true>, grid, dim3(LIN_THREADS), LIN_SMEM, s, B); }
+    { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), MARG_SMEM, s, B); }
+  }
+  HIPCHK(c, hipGetLastError());
+  return VPL_OK;
+}
+
+int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_solve_report* reports) {
+  if (!c || nW != c->nW || !win) return VPL_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBatch& B = c->B;
+  const size_t W = nW;
+  std::vector<double> pose(W * 77), sb(W * 99), ex(W * 7), invd(W * B.maxP), plk(W * B.maxL * 6);
+  std::vector<TrState> tr(W);
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(pose.data(), B.pose, W * 77 * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(sb.data(), B.sb, W * 99 * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(ex.data(), B.ex, W * 7 * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(invd.data(), B.invd, W * B.maxP * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(plk.data(), B.plk, W * B.maxL * 6 * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(tr.data(), B.tr, W * sizeof(TrState), hipMemcpyDeviceToHost, s));
+  std::vector<int> mg_n, mg_nb, mg_kind, mg_frame, mg_idx;
+  std::vector<double> mg_x0, mg_J0, mg_r0;
+  const bool marg = priors && c->opt.marginalization_flag == VPL_MARGIN_OLD;
+  if (marg) {
+    mg_n.resize(W); mg_nb.resize(W); mg_kind.resize(W * MAXPB); mg_frame.resize(W * MAXPB); mg_idx.resize(W * MAXPB);
+    mg_x0.resize(W * MAXPB * 9); mg_J0.resize(W * MAXKEEP * MAXKEEP); mg_r0.resize(W * MAXKEEP);
+    HIPCHK(c, hipMemcpyAsync(mg_n.data(), B.mg_n, W * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(mg_nb.data(), B.mg_nb, W * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(mg_kind.data(), B.mg_kind, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(mg_frame.data(), B.mg_frame, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(mg_idx.data(), B.mg_idx, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(mg_x0.data(), B.mg_x0, W * MAXPB * 9 * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(mg_J0.data(), B.mg_J0, W * MAXKEEP * MAXKEEP * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(mg_r0.data(), B.mg_r0, W * MAXKEEP * 8, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (size_t w = 0; w < W; ++w) {
+    vpl_window& v = win[w];
+    std::memcpy(v.pose, &pose[w * 77], 77 * 8);
+    std::memcpy(v.speed_bias, &sb[w * 99], 99 * 8);
+    std::memcpy(v.ex_pose, &ex[w * 7], 7 * 8);
+    for (int p = 0; p < v.n_points; ++p) v.inv_depth[p] = invd[w * B.maxP + p];
+    for (int l = 0; l < v.n_lines; ++l) std::memcpy(v.line_plk + (size_t)l * 6, &plk[(w * B.maxL + l) * 6], 6 * 8);
+    if (reports) {
+      vpl_solve_report& r = reports[w];
+      std::memset(&r, 0, sizeof(r));
+      r.iterations = tr[w].iter;
+      r.num_successful_steps = tr[w].num_successful;
+      r.termination = tr[w].status == 1 ? 1 : tr[w].status == 2 ? 2 : 0;
+      r.initial_cost = tr[w].initial_cost;
+      r.final_cost = tr[w].x_cost;
+      r.prior_m = c->h_mg_m[w];
+      r.prior_n = marg ? mg_n[w] : 0;
+    }
+    if (marg) {
+      vpl_prior& p = priors[w];
+      std::memset(&p, 0, sizeof(int) * (2 + 3 * VPL_MAX_PRIOR_BLOCKS));
+      const int n = mg_n[w];
+      p.n = n; p.n_blocks = mg_nb[w];
+      for (int b = 0; b < p.n_blocks; ++b) {
+        p.block_kind[b] = mg_kind[w * MAXPB + b];
+        p.block_frame[b] = mg_frame[w * MAXPB + b];
+        p.block_idx[b] = mg_idx[w * MAXPB + b];
+        std::memcpy(p.x0[b], &mg_x0[(w * MAXPB + b) * 9], 9 * 8);
+      }
+      std::memcpy(p.J0, &mg_J0[w * MAXKEEP * MAXKEEP], (size_t)n * n * 8);
+      std::memcpy(p.r0, &mg_r0[w * MAXKEEP], (size_t)n * 8);
+    }
+  }
+  return VPL_OK;
+}
+
+int vpl_ba_solve_windows(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt, vpl_prior* priors,
+                         vpl_solve_report* reports) {
+  int rc = vpl_ba_upload(c, nW, win, opt);
+  if (rc) return rc;
+  rc = vpl_ba_solve(c);
+  if (rc) return rc;
+  rc = vpl_ctx_synchronize(c);
+  if (rc) return rc;
+  return vpl_ba_download(c, nW, win, priors, reports);
+}
+
+// Debug/test access to the marginalisation invariants (A, b before the final eigen-decomposition),
+// mirroring the reference's commented check at marginalization_factor.cpp:361-362.
+int vpl_ba_debug_marg_Ab(vpl_ctx* c, int w, double* A, double* b) {
+  if (!c || w < 0 || w >= c->nW) return VPL_E_INVALID;
+  int n = 0;
+  HIPCHK(c, hipMemcpy(&n, c->B.mg_n + w, 4, hipMemcpyDeviceToHost));
+  std::vector<double> t((size_t)n * n);
+  HIPCHK(c, hipMemcpy(A, c->B.mg_A + (size_t)w * MAXKEEP * MAXKEEP, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(b, c->B.mg_b + (size_t)w * MAXKEEP, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return n;
+}
+
+int vpl_ba_enable_kernel_timing(vpl_ctx* c, int enable) {
+  if (!c) return VPL_E_INVALID;
+  c->timing = enable != 0;
+  c->ktimes.clear();
+  return VPL_OK;
+}
+int vpl_ba_kernel_times(vpl_ctx* c, int* count, const char** names, double* total_ms, int* launches) {
+  if (!c || !count) return VPL_E_INVALID;
+  int cap = *count, i = 0;
+  c->kname_store.clear();
+  for (auto& kv : c->ktimes) c->kname_store.push_back(kv.first);
+  for (auto& kv : c->ktimes) {
+    if (i >= cap) break;
+    names[i] = c->kname_store[i].c_str();
+    total_ms[i] = kv.second.first;
+    launches[i] = kv.second.second;
+    ++i;
+  }
+  *count = i;
+  return VPL_OK;
+}
+
+}  // extern "C"
