@@ -77,97 +77,144 @@ __global__ __launch_bounds__(128) void k_gauge(DevBatch B) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Block-cooperative cyclic Jacobi eigen-solver on a symmetric n x n matrix in LDS (row stride ld).
-// On exit A holds the eigenvalues on its diagonal and V (n x n, row stride ld) the eigenvectors
-// in its columns.  Parallel round-robin ordering: n/2 disjoint rotations per step.
-__device__ void jacobi_eig(double* A, double* V, int n, int ld, double* cs, int* prm, double* red) {
+// Block-cooperative cyclic Jacobi eigen-solver for a symmetric matrix held in LDS.
+// The matrix is padded to an even dimension m (dummy row/column of zeros when n is odd) with row
+// stride ld.  Parallel round-robin ordering: m/2 disjoint rotations per step; every step is ONE pass
+// over 2x2 blocks B' = R_P^T B R_Q (double buffered between A0/A1) plus the column update of V, so a
+// step costs two barriers.  On exit *Aout points at the buffer whose diagonal holds the eigenvalues;
+// V's columns are the eigenvectors.
+__device__ double* jacobi_eig(double* A0, double* A1, double* V, int m, int ld, double* cs, int* prm, double* red, int* nsweeps) {
   const int tid = threadIdx.x, T = blockDim.x;
-  const int m = (n + 1) & ~1;       // even number of players (one dummy when n is odd)
   const int half = m / 2;
-  for (int i = tid; i < n * n; i += T) V[(i / n) * ld + (i % n)] = (i / n == i % n) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 30; ++sweep) {
-    double off = 0.0, dia = 0.0;
-    __syncthreads();
-    for (int i = tid; i < n * n; i += T) {
-      const int r = i / n, c = i % n;
-      const double v = A[r * ld + c];
-      if (r == c) dia += v * v; else off += v * v;
+  for (int i = tid; i < m * m; i += T) V[(i / m) * ld + (i % m)] = (i / m == i % m) ? 1.0 : 0.0;
+  // the task list of a step does not depend on the step: decode it once (no integer divisions inside)
+  constexpr int MAXT = 8;
+  const int nblk = half * (half + 1) / 2;        // 2x2 blocks with P >= Q (the mirror is written too)
+  const int ntask = nblk + half * m;
+  int tP[MAXT], tQ[MAXT];                        // A task: (P, Q) ; V task: (P, -1 - k)
+  int nt = 0;
+  for (int it = tid; it < ntask && nt < MAXT; it += T, ++nt) {
+    if (it < nblk) {
+      int P, Q;
+      tri_decode(it, P, Q);
+      tP[nt] = P; tQ[nt] = Q;
+    } else {
+      const int it2 = it - nblk;
+      tP[nt] = it2 / m;
+      tQ[nt] = -1 - (it2 % m);
     }
-    off = block_sum(off, red);
-    dia = block_sum(dia, red);
-    if (off <= 1e-60 || off <= 1e-28 * dia) break;
+  }
+  double* cur = A0;
+  double* nxt = A1;
+  // Convergence: the classical relative criterion -- a sweep in which no pair needed a rotation
+  // (|a_pq| <= 1e-15 sqrt(|a_pp a_qq|)).  The matrices here are strongly graded (eigenvalues from
+  // 1e-8 to 1e10) and the pseudo-inverse / 1/sqrt(lambda) of the small ones is what is consumed,
+  // so relative (not Frobenius) accuracy is required; graded inputs take 12-20 sweeps.
+  int* rotflag = prm + 2 * half;   // prm holds 2*half ints; one spare slot follows (m + 1 allocated)
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    __syncthreads();
+    const int had = (sweep == 0) ? 1 : *rotflag;
+    __syncthreads();
+    if (nsweeps && threadIdx.x == 0) *nsweeps = sweep;
+    if (!had) break;
+    if (tid == 0) *rotflag = 0;
+    __syncthreads();
     for (int step = 0; step < m - 1; ++step) {
-      // round-robin pairing: player 0 fixed, the others rotate
-      if (tid < half) {
+      if (tid < half) {   // round-robin pairing: player 0 fixed, the others rotate
         int a = tid == 0 ? 0 : 1 + (tid - 1 + step) % (m - 1);
-        int b = 1 + (m - 1 - tid - 1 + step) % (m - 1);
-        if (tid == 0) b = 1 + (m - 2 + step) % (m - 1);
-        int p = min(a, b), q = max(a, b);
+        int b = tid == 0 ? 1 + (m - 2 + step) % (m - 1) : 1 + (m - 2 - tid + step) % (m - 1);
+        const int p = min(a, b), q = max(a, b);
         double c = 1.0, s = 0.0;
-        if (q < n) {
-          const double apq = A[p * ld + q];
-          if (apq != 0.0) {
-            const double theta = (A[q * ld + q] - A[p * ld + p]) / (2.0 * apq);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            c = 1.0 / sqrt(t * t + 1.0);
-            s = t * c;
-          }
+        const double apq = cur[p * ld + q], app = cur[p * ld + p], aqq = cur[q * ld + q];
+        if (fabs(apq) > 1e-15 * sqrt(fabs(app * aqq)) && apq != 0.0) {
+          *rotflag = 1;
+          const double theta = (aqq - app) / (2.0 * apq);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(t * t + 1.0);
+          s = t * c;
         }
         prm[2 * tid] = p; prm[2 * tid + 1] = q;
         cs[2 * tid] = c; cs[2 * tid + 1] = s;
       }
       __syncthreads();
-      // columns of A and V
-      for (int it = tid; it < half * n; it += T) {
-        const int pr = it / n, k = it % n;
-        const int p = prm[2 * pr], q = prm[2 * pr + 1];
-        if (q >= n) continue;
-        const double c = cs[2 * pr], s = cs[2 * pr + 1];
-        const double akp = A[k * ld + p], akq = A[k * ld + q];
-        A[k * ld + p] = c * akp - s * akq;
-        A[k * ld + q] = s * akp + c * akq;
-        const double vkp = V[k * ld + p], vkq = V[k * ld + q];
-        V[k * ld + p] = c * vkp - s * vkq;
-        V[k * ld + q] = s * vkp + c * vkq;
+#pragma unroll
+      for (int k2 = 0; k2 < MAXT; ++k2) {
+        if (k2 >= nt) break;
+        const int P = tP[k2], Q = tQ[k2];
+        const int p = prm[2 * P], q = prm[2 * P + 1];
+        const double c1 = cs[2 * P], s1 = cs[2 * P + 1];
+        if (Q >= 0) {
+          const int r = prm[2 * Q], u = prm[2 * Q + 1];
+          const double c2 = cs[2 * Q], s2 = cs[2 * Q + 1];
+          const double bpr = cur[p * ld + r], bpu = cur[p * ld + u], bqr = cur[q * ld + r], bqu = cur[q * ld + u];
+          // columns: [x_r, x_u] <- [c2 x_r - s2 x_u, s2 x_r + c2 x_u] ; rows likewise with (c1, s1)
+          const double tpr = c2 * bpr - s2 * bpu, tpu = s2 * bpr + c2 * bpu;
+          const double tqr = c2 * bqr - s2 * bqu, tqu = s2 * bqr + c2 * bqu;
+          const double npr = c1 * tpr - s1 * tqr, npu = c1 * tpu - s1 * tqu;
+          const double nqr = s1 * tpr + c1 * tqr, nqu = s1 * tpu + c1 * tqu;
+          nxt[p * ld + r] = npr; nxt[p * ld + u] = npu; nxt[q * ld + r] = nqr; nxt[q * ld + u] = nqu;
+          nxt[r * ld + p] = npr; nxt[u * ld + p] = npu; nxt[r * ld + q] = nqr; nxt[u * ld + q] = nqu;
+        } else {
+          const int k = -1 - Q;
+          const double vkp = V[k * ld + p], vkq = V[k * ld + q];
+          V[k * ld + p] = c1 * vkp - s1 * vkq;
+          V[k * ld + q] = s1 * vkp + c1 * vkq;
+        }
       }
       __syncthreads();
-      // rows of A
-      for (int it = tid; it < half * n; it += T) {
-        const int pr = it / n, k = it % n;
-        const int p = prm[2 * pr], q = prm[2 * pr + 1];
-        if (q >= n) continue;
-        const double c = cs[2 * pr], s = cs[2 * pr + 1];
-        const double apk = A[p * ld + k], aqk = A[q * ld + k];
-        A[p * ld + k] = c * apk - s * aqk;
-        A[q * ld + k] = s * apk + c * aqk;
-      }
-      __syncthreads();
+      double* t = cur; cur = nxt; nxt = t;
     }
   }
   __syncthreads();
+  return cur;
 }
 
-constexpr int MARG_THREADS = 256;
-constexpr int MD = 96;            // dense working dimension: 15 (frame 0) + kept (<= 75), padded
-constexpr double kMargEps = 1e-8; // marginalization_factor.h:67
+constexpr int MARG_THREADS = 512;
+constexpr double kMargEps = 1e-8;   // marginalization_factor.h:67
+constexpr int MTROWS = 32;          // landmark rows staged per elimination pass
 
-// LDS: A (MD*MD) + V (MD*MD) + small.  The Schur step runs on the packed Hessian in HBM/L2
-// (written by k_lin<MARG>), output-stationary, before the dense block is pulled into LDS.
+// LDS layout of k_marg (doubles), shared by host (size) and device (offsets)
+struct MargLayout {
+  int m, ldm, EB, nd, ldd, WS, total;
+};
+__host__ __device__ inline MargLayout marg_layout(int n) {
+  MargLayout L;
+  L.m = (n + 1) & ~1;
+  if (L.m < 2) L.m = 2;
+  L.ldm = L.m + 1;
+  L.EB = L.m * L.ldm;
+  L.nd = 15 + n;
+  L.ldd = L.nd + 1;
+  const int need = L.nd * L.ldd + MTROWS * 74 + 3 * 16 * 17;
+  L.WS = need > 2 * L.EB ? need : 2 * L.EB;
+  // A0 | workspace | bv(nd) | tmp(nd*16) | cs(m) | red(20) | ints: prm(m) dmap(nd) lst(2*1024)
+  L.total = L.EB + L.WS + L.nd + L.nd * 16 + L.m + 20 + (L.m + 2 + L.nd + 2048 + 8) / 2 + 4;
+  return L;
+}
+
 __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   const int w = blockIdx.x, tid = threadIdx.x, T = MARG_THREADS;
   extern __shared__ double sm[];
-  double* A = sm;                 // MD x MD
-  double* V = A + MD * MD;        // MD x MD
-  double* bv = V + MD * MD;       // MD
-  double* tmp = bv + MD;          // MD * 16  (Arm * Amm_inv)
-  double* cs = tmp + MD * 16;     // MD
-  double* red = cs + MD;          // 20
-  int* prm = (int*)(red + 20);    // MD
-  int* dmap = prm + MD;           // MD : dense index -> cam index
-
   const int nP = B.nP[w], nL = B.nL[w];
   const int nb = B.mg_nb[w];
   const int n = B.mg_n[w];
+  const MargLayout L = marg_layout(n);
+  const int nd = L.nd, ldd = L.ldd, m = L.m, ldm = L.ldm;
+  double* A0 = sm;                       // m x ldm : kept block / eigen buffer 0
+  double* WSP = A0 + L.EB;               // workspace
+  double* Ad = WSP;                      // nd x ldd dense pre-marginalisation matrix
+  double* tile = Ad + nd * ldd;          // MTROWS x 74
+  double* E0 = tile + MTROWS * 74;       // 3 x (16 x 17) buffers for the 15x15 eigen problem
+  double* bv = WSP + L.WS;               // nd
+  double* tmp = bv + nd;                 // nd * 16
+  double* cs = tmp + nd * 16;            // m
+  double* red = cs + m;                  // 20
+  int* prm = (int*)(red + 20);           // m
+  int* dmap = prm + m + 2;               // nd
+  int* lst = dmap + nd;                  // 2 x 1024
+  constexpr int LOFF = 1024;
+  __shared__ int s_np0, s_nl0;
+
   // dense order: [sb_0 (9), pose_0 (6) | kept blocks in canonical order]  (the reference moves the
   // pose-like marginalised blocks behind the landmarks in descending index order, :291-309)
   if (tid < 15) dmap[tid] = tid < 9 ? 6 + tid : tid - 9;
@@ -177,177 +224,165 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     const int ls = kind == 1 ? 9 : 6;
     for (int k = 0; k < ls; ++k) dmap[15 + idx + k] = base + k;
   }
+  if (tid == 32) {
+    int a = 0;
+    for (int p = 0; p < nP && a < LOFF; ++p)
+      if (B.pt_start[(size_t)w * B.maxP + p] == 0 && B.Hpp[(size_t)w * B.maxP + p] != 0.0) lst[a++] = p;
+    s_np0 = a;
+    int c = 0;
+    for (int l = 0; l < nL && c < LOFF; ++l)
+      if (B.ln_start[(size_t)w * B.maxL + l] == 0 && B.ln_nobs[(size_t)w * B.maxL + l] >= 2) lst[LOFF + c++] = l;
+    s_nl0 = c;
+  }
   __syncthreads();
-  const int nd = 15 + n;
   const double* Hcc = B.Hcc + (size_t)w * NCP;
   const double* gc = B.gc + (size_t)w * NC;
-  // dense A, b over the involved dims, then subtract the landmark Schur terms (plain inverse, :316-326)
+  // ---- landmark elimination (plain inverse of the block-diagonal landmark part, :316-326) --------
+  // rows X = C^-1 [W | g] per start-frame-0 landmark (C C^T = H_ll); A = Hcc - X^T X, b = gc - X^T z
   for (int it = tid; it < nd * nd; it += T) {
     const int i = it / nd, j = it % nd;
     const int ci = dmap[i], cj = dmap[j];
-    double v = ci >= cj ? Hcc[tri(ci, cj)] : Hcc[tri(cj, ci)];
-    const int vi = cam2vis(ci), vj = cam2vis(cj);
-    if (vi >= 0 && vj >= 0) {
-      double s = 0.0;
-      for (int p = 0; p < nP; ++p) {
-        const size_t pi = (size_t)w * B.maxP + p;
-        if (B.pt_start[pi] != 0) continue;
-        const double h = B.Hpp[pi];
-        if (h == 0.0) continue;
-        s += B.Wp[pi * NV + vi] * B.Wp[pi * NV + vj] / h;
-      }
-      for (int l = 0; l < nL; ++l) {
-        const size_t li = (size_t)w * B.maxL + l;
-        if (B.ln_start[li] != 0) continue;
-        // x = H^-1 w_j by Cholesky; s += w_i . x
-        const double* Hl = B.Hll + li * 16;
-        double C[10], x[4];
-        int t = 0;
-        for (int a = 0; a < 4; ++a)
-          for (int c = 0; c <= a; ++c, ++t) C[t] = Hl[4 * a + c];
-        for (int jj = 0; jj < 4; ++jj) {
-          double d = C[tri(jj, jj)];
-          for (int k = 0; k < jj; ++k) d -= C[tri(jj, k)] * C[tri(jj, k)];
-          d = sqrt(d);
-          C[tri(jj, jj)] = d;
-          for (int ii = jj + 1; ii < 4; ++ii) {
-            double s2 = C[tri(ii, jj)];
-            for (int k = 0; k < jj; ++k) s2 -= C[tri(ii, k)] * C[tri(jj, k)];
-            C[tri(ii, jj)] = s2 / d;
-          }
-        }
-        for (int a = 0; a < 4; ++a) {
-          double s2 = B.Wl[(li * 4 + a) * NV + vj];
-          for (int k = 0; k < a; ++k) s2 -= C[tri(a, k)] * x[k];
-          x[a] = s2 / C[tri(a, a)];
-        }
-        for (int a = 3; a >= 0; --a) {
-          double s2 = x[a];
-          for (int k = a + 1; k < 4; ++k) s2 -= C[tri(k, a)] * x[k];
-          x[a] = s2 / C[tri(a, a)];
-        }
-        for (int a = 0; a < 4; ++a) s += B.Wl[(li * 4 + a) * NV + vi] * x[a];
-      }
-      v -= s;
-    }
-    A[i * MD + j] = v;
+    Ad[i * ldd + j] = ci >= cj ? Hcc[tri(ci, cj)] : Hcc[tri(cj, ci)];
   }
-  for (int i = tid; i < nd; i += T) {
-    const int ci = dmap[i];
-    double v = gc[ci];
-    const int vi = cam2vis(ci);
-    if (vi >= 0) {
-      double s = 0.0;
-      for (int p = 0; p < nP; ++p) {
-        const size_t pi = (size_t)w * B.maxP + p;
-        if (B.pt_start[pi] != 0) continue;
-        const double h = B.Hpp[pi];
-        if (h == 0.0) continue;
-        s += B.Wp[pi * NV + vi] * B.gp[pi] / h;
-      }
-      for (int l = 0; l < nL; ++l) {
-        const size_t li = (size_t)w * B.maxL + l;
-        if (B.ln_start[li] != 0) continue;
-        const double* Hl = B.Hll + li * 16;
-        double C[10], x[4];
-        int t = 0;
-        for (int a = 0; a < 4; ++a)
-          for (int c = 0; c <= a; ++c, ++t) C[t] = Hl[4 * a + c];
-        for (int jj = 0; jj < 4; ++jj) {
-          double d = C[tri(jj, jj)];
-          for (int k = 0; k < jj; ++k) d -= C[tri(jj, k)] * C[tri(jj, k)];
-          d = sqrt(d);
-          C[tri(jj, jj)] = d;
-          for (int ii = jj + 1; ii < 4; ++ii) {
-            double s2 = C[tri(ii, jj)];
-            for (int k = 0; k < jj; ++k) s2 -= C[tri(ii, k)] * C[tri(jj, k)];
-            C[tri(ii, jj)] = s2 / d;
-          }
-        }
-        for (int a = 0; a < 4; ++a) {
-          double s2 = B.gl[li * 4 + a];
-          for (int k = 0; k < a; ++k) s2 -= C[tri(a, k)] * x[k];
-          x[a] = s2 / C[tri(a, a)];
-        }
-        for (int a = 3; a >= 0; --a) {
-          double s2 = x[a];
-          for (int k = a + 1; k < 4; ++k) s2 -= C[tri(k, a)] * x[k];
-          x[a] = s2 / C[tri(a, a)];
-        }
-        for (int a = 0; a < 4; ++a) s += B.Wl[(li * 4 + a) * NV + vi] * x[a];
-      }
-      v -= s;
-    }
-    bv[i] = v;
-  }
+  for (int i = tid; i < nd; i += T) bv[i] = gc[dmap[i]];
   __syncthreads();
+  const int np0 = s_np0, nl0 = s_nl0;
+  for (int base = 0; base < np0 + nl0; ) {
+    int nrows;
+    if (base < np0) {
+      const int cnt = min(MTROWS, np0 - base);
+      nrows = cnt;
+      for (int it = tid; it < cnt * 73; it += T) {
+        const int rr = it / 73, c = it % 73;
+        const size_t pi = (size_t)w * B.maxP + lst[base + rr];
+        const double isq = 1.0 / sqrt(B.Hpp[pi]);
+        tile[rr * 74 + c] = isq * (c < NV ? B.Wp[pi * NV + c] : B.gp[pi]);
+      }
+      base += cnt;
+    } else {
+      const int l0 = base - np0;
+      const int cnt = min(MTROWS / 4, nl0 - l0);
+      nrows = 4 * cnt;
+      for (int it = tid; it < cnt * 73; it += T) {
+        const int ll = it / 73, c = it % 73;
+        const size_t li = (size_t)w * B.maxL + lst[LOFF + l0 + ll];
+        const double* Hl = B.Hll + li * 16;
+        double Cc[10], x[4];
+        int t = 0;
+        for (int a = 0; a < 4; ++a)
+          for (int cc = 0; cc <= a; ++cc, ++t) Cc[t] = Hl[4 * a + cc];
+        for (int jj = 0; jj < 4; ++jj) {
+          double d = Cc[tri(jj, jj)];
+          for (int k = 0; k < jj; ++k) d -= Cc[tri(jj, k)] * Cc[tri(jj, k)];
+          d = sqrt(d);
+          Cc[tri(jj, jj)] = d;
+          for (int ii = jj + 1; ii < 4; ++ii) {
+            double s2 = Cc[tri(ii, jj)];
+            for (int k = 0; k < jj; ++k) s2 -= Cc[tri(ii, k)] * Cc[tri(jj, k)];
+            Cc[tri(ii, jj)] = s2 / d;
+          }
+        }
+        for (int a = 0; a < 4; ++a) {
+          double s2 = c < NV ? B.Wl[(li * 4 + a) * NV + c] : B.gl[li * 4 + a];
+          for (int k = 0; k < a; ++k) s2 -= Cc[tri(a, k)] * x[k];
+          x[a] = s2 / Cc[tri(a, a)];
+          tile[(4 * ll + a) * 74 + c] = x[a];
+        }
+      }
+      base += cnt;
+    }
+    __syncthreads();
+    for (int it = tid; it < nd * nd; it += T) {
+      const int i = it / nd, j = it % nd;
+      const int vi = cam2vis(dmap[i]), vj = cam2vis(dmap[j]);
+      if (vi >= 0 && vj >= 0) {
+        double s = 0.0;
+        for (int r = 0; r < nrows; ++r) s += tile[r * 74 + vi] * tile[r * 74 + vj];
+        Ad[i * ldd + j] -= s;
+      }
+    }
+    for (int i = tid; i < nd; i += T) {
+      const int vi = cam2vis(dmap[i]);
+      if (vi >= 0) {
+        double s = 0.0;
+        for (int r = 0; r < nrows; ++r) s += tile[r * 74 + vi] * tile[r * 74 + 72];
+        bv[i] -= s;
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- marginalise the 15 dims of frame 0 through the eigen pseudo-inverse (:329-346) ----------
-  // Amm = 0.5 (A + A^T) is symmetric by construction here.  Work on a 16-stride copy in V's space.
-  double* Amm = V;            // 15 x 15, stride 16
-  double* Vmm = V + 16 * 16;  // eigenvectors
-  for (int it = tid; it < 225; it += T) Amm[(it / 15) * 16 + it % 15] = 0.5 * (A[(it / 15) * MD + it % 15] + A[(it % 15) * MD + it / 15]);
+  double* Em0 = E0;
+  double* Em1 = E0 + 16 * 17;
+  double* Vmm = E0 + 2 * 16 * 17;
+  for (int it = tid; it < 16 * 16; it += T) {
+    const int i = it / 16, j = it % 16;
+    Em0[i * 17 + j] = (i < 15 && j < 15) ? 0.5 * (Ad[i * ldd + j] + Ad[j * ldd + i]) : 0.0;
+  }
   __syncthreads();
-  jacobi_eig(Amm, Vmm, 15, 16, cs, prm, red);
-  // Amm_inv = V diag(1/l if l > eps) V^T  -> stored over Amm's off-diagonal-free space: reuse tmp
-  double* Ainv = V + 2 * 16 * 16;   // 15 x 15 stride 16
+  double* Emm = jacobi_eig(Em0, Em1, Vmm, 16, 17, cs, prm, red, nullptr);
+  double* Ainv = (Emm == Em0) ? Em1 : Em0;   // the other buffer is free now
   for (int it = tid; it < 225; it += T) {
     const int i = it / 15, j = it % 15;
     double s = 0;
     for (int k = 0; k < 15; ++k) {
-      const double lam = Amm[k * 16 + k];
-      if (lam > kMargEps) s += Vmm[i * 16 + k] * Vmm[j * 16 + k] / lam;
+      const double lam = Emm[k * 17 + k];
+      if (lam > kMargEps) s += Vmm[i * 17 + k] * Vmm[j * 17 + k] / lam;
     }
-    Ainv[i * 16 + j] = s;
+    Ainv[i * 17 + j] = s;
   }
   __syncthreads();
   // tmp = Arm * Amm_inv  (n x 15)
   for (int it = tid; it < n * 15; it += T) {
     const int i = it / 15, j = it % 15;
     double s = 0;
-    for (int k = 0; k < 15; ++k) s += A[(15 + i) * MD + k] * Ainv[k * 16 + j];
+    for (int k = 0; k < 15; ++k) s += Ad[(15 + i) * ldd + k] * Ainv[k * 17 + j];
     tmp[i * 16 + j] = s;
   }
   __syncthreads();
-  // A <- Arr - tmp * Amr ; b <- brr - tmp * bmm   (results moved to the top-left n x n of V's upper area later)
-  double* An = V + 3 * 16 * 16;   // n x n, stride MD  (fits: 768 + 75*96 < MD*MD)
-  for (int it = tid; it < n * n; it += T) {
-    const int i = it / n, j = it % n;
-    double s = 0;
-    for (int k = 0; k < 15; ++k) s += tmp[i * 16 + k] * A[k * MD + 15 + j];
-    An[i * MD + j] = A[(15 + i) * MD + 15 + j] - s;
+  // A0 <- Arr - tmp * Amr (padded to m x m with zeros) ; b <- brr - tmp * bmm
+  double* Aout = B.mg_A + (size_t)w * MAXKEEP * MAXKEEP;
+  double* bout = B.mg_b + (size_t)w * MAXKEEP;
+  for (int it = tid; it < m * m; it += T) {
+    const int i = it / m, j = it % m;
+    double v = 0.0;
+    if (i < n && j < n) {
+      double s = 0;
+      for (int k = 0; k < 15; ++k) s += tmp[i * 16 + k] * Ad[k * ldd + 15 + j];
+      v = Ad[(15 + i) * ldd + 15 + j] - s;
+      Aout[i * n + j] = v;
+    }
+    A0[i * ldm + j] = v;
   }
   for (int i = tid; i < n; i += T) {
     double s = 0;
     for (int k = 0; k < 15; ++k) s += tmp[i * 16 + k] * bv[k];
-    cs[i] = bv[15 + i] - s;   // cs doubles as b_n until the eig below (copied out first)
+    const double v = bv[15 + i] - s;
+    cs[i] = v;
   }
   __syncthreads();
-  double* Aout = B.mg_A + (size_t)w * MAXKEEP * MAXKEEP;
-  double* bout = B.mg_b + (size_t)w * MAXKEEP;
-  for (int it = tid; it < n * n; it += T) Aout[it] = An[(it / n) * MD + it % n];
-  for (int i = tid; i < n; i += T) { bout[i] = cs[i]; bv[i] = cs[i]; }
+  for (int i = tid; i < n; i += T) { bv[i] = cs[i]; bout[i] = cs[i]; }
   __syncthreads();
-  // ---- eigen decomposition of the kept block (:349-357) ------------------------------------------
-  // move An to A (stride MD), eigenvectors into V
-  for (int it = tid; it < n * n; it += T) A[(it / n) * MD + it % n] = Aout[it];
-  __syncthreads();
-  jacobi_eig(A, V, n, MD, cs, prm, red);
+  // ---- eigen decomposition of the kept block (:349-357): workspace now holds A1 and V ------------
+  double* A1 = WSP;
+  double* V = WSP + L.EB;
+  double* Af = jacobi_eig(A0, A1, V, m, ldm, cs, prm, red, B.mg_m + w);
   double* J0 = B.mg_J0 + (size_t)w * MAXKEEP * MAXKEEP;
   double* r0 = B.mg_r0 + (size_t)w * MAXKEEP;
-  // the reference's SelfAdjointEigenSolver returns eigenvalues ascending; row order of J0 is
-  // irrelevant to the prior it defines (rows of an orthogonal transform), kept in Jacobi order.
+  // the reference's SelfAdjointEigenSolver returns eigenvalues ascending; the row order of J0 is
+  // irrelevant to the prior it defines (an orthogonal transform of the residual), kept in Jacobi order.
   for (int it = tid; it < n * n; it += T) {
     const int k = it / n, i = it % n;
-    const double lam = A[k * MD + k];
+    const double lam = Af[k * ldm + k];
     const double S = lam > kMargEps ? lam : 0.0;
-    J0[it] = sqrt(S) * V[i * MD + k];
+    J0[it] = sqrt(S) * V[i * ldm + k];
   }
   for (int k = tid; k < n; k += T) {
-    const double lam = A[k * MD + k];
+    const double lam = Af[k * ldm + k];
     const double Sinv = lam > kMargEps ? 1.0 / lam : 0.0;
     double vb = 0;
-    for (int i = 0; i < n; ++i) vb += V[i * MD + k] * bv[i];
+    for (int i = 0; i < n; ++i) vb += V[i * ldm + k] * bv[i];
     r0[k] = sqrt(Sinv) * vb;
   }
   // x0 of the kept blocks: the linearisation point (preMarginalize copies, :110-129)
@@ -360,7 +395,5 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     for (int k = 0; k < 9; ++k) B.mg_x0[((size_t)w * MAXPB + tid) * 9 + k] = k < gs ? x[k] : 0.0;
   }
 }
-
-constexpr size_t MARG_SMEM = (size_t)(2 * MD * MD + MD + MD * 16 + MD + 20) * sizeof(double) + 2 * MD * sizeof(int);
 
 }  // namespace vpl

@@ -36,6 +36,7 @@ struct vpl_ctx {
   // host-side marg structure of the uploaded windows
   std::vector<int> h_mg_m;
   std::vector<int> h_nP, h_nL;
+  size_t marg_smem = 0;
 };
 
 static int fail(vpl_ctx* c, int code, const std::string& msg) {
@@ -191,7 +192,8 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   hipFuncSetAttribute((const void*)k_lin<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_SMEM);
   hipFuncSetAttribute((const void*)k_lin<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_SMEM);
   hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
-  hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_SMEM);
+  hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+  (void)hipGetLastError();
   vpl_ba_default_options(&c->opt);
   *out = c;
   return VPL_OK;
@@ -451,6 +453,12 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
       c->h_mg_m[w] = m;
     }
   }
+  {
+    int nmax = 0;
+    for (size_t w = 0; w < W; ++w) nmax = std::max(nmax, mg_n[w]);
+    c->marg_smem = (size_t)marg_layout(nmax).total * sizeof(double);
+    if (c->marg_smem > 159 * 1024) return fail(c, VPL_E_CAPACITY, "marginalisation workspace exceeds LDS");
+  }
   HIPCHK(c, up(c, B.pose, pose)); HIPCHK(c, up(c, B.sb, sb)); HIPCHK(c, up(c, B.ex, ex)); HIPCHK(c, up(c, B.invd, invd));
   HIPCHK(c, up(c, B.plk, plk));
   HIPCHK(c, up(c, B.pose_0, pose)); HIPCHK(c, up(c, B.sb_0, sb)); HIPCHK(c, up(c, B.ex_0, ex)); HIPCHK(c, up(c, B.invd_0, invd));
@@ -501,7 +509,7 @@ int vpl_ba_solve(vpl_ctx* c) {
   { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
   if (c->opt.marginalization_flag == VPL_MARGIN_OLD) {
     { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<true>, grid, dim3(LIN_THREADS), LIN_SMEM, s, B); }
-    { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), MARG_SMEM, s, B); }
+    { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   }
   HIPCHK(c, hipGetLastError());
   return VPL_OK;
@@ -594,6 +602,11 @@ int vpl_ba_debug_marg_Ab(vpl_ctx* c, int w, double* A, double* b) {
   HIPCHK(c, hipMemcpy(A, c->B.mg_A + (size_t)w * MAXKEEP * MAXKEEP, (size_t)n * n * 8, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(b, c->B.mg_b + (size_t)w * MAXKEEP, (size_t)n * 8, hipMemcpyDeviceToHost));
   return n;
+}
+
+int vpl_ba_debug_sweeps(vpl_ctx* c, int* out) {
+  HIPCHK(c, hipMemcpy(out, c->B.mg_m, c->nW * 4, hipMemcpyDeviceToHost));
+  return VPL_OK;
 }
 
 int vpl_ba_enable_kernel_timing(vpl_ctx* c, int enable) {
