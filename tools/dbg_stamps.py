@@ -1,0 +1,18 @@
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import vplines_slam_amd as v, oracle_api as o
+from test_gpu_solve import make_windows
+nw = 512
+ctx = v.Context(device=0, max_windows=nw)
+ws, opt = make_windows(nw, 200, 80, True)
+opt.num_iterations = 1
+ctx.solve_windows(ws, opt)
+ctx.lib.vpl_ba_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
+for w in (0, 1, 300):
+    out = (C.c_longlong * 64)()
+    ctx.lib.vpl_ba_debug_stamps(ctx.h, w, out)
+    s = list(out)
+    print("window", w, "k_solve phases (cycles):", [s[i + 1] - s[i] for i in range(0, 7)])
+    print("   k_lin phases:", [s[i + 1] - s[i] for i in range(16, 21)])

@@ -45,6 +45,8 @@ def build_hip(force=False, verbose=False):
         return HIP_LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_LIB] + srcs
+    if os.environ.get("VPL_STAMPS"):
+        cmd.insert(1, "-DVPL_STAMPS")
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     out = _run(cmd)

@@ -6,6 +6,12 @@
 
 namespace vpl {
 
+#ifdef VPL_STAMPS
+#define VPL_STAMP(B, w, i) do { if (threadIdx.x == 0) (B).dbg[(size_t)(w) * 64 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define VPL_STAMP(B, w, i) do {} while (0)
+#endif
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

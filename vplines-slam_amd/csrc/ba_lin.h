@@ -164,6 +164,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   for (int i = tid; i < NC; i += T) invmap[i] = -1;
   __syncthreads();
   double cost = 0.0;
+  VPL_STAMP(B, w, 16);
 
   // ---- prior: r = r0 + J0 dx ; g = J0^T r -------------------------------------------
   const int n = B.pr_n[w];
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     }
   }
 
+  VPL_STAMP(B, w, 17);
   // ---- IMU factors: raw residual / Jacobian per factor, then cooperative whitening ------
   if (tid < 10) {
     const int j = tid + 1;
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     cost += 0.5 * s;
   }
 
+  VPL_STAMP(B, w, 18);
   // ---- visual factors ----------------------------------------------------------------------
   const double* xe = xp + 77;
   double Aee[21], ge[6];
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     }
   }
 
+  VPL_STAMP(B, w, 19 + (threadIdx.x >= 448 ? 0 : 0));
   // extrinsic-extrinsic block and gradient: wave reduction, then one LDS add per wave
   {
     const int lane = tid & 63;
@@ -423,6 +427,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   }
   __syncthreads();
 
+  VPL_STAMP(B, w, 20);
   // ---- assemble the packed cam Hessian and gradient in HBM -----------------------------------
   double* Hout = B.Hcc + (size_t)w * NCP;
   const double* pH = B.pr_H + (size_t)w * MAXPN * MAXPN;
@@ -490,6 +495,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     if (!ex_free && r >= 165) v = 0.0;
     B.gc[(size_t)w * NC + r] = v;
   }
+  VPL_STAMP(B, w, 21);
   cost = block_sum(cost, red);
   if (tid == 0 && !MARG) {
     tr->x_cost = cost;

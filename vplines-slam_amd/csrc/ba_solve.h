@@ -17,8 +17,10 @@ namespace vpl {
 
 constexpr int SOLVE_THREADS = 512;
 constexpr int NA = NC + 1;                   // reduced system augmented with the rhs as last row
-constexpr int NAP = NA * (NA + 1) / 2;       // 14878
-constexpr int TK = 36;                       // rows of the landmark tile staged per pass
+constexpr int NT16 = 11;                     // 16x16 tiles per dimension (176 >= 172)
+constexpr int NTILES = NT16 * (NT16 + 1) / 2;  // lower-triangular tile count (66)
+constexpr int NAP = NTILES * 256;            // tile-major lower storage of the reduced system (16896 doubles)
+constexpr int TK = 16;                       // rows of the landmark tile staged per pass
 constexpr int TW = NV + 1;                   // tile width: 72 vis dims + rhs column
 constexpr int NB3 = 25;                      // 3-wide output blocks over the 73(+2 pad) tile columns
 
@@ -28,21 +30,52 @@ constexpr double kMinRelDecrease = 1e-3, kFuncTol = 1e-6, kParamTol = 1e-8, kMin
 constexpr int kMaxInvalid = 5;
 
 __device__ __forceinline__ int tcol2row(int a) { return a < NV ? vis2cam(a) : NC; }
+// tile-major index of element (r, c), r >= c (or both inside a diagonal tile)
+__device__ __forceinline__ int tix(int r, int c) {
+  const int I = r >> 4, J = c >> 4;
+  return ((I * (I + 1) / 2 + J) << 8) + ((r & 15) << 4) + (c & 15);
+}
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// Compact "vis" system used by the Schur accumulation: 72 vis dims + rhs column (72) + Cauchy
+// column (73), padded to 80 = 5 tiles of 16.  15 lower tiles live in MFMA accumulators.
+constexpr int CW = 80;             // staged row width (doubles)
+constexpr int CROWS = 64;          // landmark rows per staged chunk
+constexpr int NCT = 15;            // lower tiles of the 5x5 compact tile grid
+
+__device__ __forceinline__ void chol4(double* A, bool& ok) {   // packed lower 4x4, in place
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double d = A[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < j) d -= A[tri(j, k)] * A[tri(j, k)];
+    if (!(d > 0.0)) { ok = false; d = 1.0; }
+    d = sqrt(d);
+    A[tri(j, j)] = d;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i > j) {
+      double s2 = A[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (k < j) s2 -= A[tri(i, k)] * A[tri(j, k)];
+      A[tri(i, j)] = s2 / d;
+    }
+  }
+}
 
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
   const int w = blockIdx.x, tid = threadIdx.x, T = SOLVE_THREADS;
+  const int lane = tid & 63, wv = tid >> 6;
   TrState* tr = &B.tr[w];
   if (tr->status != 0) return;
   extern __shared__ double sm[];
-  double* S = sm;                 // NAP packed lower (row NC = rhs)
-  double* sc = S + NAP;           // NC  jacobi scale of cam dims
-  double* dg = sc + NC;           // NC  dogleg diagonal of cam dims
-  double* uc = dg + NC;           // NC  work vector (u for the Cauchy point, later S_c y_c)
-  double* yv = uc + NC;           // NC  solution of the reduced system / z
-  double* tile = yv + NC;         // TK * (TW+2)
-  double* Cl = tile + TK * (TW + 2);  // (TK/4) * 10 line Cholesky factors
-  double* red = Cl + (TK / 4) * 10;   // 20
-  int* flag = (int*)(red + 20);       // 4
+  double* S = sm;                 // NAP tile-major lower (row NC = rhs); first used as 2 staging buffers
+  double* sc = S + NAP;           // 176 jacobi scale of cam dims
+  double* dg = sc + 176;          // 176 dogleg diagonal of cam dims
+  double* uc = dg + 176;          // 176 work vector (u for the Cauchy point, later S_c y_c)
+  double* yv = uc + 176;          // 176 solution of the reduced system / z
+  double* isd = yv + 176;         // 176 1/L_jj
+  double* red = isd + 176;        // 24
+  int* flag = (int*)(red + 24);   // 4
 
   const int nP = B.nP[w], nL = B.nL[w];
   const size_t fb = (size_t)w * B.nfull;
@@ -53,188 +86,233 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
   double* gdelta = B.delta + fb;
   const double* Hcc = B.Hcc + (size_t)w * NCP;
   const double* gc = B.gc + (size_t)w * NC;
+  double* lch = B.lchol + (size_t)w * B.maxL * 10;
   const int LP = NC, LL = NC + B.maxP;   // offsets of the landmark sections in the full index
   if (tid == 0) { flag[0] = 0; flag[1] = 0; }
   __syncthreads();
 
+  VPL_STAMP(B, w, 0);
   if (!tr->reuse) {
     // ---- jacobi scaling (iteration 0 only), diagonal_, gradient_ --------------------------
     const bool first = (tr->iter == 0);
-    double a1 = 0.0;
-    for (int c = tid; c < NC; c += T) {
-      const double h = Hcc[tri(c, c)];
-      double s = first ? 1.0 / (1.0 + sqrt(h)) : gscale[c];
-      if (first) gscale[c] = s;
-      double d = sqrt(fmin(fmax(s * s * h, kMinDiag), kMaxDiag));
-      double g = s * gc[c] / d;
+    double a1 = 0.0, q = 0.0;
+    for (int c = tid; c < 176; c += T) {
+      double s = 0.0, d = 1.0, g = 0.0;
+      if (c < NC) {
+        const double h = Hcc[tri(c, c)];
+        s = first ? 1.0 / (1.0 + sqrt(h)) : gscale[c];
+        if (first) gscale[c] = s;
+        d = sqrt(fmin(fmax(s * s * h, kMinDiag), kMaxDiag));
+        g = s * gc[c] / d;
+        gdiag[c] = d; ggrad[c] = g;
+        a1 += g * g;
+      }
       sc[c] = s; dg[c] = d;
-      gdiag[c] = d; ggrad[c] = g;
       uc[c] = s * g / d;   // unscaled-space vector of gradient_/diagonal_
-      a1 += g * g;
     }
-    double q = 0.0;
-    __syncthreads();
     for (int p = tid; p < nP; p += T) {
       const size_t pi = (size_t)w * B.maxP + p;
       const double h = B.Hpp[pi];
-      double s = first ? 1.0 / (1.0 + sqrt(h)) : gscale[LP + p];
+      const double s = first ? 1.0 / (1.0 + sqrt(h)) : gscale[LP + p];
       if (first) gscale[LP + p] = s;
-      double d = sqrt(fmin(fmax(s * s * h, kMinDiag), kMaxDiag));
-      double g = s * B.gp[pi] / d;
+      const double d = sqrt(fmin(fmax(s * s * h, kMinDiag), kMaxDiag));
+      const double g = s * B.gp[pi] / d;
       gdiag[LP + p] = d; ggrad[LP + p] = g;
       a1 += g * g;
       const double u = s * g / d;
-      const double* Wr = B.Wp + pi * NV;
-      double wu = 0;
-      for (int k = 0; k < NV; ++k) wu += Wr[k] * uc[vis2cam(k)];
-      q += u * (h * u + 2.0 * wu);
+      q += u * h * u;
     }
     for (int l = tid; l < nL; l += T) {
       const size_t li = (size_t)w * B.maxL + l;
       const double* Hl = B.Hll + li * 16;
       double u[4];
+#pragma unroll
       for (int a = 0; a < 4; ++a) {
         const double h = Hl[5 * a];
-        double s = first ? 1.0 / (1.0 + sqrt(h)) : gscale[LL + 4 * l + a];
+        const double s = first ? 1.0 / (1.0 + sqrt(h)) : gscale[LL + 4 * l + a];
         if (first) gscale[LL + 4 * l + a] = s;
-        double d = sqrt(fmin(fmax(s * s * h, kMinDiag), kMaxDiag));
-        double g = s * B.gl[li * 4 + a] / d;
+        const double d = sqrt(fmin(fmax(s * s * h, kMinDiag), kMaxDiag));
+        const double g = s * B.gl[li * 4 + a] / d;
         gdiag[LL + 4 * l + a] = d; ggrad[LL + 4 * l + a] = g;
         a1 += g * g;
         u[a] = s * g / d;
       }
-      const double* Wl = B.Wl + li * 4 * NV;
+#pragma unroll
       for (int a = 0; a < 4; ++a) {
-        double wu = 0;
-        for (int k = 0; k < NV; ++k) wu += Wl[a * NV + k] * uc[vis2cam(k)];
         double hu = 0;
+#pragma unroll
         for (int b = 0; b < 4; ++b) hu += Hl[4 * a + b] * u[b];
-        q += u[a] * (hu + 2.0 * wu);
+        q += u[a] * hu;
       }
     }
-    // u_c^T Hcc u_c while loading the packed Hessian into LDS
-    for (int idx = tid; idx < NCP; idx += T) {
-      int r, c;
-      tri_decode(idx, r, c);
-      const double h = Hcc[idx];
-      S[idx] = h;
-      q += (r == c ? 1.0 : 2.0) * uc[r] * h * uc[c];
-    }
-    for (int c = tid; c < NC; c += T) S[tri(NC, c)] = gc[c];
     a1 = block_sum(a1, red);
     q = block_sum(q, red);
-    const double alpha = a1 / q;   // DoglegStrategy::ComputeCauchyPoint
+    VPL_STAMP(B, w, 1);
 
     // ---- Gauss-Newton step: (J^T J + mu D^2) y = J^T r via the Schur complement -------------
     double mu = tr->mu;
     bool solved = false;
+    double alpha = 0.0;
     while (mu < kMaxMu) {
-      // 3x3 register blocks of T -= A''^T A''
-      const bool own = tid < NB3 * (NB3 + 1) / 2;
-      int ba = 0, bb = 0;
-      if (own) tri_decode(tid, ba, bb);
-      double acc[9];
+      // per-landmark regularised blocks: points A = s^2 H + mu d^2 -> row scale s/sqrt(A) (kept in ggn as
+      // scratch); lines A_l = S H S + mu D^2 = C C^T -> C kept in lch
+      for (int p = tid; p < nP; p += T) {
+        const size_t pi = (size_t)w * B.maxP + p;
+        const double s = gscale[LP + p], d = gdiag[LP + p];
+        const double Al = s * s * B.Hpp[pi] + mu * d * d;
+        if (!(Al > 0.0)) flag[0] = 1;
+        ggn[LP + p] = s / sqrt(Al);
+      }
+      for (int l = tid; l < nL; l += T) {
+        const size_t li = (size_t)w * B.maxL + l;
+        const double* Hl = B.Hll + li * 16;
+        double A[10];
+        int t = 0;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-      const int rowsP = nP, rowsL = 4 * nL;
-      for (int base = 0; base < rowsP + rowsL; ) {
-        const bool isP = base < rowsP;
-        int cnt;
-        __syncthreads();
-        if (isP) {
-          cnt = min(TK, rowsP - base);
-          // points: row = sqrt(m) [W | g],  m = s^2 / (s^2 H + mu d^2)
-          for (int it = tid; it < cnt * TW; it += T) {
-            const int rr = it / TW, c = it % TW;
-            const int p = base + rr;
-            const size_t pi = (size_t)w * B.maxP + p;
-            const double s = gscale[LP + p], d = gdiag[LP + p];
-            const double Al = s * s * B.Hpp[pi] + mu * d * d;
-            if (!(Al > 0.0)) flag[0] = 1;
-            const double sm_ = s / sqrt(Al);
-            tile[rr * (TW + 2) + c] = sm_ * (c < NV ? B.Wp[pi * NV + c] : B.gp[pi]);
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) if (b <= a) {
+            A[t] = gscale[LL + 4 * l + a] * gscale[LL + 4 * l + b] * Hl[4 * a + b];
+            if (a == b) { const double d = gdiag[LL + 4 * l + a]; A[t] += mu * d * d; }
+            ++t;
+          }
+        bool ok = true;
+        chol4(A, ok);
+        if (!ok) flag[0] = 1;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) lch[l * 10 + k] = A[k];
+      }
+      __syncthreads();
+      // ---- Schur accumulation on the matrix cores: Acc = X^T X over all landmark rows, where a row of
+      //      X is C^-1 S_l [W | g | e] (e chosen so that X^T e = W^T u: the Cauchy cross term).
+      //      Rows are streamed through two LDS buffers of CROWS x CW; 15 lower 16x16 tiles of the compact
+      //      80x80 result stay in accumulator registers (2 tiles per wave).
+      v4d acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      int ta0 = 0, tb0 = 0, ta1 = 0, tb1 = 0;
+      tri_decode(wv, ta0, tb0);
+      const bool has1 = wv + 8 < NCT;
+      if (has1) tri_decode(wv + 8, ta1, tb1);
+      const int nchP = (nP + CROWS - 1) / CROWS, nchL = (4 * nL + CROWS - 1) / CROWS;
+      const int nch = nchP + nchL;
+      double* buf0 = S;
+      double* buf1 = S + CROWS * CW;
+      auto stage = [&](int ch, double* buf) {
+        if (ch < nchP) {
+          const int r0 = ch * CROWS, cnt = min(CROWS, nP - r0);
+          for (int it = tid; it < CROWS * CW; it += T) {
+            const int rr = it / CW, c = it - rr * CW;
+            double v = 0.0;
+            if (rr < cnt && c < 74) {
+              const int p = r0 + rr;
+              const size_t pi = (size_t)w * B.maxP + p;
+              const double smv = ggn[LP + p];
+              if (c < NV) v = smv * B.Wp[pi * NV + c];
+              else if (c == NV) v = smv * B.gp[pi];
+              else v = (gscale[LP + p] * ggrad[LP + p] / gdiag[LP + p]) / smv;   // e = u / (s/sqrt(A))
+            }
+            buf[it] = v;
           }
         } else {
-          const int l0 = (base - rowsP) / 4;
-          const int nl = min(TK / 4, nL - l0);
-          cnt = 4 * nl;
-          if (tid < nl) {   // Cholesky of A_l = S H S + mu D^2
-            const int l = l0 + tid;
-            const size_t li = (size_t)w * B.maxL + l;
-            const double* Hl = B.Hll + li * 16;
-            double A[10];
-            int t = 0;
-            for (int a = 0; a < 4; ++a)
-              for (int b = 0; b <= a; ++b, ++t) {
-                const double sa = gscale[LL + 4 * l + a], sb_ = gscale[LL + 4 * l + b];
-                A[t] = sa * sb_ * Hl[4 * a + b];
-                if (a == b) { const double d = gdiag[LL + 4 * l + a]; A[t] += mu * d * d; }
-              }
-            // packed lower Cholesky 4x4
-            bool ok = true;
-            for (int j = 0; j < 4; ++j) {
-              double d = A[tri(j, j)];
-              for (int k = 0; k < j; ++k) d -= A[tri(j, k)] * A[tri(j, k)];
-              if (!(d > 0.0)) { ok = false; d = 1.0; }
-              d = sqrt(d);
-              A[tri(j, j)] = d;
-              for (int i = j + 1; i < 4; ++i) {
-                double s2 = A[tri(i, j)];
-                for (int k = 0; k < j; ++k) s2 -= A[tri(i, k)] * A[tri(j, k)];
-                A[tri(i, j)] = s2 / d;
+          const int l0 = (ch - nchP) * (CROWS / 4), cnt = min(CROWS / 4, nL - l0);
+          for (int it = tid; it < (CROWS / 4) * CW; it += T) {
+            const int ll = it / CW, c = it - ll * CW;
+            double x[4] = {0, 0, 0, 0};
+            if (ll < cnt && c < 74) {
+              const int l = l0 + ll;
+              const size_t li = (size_t)w * B.maxL + l;
+              const double* C = lch + l * 10;
+              if (c <= NV) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                  const double v = c < NV ? B.Wl[(li * 4 + a) * NV + c] : B.gl[li * 4 + a];
+                  double s2 = gscale[LL + 4 * l + a] * v;
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) if (k < a) s2 -= C[tri(a, k)] * x[k];
+                  x[a] = s2 / C[tri(a, a)];
+                }
+              } else {   // e = C^T (u ./ s),  u = s g~ / d  =>  u/s = g~/d
+                double us[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) us[a] = ggrad[LL + 4 * l + a] / gdiag[LL + 4 * l + a];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                  double s2 = 0;
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) if (k >= a) s2 += C[tri(k, a)] * us[k];
+                  x[a] = s2;
+                }
               }
             }
-            if (!ok) flag[0] = 1;
-            for (int k = 0; k < 10; ++k) Cl[tid * 10 + k] = A[k];
-          }
-          __syncthreads();
-          // rows X = C^-1 (S_l [W_l | g_l])  column by column
-          for (int it = tid; it < nl * TW; it += T) {
-            const int ll = it / TW, c = it % TW;
-            const int l = l0 + ll;
-            const size_t li = (size_t)w * B.maxL + l;
-            const double* C = Cl + ll * 10;
-            double x[4];
-            for (int a = 0; a < 4; ++a) {
-              const double v = c < NV ? B.Wl[(li * 4 + a) * NV + c] : B.gl[li * 4 + a];
-              double s2 = gscale[LL + 4 * l + a] * v;
-              for (int k = 0; k < a; ++k) s2 -= C[tri(a, k)] * x[k];
-              x[a] = s2 / C[tri(a, a)];
-              tile[(4 * ll + a) * (TW + 2) + c] = x[a];
-            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) buf[(4 * ll + a) * CW + c] = x[a];
           }
         }
-        // pad columns 73,74 of the tile are never read as outputs of interest but must be finite
-        for (int it = tid; it < cnt * 2; it += T) tile[(it >> 1) * (TW + 2) + TW + (it & 1)] = 0.0;
+      };
+      if (nch > 0) stage(0, buf0);
+      __syncthreads();
+      for (int ch = 0; ch < nch; ++ch) {
+        double* cur = (ch & 1) ? buf1 : buf0;
+        if (ch + 1 < nch) stage(ch + 1, (ch & 1) ? buf0 : buf1);
+        const int m = lane & 15, kk = lane >> 4;
+#pragma unroll 4
+        for (int ks = 0; ks < CROWS / 4; ++ks) {
+          const double* row = cur + (4 * ks + kk) * CW;
+          const double a0 = row[16 * ta0 + m], b0 = row[16 * tb0 + m];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+          if (has1) {
+            const double a1v = row[16 * ta1 + m], b1v = row[16 * tb1 + m];
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1v, acc1, 0, 0, 0);
+          }
+        }
         __syncthreads();
-        if (own) {
-          const double* ta = tile + 3 * ba;
-          const double* tb = tile + 3 * bb;
-          for (int rr = 0; rr < cnt; ++rr) {
-            const double a0 = ta[rr * (TW + 2)], a1_ = ta[rr * (TW + 2) + 1], a2 = ta[rr * (TW + 2) + 2];
-            const double b0 = tb[rr * (TW + 2)], b1 = tb[rr * (TW + 2) + 1], b2 = tb[rr * (TW + 2) + 2];
-            acc[0] += a0 * b0; acc[1] += a0 * b1; acc[2] += a0 * b2;
-            acc[3] += a1_ * b0; acc[4] += a1_ * b1; acc[5] += a1_ * b2;
-            acc[6] += a2 * b0; acc[7] += a2 * b1; acc[8] += a2 * b2;
-          }
-        }
-        base += cnt;
       }
+      VPL_STAMP(B, w, 2);
+      // ---- reduced system: S = Hcc - X^T X (tile-major), rhs row = gc - X^T z; Cauchy denominator ----
+      for (int idx = tid; idx < NAP; idx += T) S[idx] = 0.0;
       __syncthreads();
-      if (own) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const int a = 3 * ba + i, b = 3 * bb + j;
-            if (a < TW && b < TW && a >= b && !(a == NV && b == NV)) S[tri(tcol2row(a), tcol2row(b))] -= acc[3 * i + j];
-          }
-      }
-      __syncthreads();
-      // scale to the Jacobi-scaled space and add the LM diagonal
-      for (int idx = tid; idx < NAP - 1; idx += T) {
+      double qq = 0.0;
+      for (int idx = tid; idx < NCP; idx += T) {
         int r, c;
         tri_decode(idx, r, c);
+        const double h = Hcc[idx];
+        S[tix(r, c)] = h;
+        if ((r >> 4) == (c >> 4)) S[tix(c, r)] = h;   // diagonal tiles are kept as full squares
+        qq += (r == c ? 1.0 : 2.0) * uc[r] * h * uc[c];
+      }
+      for (int c = tid; c < NC; c += T) S[tix(NC, c)] = gc[c];
+      if (tid < 5) S[tix(NC + tid, NC + tid)] = 1.0;   // padding rows 171..175: unit pivots, never used
+      __syncthreads();
+      {
+        const int m = lane & 15, kk = lane >> 4;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if (half == 1 && !has1) break;
+          const v4d acc = half ? acc1 : acc0;
+          const int ta = half ? ta1 : ta0, tb = half ? tb1 : tb0;
+          const double vals[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int a = 16 * ta + kk + 4 * v, b = 16 * tb + m;   // compact row / col
+            if (a < b || b >= NV || a > NV + 1) continue;
+            if (a <= NV) {
+              const int ra = tcol2row(a), rb = vis2cam(b);
+              S[tix(ra, rb)] -= vals[v];
+              if ((ra >> 4) == (rb >> 4) && ra != rb) S[tix(rb, ra)] -= vals[v];
+            } else {
+              qq += 2.0 * vals[v] * uc[vis2cam(b)];   // (W^T u)_b u_c,b
+            }
+          }
+        }
+      }
+      qq = block_sum(qq, red);
+      alpha = a1 / (q + qq);   // DoglegStrategy::ComputeCauchyPoint
+      // scale to the Jacobi-scaled space and add the LM diagonal
+      for (int idx = tid; idx < NAP; idx += T) {
+        const int tl = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
+        int I, J;
+        tri_decode(tl, I, J);
+        const int r = 16 * I + rr, c = 16 * J + cc;
+        if (r > NC || c >= NC) continue;
         double v = S[idx];
         if (r < NC) {
           v *= sc[r] * sc[c];
@@ -245,28 +323,96 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
         S[idx] = v;
       }
       __syncthreads();
-      // Cholesky, right-looking, one barrier per column; the rhs row rides along (forward solve for free)
-      {
-        const int tx = tid & 31, ty = tid >> 5;
-        for (int j = 0; j < NC; ++j) {
-          const double ajj = S[tri(j, j)];
-          if (!(ajj > 0.0)) { if (tid == 0) flag[0] = 1; break; }   // uniform: every lane reads the same value
-          const double inv = 1.0 / ajj;
-          for (int r = j + 1 + ty; r <= NC; r += 16) {
-            const double f = S[tri(r, j)] * inv;
-            const int cmax = r < NC ? r : NC - 1;
-            for (int c = j + 1 + tx; c <= cmax; c += 32) S[tri(r, c)] -= f * S[tri(c, j)];
+      VPL_STAMP(B, w, 3);
+      // ---- left-looking tile Cholesky (16x16 tiles).  Per tile column K:
+      //   (a) C(I,K) -= sum_{J<K} L(I,J) L(K,J)^T  on the FP64 matrix cores, accumulator in registers
+      //   (b) factor the diagonal tile (one wave, 16 column steps)
+      //   (c) rows below: x = a L(K,K)^-T, one lane per row
+      // The rhs row (row NC, inside tile row 10) rides along: forward substitution for free.
+      for (int K = 0; K < NT16; ++K) {
+        if (K > 0) {
+          for (int I = K + wv; I < NT16; I += SOLVE_THREADS / 64) {
+            const int m = lane & 15, kk = lane >> 4;
+            double* Ct = S + ((I * (I + 1) / 2 + K) << 8);
+            v4d c;
+            c.x = Ct[kk * 16 + m]; c.y = Ct[(kk + 4) * 16 + m]; c.z = Ct[(kk + 8) * 16 + m]; c.w = Ct[(kk + 12) * 16 + m];
+            for (int J = 0; J < K; ++J) {
+              const double* Ai = S + ((I * (I + 1) / 2 + J) << 8);
+              const double* Bk = S + ((K * (K + 1) / 2 + J) << 8);
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) {
+                const double av = -Ai[m * 16 + 4 * ks + kk];
+                const double bv = Bk[m * 16 + 4 * ks + kk];
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+              }
+            }
+            Ct[kk * 16 + m] = c.x; Ct[(kk + 4) * 16 + m] = c.y; Ct[(kk + 8) * 16 + m] = c.z; Ct[(kk + 12) * 16 + m] = c.w;
           }
           __syncthreads();
         }
+        if (wv == 0) {   // diagonal tile: right-looking 16x16, lanes tile the trailing block
+          double* D = S + ((K * (K + 1) / 2 + K) << 8);
+          const int r4 = lane >> 4, cc = lane & 15;   // lane handles rows r4, r4+4, r4+8, r4+12 of column cc
+          for (int j = 0; j < 16; ++j) {
+            const int gj = 16 * K + j;
+            if (gj >= NC) break;
+            const double ajj = D[j * 16 + j];
+            if (!(ajj > 0.0)) { if (lane == 0) flag[0] = 1; break; }
+            const double inv = 1.0 / ajj;
+            const double lcj = D[cc * 16 + j];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int r = r4 + 4 * v;
+              if (r > j && cc > j && cc <= r) D[r * 16 + cc] -= D[r * 16 + j] * lcj * inv;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+          // scale columns: L_ij = a_ij / sqrt(a_jj); publish 1/L_jj
+          for (int it = lane; it < 256; it += 64) {
+            const int r = it >> 4, c = it & 15;
+            const int gc2 = 16 * K + c;
+            if (gc2 < NC && r >= c) {
+              const double d = sqrt(D[c * 16 + c]);
+              if (r > c) D[r * 16 + c] = D[r * 16 + c] / d;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane < 16 && 16 * K + lane < NC) {
+            const double d = sqrt(D[lane * 16 + lane]);
+            isd[16 * K + lane] = 1.0 / d;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane < 16 && 16 * K + lane < NC) D[lane * 16 + lane] = 1.0 / isd[16 * K + lane];
+        }
+        __syncthreads();
+        if (flag[0]) break;
+        {   // rows below the diagonal tile (including the rest of the rhs row's tile row)
+          const int nrow = 16 * (NT16 - 1 - K);
+          const double* D = S + ((K * (K + 1) / 2 + K) << 8);
+          const int ncol = min(16, NC - 16 * K);
+          for (int rr = tid; rr < nrow; rr += T) {
+            const int r = 16 * (K + 1) + rr;
+            if (r > NC) continue;
+            double* Ar = S + (((r >> 4) * ((r >> 4) + 1) / 2 + K) << 8) + (r & 15) * 16;
+            double x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              double s2 = Ar[j];
+#pragma unroll
+              for (int k = 0; k < 16; ++k) if (k < j) s2 -= x[k] * D[j * 16 + k];
+              x[j] = j < ncol ? s2 * isd[16 * K + j] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (j < ncol) Ar[j] = x[j];
+          }
+        }
+        __syncthreads();
       }
       __syncthreads();
       if (flag[0]) {   // LINEAR_SOLVER_FAILURE: raise mu and retry from the stored linearisation
         mu *= kMuIncrease;
         __syncthreads();
         if (tid == 0) flag[0] = 0;
-        for (int idx = tid; idx < NCP; idx += T) S[idx] = Hcc[idx];
-        for (int c = tid; c < NC; c += T) S[tri(NC, c)] = gc[c];
         __syncthreads();
         continue;
       }
@@ -287,25 +433,34 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
       }
       return;
     }
-    // L = S with columns divided by sqrt(pivot); z_j = S[NC][j] / sqrt(pivot_j)
-    // back substitution L^T y = z on one wave (column oriented, rows of L are contiguous)
-    double* isd = tile;   // 1/sqrt(pivot)
-    for (int c = tid; c < NC; c += T) {
-      const double v = 1.0 / sqrt(S[tri(c, c)]);
-      isd[c] = v;
-      yv[c] = S[tri(NC, c)] * v;
-    }
+    VPL_STAMP(B, w, 4);
+    // ---- back substitution L^T y = z, tile by tile from the bottom: the diagonal tile is solved by one
+    //      wave (16 dependent steps), the update z_J -= L(K,J)^T y_K is spread over the workgroup.
+    for (int c = tid; c < 176; c += T) yv[c] = c < NC ? S[tix(NC, c)] : 0.0;
     __syncthreads();
-    if (tid < 64) {
-      volatile double* yy = yv;
-      for (int j = NC - 1; j >= 0; --j) {
-        const double yj = yy[j] * isd[j];
-        for (int i = tid; i < j; i += 64) yy[i] -= (S[tri(j, i)] * isd[i]) * yj;
-        if (tid == 0) yy[j] = yj;
-        __builtin_amdgcn_wave_barrier();
+    for (int K = NT16 - 1; K >= 0; --K) {
+      const double* D = S + ((K * (K + 1) / 2 + K) << 8);
+      if (wv == 0) {
+        volatile double* yy = yv + 16 * K;
+        const int ncol = min(16, NC - 16 * K);
+        for (int j = ncol - 1; j >= 0; --j) {
+          const double yj = yy[j] * isd[16 * K + j];
+          if (lane < j) yy[lane] -= D[j * 16 + lane] * yj;
+          if (lane == 0) yy[j] = yj;
+          __builtin_amdgcn_wave_barrier();
+        }
       }
+      __syncthreads();
+      for (int c = tid; c < 16 * K; c += T) {
+        const double* Lk = S + ((K * (K + 1) / 2 + (c >> 4)) << 8) + (c & 15);
+        double s2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s2 += Lk[r * 16] * yv[16 * K + r];
+        yv[c] -= s2;
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    VPL_STAMP(B, w, 5);
     // y_c (scaled space) in yv; uc <- S_c y_c ; gn_c = -diag y
     double a2 = 0.0, a3 = 0.0;
     for (int c = tid; c < NC; c += T) {
@@ -317,62 +472,71 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
       a3 += ggrad[c] * gnv;
     }
     __syncthreads();
-    // landmark back substitution: y_l = A_l^-1 S_l (g_l - W_l S_c y_c)
-    for (int p = tid; p < nP; p += T) {
-      const size_t pi = (size_t)w * B.maxP + p;
-      const double s = gscale[LP + p], d = gdiag[LP + p];
-      const double Al = s * s * B.Hpp[pi] + mu * d * d;
-      const double* Wr = B.Wp + pi * NV;
-      double wy = 0;
-      for (int k = 0; k < NV; ++k) wy += Wr[k] * uc[vis2cam(k)];
-      const double y = s * (B.gp[pi] - wy) / Al;
-      const double gnv = -d * y;
-      ggn[LP + p] = gnv;
-      a2 += gnv * gnv;
-      a3 += ggrad[LP + p] * gnv;
-    }
-    for (int l = tid; l < nL; l += T) {
-      const size_t li = (size_t)w * B.maxL + l;
-      const double* Hl = B.Hll + li * 16;
-      double A[10], t4[4];
-      int t = 0;
-      for (int a = 0; a < 4; ++a) {
-        const double sa = gscale[LL + 4 * l + a];
-        for (int b = 0; b <= a; ++b, ++t) {
-          A[t] = sa * gscale[LL + 4 * l + b] * Hl[4 * a + b];
-          if (a == b) { const double d = gdiag[LL + 4 * l + a]; A[t] += mu * d * d; }
+    // ---- landmark back substitution y_l = A_l^-1 S_l (g_l - W_l S_c y_c): 8 lanes per landmark row so
+    //      that every 72-wide row of W is read as one contiguous 576-byte segment
+    {
+      const int sub = lane & 7, grp = tid >> 3;   // 64 row groups per pass
+      for (int p0 = 0; p0 < nP; p0 += T / 8) {
+        const int p = p0 + grp;
+        double wy = 0.0;
+        size_t pi = 0;
+        if (p < nP) {
+          pi = (size_t)w * B.maxP + p;
+          const double* Wr = B.Wp + pi * NV + 9 * sub;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) wy += Wr[k] * uc[vis2cam(9 * sub + k)];
         }
-        const double* Wl = B.Wl + (li * 4 + a) * NV;
-        double wy = 0;
-        for (int k = 0; k < NV; ++k) wy += Wl[k] * uc[vis2cam(k)];
-        t4[a] = sa * (B.gl[li * 4 + a] - wy);
-      }
-      for (int j = 0; j < 4; ++j) {
-        double d = A[tri(j, j)];
-        for (int k = 0; k < j; ++k) d -= A[tri(j, k)] * A[tri(j, k)];
-        d = sqrt(d);
-        A[tri(j, j)] = d;
-        for (int i = j + 1; i < 4; ++i) {
-          double s2 = A[tri(i, j)];
-          for (int k = 0; k < j; ++k) s2 -= A[tri(i, k)] * A[tri(j, k)];
-          A[tri(i, j)] = s2 / d;
+        wy += __shfl_xor(wy, 1, 64); wy += __shfl_xor(wy, 2, 64); wy += __shfl_xor(wy, 4, 64);
+        if (p < nP && sub == 0) {
+          const double s = gscale[LP + p], d = gdiag[LP + p];
+          const double Al = s * s * B.Hpp[pi] + mu * d * d;
+          const double y = s * (B.gp[pi] - wy) / Al;
+          const double gnv = -d * y;
+          ggn[LP + p] = gnv;
+          a2 += gnv * gnv;
+          a3 += ggrad[LP + p] * gnv;
         }
       }
-      for (int a = 0; a < 4; ++a) {
-        double s2 = t4[a];
-        for (int k = 0; k < a; ++k) s2 -= A[tri(a, k)] * t4[k];
-        t4[a] = s2 / A[tri(a, a)];
-      }
-      for (int a = 3; a >= 0; --a) {
-        double s2 = t4[a];
-        for (int k = a + 1; k < 4; ++k) s2 -= A[tri(k, a)] * t4[k];
-        t4[a] = s2 / A[tri(a, a)];
-      }
-      for (int a = 0; a < 4; ++a) {
-        const double gnv = -gdiag[LL + 4 * l + a] * t4[a];
-        ggn[LL + 4 * l + a] = gnv;
-        a2 += gnv * gnv;
-        a3 += ggrad[LL + 4 * l + a] * gnv;
+      for (int r0 = 0; r0 < 4 * nL; r0 += T / 8) {
+        const int r = r0 + grp, l = r >> 2, a = r & 3;
+        double wy = 0.0;
+        size_t li = 0;
+        if (l < nL) {
+          li = (size_t)w * B.maxL + l;
+          const double* Wr = B.Wl + (li * 4 + a) * NV + 9 * sub;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) wy += Wr[k] * uc[vis2cam(9 * sub + k)];
+        }
+        wy += __shfl_xor(wy, 1, 64); wy += __shfl_xor(wy, 2, 64); wy += __shfl_xor(wy, 4, 64);
+        // the 4 rows of a line sit in 4 adjacent 8-lane groups of the same wave: gather on the first
+        const double t1 = __shfl(wy, (lane & 32) + 8, 64), t2 = __shfl(wy, (lane & 32) + 16, 64), t3 = __shfl(wy, (lane & 32) + 24, 64);
+        if (l < nL && (lane & 31) == 0) {
+          const double* C = lch + l * 10;
+          double t4[4] = {wy, t1, t2, t3};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t4[k] = gscale[LL + 4 * l + k] * (B.gl[li * 4 + k] - t4[k]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            double s2 = t4[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j < k) s2 -= C[tri(k, j)] * t4[j];
+            t4[k] = s2 / C[tri(k, k)];
+          }
+#pragma unroll
+          for (int k = 3; k >= 0; --k) {
+            double s2 = t4[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j > k) s2 -= C[tri(j, k)] * t4[j];
+            t4[k] = s2 / C[tri(k, k)];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const double gnv = -gdiag[LL + 4 * l + k] * t4[k];
+            ggn[LL + 4 * l + k] = gnv;
+            a2 += gnv * gnv;
+            a3 += ggrad[LL + 4 * l + k] * gnv;
+          }
+        }
       }
     }
     a2 = block_sum(a2, red);
@@ -386,6 +550,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
     __syncthreads();
   }
 
+  VPL_STAMP(B, w, 6);
   // ---- DoglegStrategy::ComputeTraditionalDoglegStep ---------------------------------------------
   const double radius = tr->radius, alpha = tr->alpha, a1 = tr->a1, a2 = tr->a2, a3 = tr->a3, mu = tr->mu;
   const double gradient_norm = sqrt(a1), gauss_newton_norm = sqrt(a2);
@@ -475,6 +640,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
   }
   sn = block_sum(sn, red);
   xn = block_sum(xn, red);
+  VPL_STAMP(B, w, 7);
   if (tid == 0) {
     tr->dogleg_step_norm = dnorm;
     tr->model_cost_change = model_cost_change;
@@ -485,7 +651,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
   }
 }
 
-constexpr size_t SOLVE_SMEM = (size_t)(NAP + 4 * NC + TK * (TW + 2) + (TK / 4) * 10 + 20) * sizeof(double) + 4 * sizeof(int);
+constexpr size_t SOLVE_SMEM = (size_t)(NAP + 5 * 176 + 24) * sizeof(double) + 4 * sizeof(int);
+static_assert(2 * CROWS * CW <= NAP, "the two staging buffers alias the reduced-system storage");
 
 // ---------------------------------------------------------------------------------------------------
 constexpr int COST_THREADS = 512;

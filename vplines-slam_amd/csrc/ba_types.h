@@ -84,6 +84,7 @@ struct DevBatch {
   double *Hcc, *gc;                              // [W][NCP] [W][NC]
   double *Hpp, *gp, *Wp;                         // [W][maxP] [W][maxP] [W][maxP][NV]
   double *Hll, *gl, *Wl;                         // [W][maxL][16] [W][maxL][4] [W][maxL][4][NV]
+  double *lchol;                                 // [W][maxL][10] Cholesky factors of the regularised line blocks
 
   // ---- trust region vectors over the full index ----
   TrState *tr;                                   // [W]
@@ -96,6 +97,7 @@ struct DevBatch {
   double *mg_J0, *mg_r0;                         // [W][MAXKEEP*MAXKEEP] [W][MAXKEEP]
   double *mg_A, *mg_b;                           // [W][MAXKEEP*MAXKEEP] [W][MAXKEEP]  (invariant check: A, b before the eig)
   int *mg_m;                                     // [W] MarginalizationInfo::m
+  long long *dbg;                                // [W][64] phase stamps (diagnostic builds: -DVPL_STAMPS)
 };
 
 }  // namespace vpl

@@ -177,12 +177,12 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(pr_x0, W * MAXPB * 9); AL(pr_J0, W * MAXPN * MAXPN); AL(pr_r0, W * MAXPN); AL(pr_H, W * MAXPN * MAXPN);
   AL(pr_map, W * MAXPN);
   AL(Hcc, W * NCP); AL(gc, W * NC); AL(Hpp, W * B.maxP); AL(gp, W * B.maxP); AL(Wp, W * B.maxP * NV);
-  AL(Hll, W * B.maxL * 16); AL(gl, W * B.maxL * 4); AL(Wl, W * B.maxL * 4 * NV);
+  AL(Hll, W * B.maxL * 16); AL(gl, W * B.maxL * 4); AL(Wl, W * B.maxL * 4 * NV); AL(lchol, W * B.maxL * 10);
   AL(tr, W);
   AL(scale, W * B.nfull); AL(diag, W * B.nfull); AL(grad, W * B.nfull); AL(gn, W * B.nfull); AL(delta, W * B.nfull);
   AL(mg_n, W); AL(mg_nb, W); AL(mg_kind, W * MAXPB); AL(mg_frame, W * MAXPB); AL(mg_idx, W * MAXPB);
   AL(mg_cam, W * MAXPB); AL(mg_x0, W * MAXPB * 9); AL(mg_J0, W * MAXKEEP * MAXKEEP); AL(mg_r0, W * MAXKEEP);
-  AL(mg_A, W * MAXKEEP * MAXKEEP); AL(mg_b, W * MAXKEEP); AL(mg_m, W);
+  AL(mg_A, W * MAXKEEP * MAXKEEP); AL(mg_b, W * MAXKEEP); AL(mg_m, W); AL(dbg, W * 64);
 #undef AL
   if (e != hipSuccess) {
     for (void* p : c->allocs) hipFree(p);
@@ -604,6 +604,10 @@ int vpl_ba_debug_marg_Ab(vpl_ctx* c, int w, double* A, double* b) {
   return n;
 }
 
+int vpl_ba_debug_stamps(vpl_ctx* c, int w, long long* out) {
+  HIPCHK(c, hipMemcpy(out, c->B.dbg + (size_t)w * 64, 64 * 8, hipMemcpyDeviceToHost));
+  return VPL_OK;
+}
 int vpl_ba_debug_sweeps(vpl_ctx* c, int* out) {
   HIPCHK(c, hipMemcpy(out, c->B.mg_m, c->nW * 4, hipMemcpyDeviceToHost));
   return VPL_OK;
