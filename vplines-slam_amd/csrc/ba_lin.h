@@ -153,7 +153,8 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   double* prg = prdx + MAXPN;      // MAXPN  J0^T r
   double* red = prg + MAXPN;       // 17
   int* invmap = (int*)(red + 18);  // NC
-  int* imuact = invmap + NC;       // 10
+  int* imuact = invmap + NC;       // 10 (+2 pad)
+  double* lacc = (double*)(imuact + 13);  // maxL * 38 per-line accumulators (NC + 13 ints keeps it 8-byte aligned)
 
   const int nP = B.nP[w], nL = B.nL[w];
   // the marginalisation evaluates every block, constant or not (marginalization_factor.cpp:3-69)
@@ -245,38 +246,49 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
 
   VPL_STAMP(B, w, 18);
   // ---- visual factors ----------------------------------------------------------------------
+  // Wave-uniform rounds: in every round each lane linearises (at most) one factor; the extrinsic
+  // block, which every factor touches, is reduced across the wave with DPP/shuffles and added once
+  // per wave, the pose blocks go to the LDS Hessian with ds_add_f64, landmark-local sums stay in
+  // registers (points: one lane per track) or in LDS accumulators (lines: one lane per observation).
   const double* xe = xp + 77;
-  double Aee[21], ge[6];
-#pragma unroll
-  for (int k = 0; k < 21; ++k) Aee[k] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) ge[k] = 0.0;
   const double hub = B.opt.huber_delta;
+  const int lane = tid & 63;
+  // zero the dense W rows first (frames a track does not observe must read as zero)
+  {
+    double* Wp0 = B.Wp + (size_t)w * B.maxP * NV;
+    for (int i = tid; i < nP * NV; i += T) Wp0[i] = 0.0;
+    double* Wl0 = B.Wl + (size_t)w * B.maxL * 4 * NV;
+    for (int i = tid; i < nL * 4 * NV; i += T) Wl0[i] = 0.0;
+    for (int i = tid; i < nL * 38; i += T) lacc[i] = 0.0;
+  }
+  __syncthreads();
 
-  // points: one lane per track, observations looped (landmark-local sums stay in registers)
-  for (int p = tid; p < nP; p += T) {
-    const size_t pi = (size_t)w * B.maxP + p;
-    const int s = B.pt_start[pi], no = B.pt_nobs[pi], off = B.pt_off[pi];
+  // points: one lane per track; rounds over the observation index k (wave-uniform trip count)
+  for (int p0 = 0; p0 < nP; p0 += T) {
+    const int p = p0 + tid;
+    const bool live = p < nP;
+    const size_t pi = (size_t)w * B.maxP + (live ? p : 0);
+    const int s = live ? B.pt_start[pi] : 0, no = live ? B.pt_nobs[pi] : 0, off = live ? B.pt_off[pi] : 0;
+    const bool use = live && (!MARG || s == 0);
+    int nomax = use ? no : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nomax = max(nomax, __shfl_xor(nomax, o, 64));
     double* Wrow = B.Wp + pi * NV;
-    for (int k = 0; k < NV; ++k) Wrow[k] = 0.0;
-    double hll = 0, gll = 0;
-    if (!MARG || s == 0) {
-      const double lam = B.invd[pi];
-      const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + off) * 3;
-      V3 pts_i{o0[0], o0[1], o0[2]};
-      double Aii[21], Aei[36], Wi[6], We[6], gi[6];
+    const double lam = live ? B.invd[pi] : 1.0;
+    const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + off) * 3;
+    double hll = 0, gll = 0, Wi[6], We[6];
 #pragma unroll
-      for (int k = 0; k < 21; ++k) Aii[k] = 0.0;
+    for (int k = 0; k < 6; ++k) { Wi[k] = 0.0; We[k] = 0.0; }
+    for (int k = 1; k < nomax; ++k) {
+      const bool act = use && k < no;
+      double r[2] = {0, 0}, Ji[12], Jj[12], Je[12], Jl[2] = {0, 0};
 #pragma unroll
-      for (int k = 0; k < 36; ++k) Aei[k] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) { Wi[k] = 0.0; We[k] = 0.0; gi[k] = 0.0; }
-      for (int k = 1; k < no; ++k) {
-        const int j = s + k;
+      for (int q = 0; q < 12; ++q) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
+      const int j = s + k;
+      if (act) {
         const double* oj = o0 + 3 * k;
-        double r[2], Ji[12], Jj[12], Je[12], Jl[2];
-        projection_factor(xp + 7 * s, xp + 7 * j, xe, lam, pts_i, V3{oj[0], oj[1], oj[2]}, B.opt.sqrt_info_point, r,
-                          true, Ji, Jj, Je, Jl);
+        projection_factor(xp + 7 * s, xp + 7 * j, xe, lam, V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]},
+                          B.opt.sqrt_info_point, r, true, Ji, Jj, Je, Jl);
         double sc;
         cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
         r[0] *= sc; r[1] *= sc; Jl[0] *= sc; Jl[1] *= sc;
@@ -288,68 +300,72 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
         }
         hll += Jl[0] * Jl[0] + Jl[1] * Jl[1];
         gll += Jl[0] * r[0] + Jl[1] * r[1];
-        int t = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
           Wi[a] += Jl[0] * Ji[a] + Jl[1] * Ji[6 + a];
           We[a] += Jl[0] * Je[a] + Jl[1] * Je[6 + a];
           Wrow[6 * j + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];
-          gi[a] += Ji[a] * r[0] + Ji[6 + a] * r[1];
-          ge[a] += Je[a] * r[0] + Je[6 + a] * r[1];
-#pragma unroll
-          for (int c = 0; c <= a; ++c, ++t) {
-            Aii[t] += Ji[a] * Ji[c] + Ji[6 + a] * Ji[6 + c];
-            Aee[t] += Je[a] * Je[c] + Je[6 + a] * Je[6 + c];
-          }
-#pragma unroll
-          for (int c = 0; c < 6; ++c) Aei[6 * a + c] += Je[a] * Ji[c] + Je[6 + a] * Ji[6 + c];
         }
         acc_diag(Hv, j, Jj);
         acc_off(Hv, j, s, Jj, Ji);
         acc_off(Hv, 11, j, Je, Jj);
         acc_g(gv, j, Jj, r);
+        acc_diag(Hv, s, Ji);
+        acc_off(Hv, 11, s, Je, Ji);
+        acc_g(gv, s, Ji, r);
       }
+      // extrinsic block: reduce over the wave, one LDS add per wave
       int t = 0;
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
-        Wrow[6 * s + a] = Wi[a];
-        Wrow[66 + a] = We[a];
-        lds_add(&gv[6 * s + a], gi[a]);
+        const double gev = wave_sum(Je[a] * r[0] + Je[6 + a] * r[1]);
+        if (lane == 0) lds_add(&gv[66 + a], gev);
 #pragma unroll
-        for (int c = 0; c <= a; ++c, ++t) lds_add(&Hv[(6 * s + a) * NV + 6 * s + c], Aii[t]);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) lds_add(&Hv[(66 + a) * NV + 6 * s + c], Aei[6 * a + c]);
+        for (int c = 0; c <= a; ++c, ++t) {
+          const double v = wave_sum(Je[a] * Je[c] + Je[6 + a] * Je[6 + c]);
+          if (lane == 0) lds_add(&Hv[(66 + a) * NV + 66 + c], v);
+        }
       }
     }
-    B.Hpp[pi] = hll;
-    B.gp[pi] = gll;
+    if (live) {
+      if (use) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { Wrow[6 * s + a] = Wi[a]; Wrow[66 + a] = We[a]; }
+      }
+      B.Hpp[pi] = hll;
+      B.gp[pi] = gll;
+    }
   }
 
-  // lines: one lane per track (top lanes of the workgroup, so line waves and point waves are distinct)
-  for (int l = T - 1 - tid; l < nL; l += T) {
-    const size_t li = (size_t)w * B.maxL + l;
-    const int s = B.ln_start[li], no = B.ln_nobs[li], off = B.ln_off[li];
-    double* Wl = B.Wl + li * 4 * NV;
-    for (int k = 0; k < 4 * NV; ++k) Wl[k] = 0.0;
-    double H4[10], g4[4], We[24];
+  // lines: one lane per (track, observation); per-track sums in the LDS accumulators lacc[l][38]
+  //        = H4 (10, packed lower) | g4 (4) | W_ext (4 x 6)
+  {
+    const int nLO = B.nLO[w];
+    const int* lo_ln = B.lo_ln + (size_t)w * B.maxLO;
+    for (int o0 = 0; o0 < nLO; o0 += T) {
+      const int o = o0 + tid;
+      const bool inb = o < nLO;
+      const int l = inb ? lo_ln[o] : 0;
+      const size_t li = (size_t)w * B.maxL + l;
+      const int s = B.ln_start[li], off = B.ln_off[li];
+      const int k = o - off, j = s + k;
+      const bool act = inb && (!MARG || (s == 0 && k >= 1));   // MARG: start-frame obs skipped (estimator.cpp:1322-1326)
+      const double* ob = B.ln_obs + ((size_t)w * B.maxLO + (inb ? o : 0)) * 8;
+      LineCtx c;
+      if (act) c = line_ctx(xp + 7 * j, xe, B.orth + li * 4);
+      double Wj[24];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) H4[k] = 0.0;
+      for (int q = 0; q < 24; ++q) Wj[q] = 0.0;
+      double* la = lacc + l * 38;
+#pragma unroll 1
+      for (int fct = 0; fct < 2; ++fct) {
+        // VP factor only in the solve and only when flagged (estimator.cpp:1153, :1341-1351)
+        const bool fa = act && (fct == 0 || (!MARG && ob[7] == 1.0));
+        double r[2] = {0, 0}, Je[12];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) g4[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 24; ++k) We[k] = 0.0;
-    if (!MARG || s == 0) {
-      const double* orth = B.orth + li * 4;
-      for (int k = (MARG ? 1 : 0); k < no; ++k) {   // MARG: the start-frame observation is skipped (estimator.cpp:1322-1326)
-        const int j = s + k;
-        const double* ob = B.ln_obs + ((size_t)w * B.maxLO + off + k) * 8;
-        LineCtx c = line_ctx(xp + 7 * j, xe, orth);
-        double Wj[24];
-#pragma unroll
-        for (int q = 0; q < 24; ++q) Wj[q] = 0.0;
-        const int nfac = (!MARG && ob[7] == 1.0) ? 2 : 1;   // VP factor only in the solve (estimator.cpp:1153, :1341-1351)
-        for (int fct = 0; fct < nfac; ++fct) {
-          double r[2], jel[6], Jp[12], Je[12], Jo[8];
+        for (int q = 0; q < 12; ++q) Je[q] = 0.0;
+        if (fa) {
+          double jel[6], Jp[12], Jo[8];
           if (fct == 0) line_factor_res(c, ob, B.opt.sqrt_info_line, r, jel);
           else vp_factor_res(c, ob + 4, B.opt.sqrt_info_vp, r, jel);
           line_chain_jac(c, jel, fct, Jp, Je, Jo);
@@ -367,62 +383,54 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
           int t = 0;
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
-            g4[a] += Jo[a] * r[0] + Jo[4 + a] * r[1];
+            lds_add(&la[10 + a], Jo[a] * r[0] + Jo[4 + a] * r[1]);
 #pragma unroll
-            for (int c2 = 0; c2 <= a; ++c2, ++t) H4[t] += Jo[a] * Jo[c2] + Jo[4 + a] * Jo[4 + c2];
+            for (int c2 = 0; c2 <= a; ++c2, ++t) lds_add(&la[t], Jo[a] * Jo[c2] + Jo[4 + a] * Jo[4 + c2]);
 #pragma unroll
             for (int c2 = 0; c2 < 6; ++c2) {
               Wj[6 * a + c2] += Jo[a] * Jp[c2] + Jo[4 + a] * Jp[6 + c2];
-              We[6 * a + c2] += Jo[a] * Je[c2] + Jo[4 + a] * Je[6 + c2];
+              lds_add(&la[14 + 6 * a + c2], Jo[a] * Je[c2] + Jo[4 + a] * Je[6 + c2]);
             }
-          }
-          t = 0;
-#pragma unroll
-          for (int a = 0; a < 6; ++a) {
-            ge[a] += Je[a] * r[0] + Je[6 + a] * r[1];
-#pragma unroll
-            for (int c2 = 0; c2 <= a; ++c2, ++t) Aee[t] += Je[a] * Je[c2] + Je[6 + a] * Je[6 + c2];
           }
           acc_diag(Hv, j, Jp);
           acc_off(Hv, 11, j, Je, Jp);
           acc_g(gv, j, Jp, r);
         }
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double gev = wave_sum(Je[a] * r[0] + Je[6 + a] * r[1]);
+          if (lane == 0) lds_add(&gv[66 + a], gev);
+#pragma unroll
+          for (int c2 = 0; c2 <= a; ++c2, ++t) {
+            const double v = wave_sum(Je[a] * Je[c2] + Je[6 + a] * Je[6 + c2]);
+            if (lane == 0) lds_add(&Hv[(66 + a) * NV + 66 + c2], v);
+          }
+        }
+      }
+      if (act) {
+        double* Wl = B.Wl + li * 4 * NV;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int c2 = 0; c2 < 6; ++c2) Wl[a * NV + 6 * j + c2] = Wj[6 * a + c2];
       }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c2 = 0; c2 < 6; ++c2) Wl[a * NV + 66 + c2] = We[6 * a + c2];
     }
+  }
+  __syncthreads();
+  // per-line results out of the LDS accumulators
+  for (int l = tid; l < nL; l += T) {
+    const size_t li = (size_t)w * B.maxL + l;
+    const double* la = lacc + l * 38;
     double* Hl = B.Hll + li * 16;
     int t = 0;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      B.gl[li * 4 + a] = g4[a];
+      B.gl[li * 4 + a] = la[10 + a];
 #pragma unroll
-      for (int c2 = 0; c2 <= a; ++c2, ++t) { Hl[4 * a + c2] = H4[t]; Hl[4 * c2 + a] = H4[t]; }
-    }
-  }
-
-  VPL_STAMP(B, w, 19 + (threadIdx.x >= 448 ? 0 : 0));
-  // extrinsic-extrinsic block and gradient: wave reduction, then one LDS add per wave
-  {
-    const int lane = tid & 63;
+      for (int c2 = 0; c2 <= a; ++c2, ++t) { Hl[4 * a + c2] = la[t]; Hl[4 * c2 + a] = la[t]; }
 #pragma unroll
-    for (int k = 0; k < 21; ++k) Aee[k] = wave_sum(Aee[k]);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) ge[k] = wave_sum(ge[k]);
-    if (lane == 0) {
-      int t = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        lds_add(&gv[66 + a], ge[a]);
-#pragma unroll
-        for (int c = 0; c <= a; ++c, ++t) lds_add(&Hv[(66 + a) * NV + 66 + c], Aee[t]);
-      }
+      for (int c2 = 0; c2 < 6; ++c2) B.Wl[(li * 4 + a) * NV + 66 + c2] = la[14 + 6 * a + c2];
     }
   }
   __syncthreads();
@@ -504,7 +512,8 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   }
 }
 
-constexpr size_t LIN_SMEM = (size_t)(NV * NV + NV + 84 + 99 + 4500 + 150 + 3 * MAXPN + 18) * sizeof(double) +
-                            (size_t)(NC + 10) * sizeof(int);
+constexpr size_t LIN_SMEM_BASE = (size_t)(NV * NV + NV + 84 + 99 + 4500 + 150 + 3 * MAXPN + 18) * sizeof(double) +
+                                 (size_t)(NC + 12 + 1) * sizeof(int);
+inline size_t lin_smem(int maxL) { return LIN_SMEM_BASE + (size_t)maxL * 38 * sizeof(double); }
 
 }  // namespace vpl

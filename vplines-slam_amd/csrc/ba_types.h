@@ -69,6 +69,7 @@ struct DevBatch {
   double *pt_obs;                                // [W][maxPO][3]
   int *ln_start, *ln_nobs, *ln_off;              // [W][maxL]
   double *ln_obs;                                // [W][maxLO][8]
+  int *nLO, *lo_ln;                              // [W] line observation count ; [W][maxLO] observation -> line
 
   DevPreint *pre;                                // [W][11]
 

@@ -172,6 +172,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(nP, W); AL(nL, W);
   AL(pt_start, W * B.maxP); AL(pt_nobs, W * B.maxP); AL(pt_off, W * B.maxP); AL(pt_obs, W * B.maxPO * 3);
   AL(ln_start, W * B.maxL); AL(ln_nobs, W * B.maxL); AL(ln_off, W * B.maxL); AL(ln_obs, W * B.maxLO * 8);
+  AL(nLO, W); AL(lo_ln, W * B.maxLO);
   AL(pre, W * NF);
   AL(pr_n, W); AL(pr_nb, W); AL(pr_kind, W * MAXPB); AL(pr_frame, W * MAXPB); AL(pr_idx, W * MAXPB);
   AL(pr_x0, W * MAXPB * 9); AL(pr_J0, W * MAXPN * MAXPN); AL(pr_r0, W * MAXPN); AL(pr_H, W * MAXPN * MAXPN);
@@ -189,8 +190,9 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
     delete c;
     return VPL_E_HIP;
   }
-  hipFuncSetAttribute((const void*)k_lin<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_SMEM);
-  hipFuncSetAttribute((const void*)k_lin<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LIN_SMEM);
+  if (lin_smem(c->maxL) > 158 * 1024) { for (void* p : c->allocs) hipFree(p); delete c; return VPL_E_CAPACITY; }
+  hipFuncSetAttribute((const void*)k_lin<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxL));
+  hipFuncSetAttribute((const void*)k_lin<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxL));
   hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
   hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
   (void)hipGetLastError();
@@ -372,6 +374,7 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
   std::vector<double> pose(W * 77), sb(W * 99), ex(W * 7), invd(W * B.maxP, 1.0), plk(W * B.maxL * 6, 0.0);
   std::vector<int> nP(W), nL(W), pt_start(W * B.maxP, 0), pt_nobs(W * B.maxP, 0), pt_off(W * B.maxP, 0);
   std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0);
+  std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
   std::vector<DevPreint> pre(W * NF);
   std::vector<int> pr_n(W, 0), pr_nb(W, 0), pr_kind(W * MAXPB, 0), pr_frame(W * MAXPB, 0), pr_idx(W * MAXPB, 0);
@@ -413,8 +416,10 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
       std::memcpy(&ln_obs[(w * B.maxLO + off) * 8], v.line_obs + (size_t)off * 8, (size_t)no * 8 * 8);
       std::memcpy(&plk[(w * B.maxL + l) * 6], v.line_plk + (size_t)l * 6, 6 * 8);
       if (s == 0 && no >= 2) { for (int k = 1; k < no; ++k) pose_touched[k] = true; any_landmark0 = true; m += 4; }
+      for (int k = 0; k < no; ++k) lo_ln[w * B.maxLO + off + k] = l;
       off += no;
     }
+    nLO[w] = off;
     for (int j = 0; j < NF; ++j) to_dev_preint(v.preint[j], pre[w * NF + j]);
     bool sb_touched[NF] = {false};
     bool ex_touched = any_landmark0;
@@ -468,6 +473,7 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
   HIPCHK(c, up(c, B.pt_obs, pt_obs));
   HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
   HIPCHK(c, up(c, B.ln_obs, ln_obs));
+  HIPCHK(c, up(c, B.nLO, nLO)); HIPCHK(c, up(c, B.lo_ln, lo_ln));
   HIPCHK(c, up(c, B.pre, pre));
   HIPCHK(c, up(c, B.pr_n, pr_n)); HIPCHK(c, up(c, B.pr_nb, pr_nb)); HIPCHK(c, up(c, B.pr_kind, pr_kind));
   HIPCHK(c, up(c, B.pr_frame, pr_frame)); HIPCHK(c, up(c, B.pr_idx, pr_idx)); HIPCHK(c, up(c, B.pr_x0, pr_x0));
@@ -497,18 +503,18 @@ int vpl_ba_solve(vpl_ctx* c) {
   const dim3 grid(c->nW);
   hipStream_t s = c->stream;
   { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, B); }
-  { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<false>, grid, dim3(LIN_THREADS), LIN_SMEM, s, B); }
+  { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<false>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
   for (int it = 0; it < c->opt.num_iterations; ++it) {
     { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), SOLVE_SMEM, s, B); }
     { KTimer t(c, "k_cost"); hipLaunchKernelGGL(k_cost, grid, dim3(COST_THREADS), 0, s, B); }
     if (it + 1 < c->opt.num_iterations) {
       KTimer t(c, "k_lin");
-      hipLaunchKernelGGL(k_lin<false>, grid, dim3(LIN_THREADS), LIN_SMEM, s, B);
+      hipLaunchKernelGGL(k_lin<false>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B);
     }
   }
   { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
   if (c->opt.marginalization_flag == VPL_MARGIN_OLD) {
-    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<true>, grid, dim3(LIN_THREADS), LIN_SMEM, s, B); }
+    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<true>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
     { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   }
   HIPCHK(c, hipGetLastError());
