@@ -15,4 +15,4 @@ for w in (0, 1, 300):
     ctx.lib.vpl_ba_debug_stamps(ctx.h, w, out)
     s = list(out)
     print("window", w, "k_solve phases (cycles):", [s[i + 1] - s[i] for i in range(0, 7)])
-    print("   k_lin phases:", [s[i + 1] - s[i] for i in range(16, 21)])
+    print("   k_lin: prior %d imu %d zero %d points %d lines+out %d assemble %d" % (s[18]-s[16], s[22]-s[24], s[23]-s[18], s[24]-s[23], s[20]-s[22], s[21]-s[20]))

@@ -10,51 +10,67 @@
 
 namespace vpl {
 
+typedef double v4d_lin __attribute__((ext_vector_type(4)));
 constexpr int LIN_THREADS = 512;
+constexpr int LIN_STAGE = 8 * 32 * 20;   // MFMA staging of the point phase (doubles)
+constexpr int PREP_NMAX = 120;            // prior dims staged in LDS by k_prep (larger priors read HBM/L2)
+constexpr size_t PREP_SMEM = (size_t)(4 * 675 + PREP_NMAX * PREP_NMAX) * sizeof(double);
 
 // ---------------------------------------------------------------------------------------
+// wave-cooperative 15x15 helpers on LDS matrices (row-major, ld 15); one wave, no block barriers
+__device__ __forceinline__ void wave_chol15(double* A, int lane) {   // lower Cholesky in place
+  for (int j = 0; j < 15; ++j) {
+    double d = A[j * 15 + j];
+    for (int k = 0; k < j; ++k) d -= A[j * 15 + k] * A[j * 15 + k];
+    d = sqrt(d);
+    if (lane > j && lane < 15) {
+      double s2 = A[lane * 15 + j];
+      for (int k = 0; k < j; ++k) s2 -= A[lane * 15 + k] * A[j * 15 + k];
+      A[lane * 15 + j] = s2 / d;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) A[j * 15 + j] = d;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_prep(DevBatch B) {
   const int w = blockIdx.x, tid = threadIdx.x;
-  __shared__ double red[17];
-  // (a) IMU: sqrt_info = LLT(cov^-1).matrixL().transpose()  (imu_factor.h:68)
-  if (tid >= 1 && tid < NF) {
-    DevPreint& P = B.pre[(size_t)w * NF + tid];
-    double a[225], inv[225];
-    for (int k = 0; k < 225; ++k) { a[k] = P.cov[k]; inv[k] = (k / 15 == k % 15) ? 1.0 : 0.0; }
-    // Gauss-Jordan with partial pivoting
-    for (int c = 0; c < 15; ++c) {
-      int piv = c;
-      double best = fabs(a[c * 15 + c]);
-      for (int r = c + 1; r < 15; ++r)
-        if (fabs(a[r * 15 + c]) > best) { best = fabs(a[r * 15 + c]); piv = r; }
-      if (piv != c)
-        for (int k = 0; k < 15; ++k) {
-          double t = a[c * 15 + k]; a[c * 15 + k] = a[piv * 15 + k]; a[piv * 15 + k] = t;
-          t = inv[c * 15 + k]; inv[c * 15 + k] = inv[piv * 15 + k]; inv[piv * 15 + k] = t;
-        }
-      double d = 1.0 / a[c * 15 + c];
-      for (int k = 0; k < 15; ++k) { a[c * 15 + k] *= d; inv[c * 15 + k] *= d; }
-      for (int r = 0; r < 15; ++r) {
-        if (r == c) continue;
-        double f = a[r * 15 + c];
-        if (f == 0.0) continue;
-        for (int k = 0; k < 15; ++k) { a[r * 15 + k] -= f * a[c * 15 + k]; inv[r * 15 + k] -= f * inv[c * 15 + k]; }
+  const int lane = tid & 63, wv = tid >> 6;
+  extern __shared__ double psm[];
+  double* wsc = psm + wv * 675;          // per-wave scratch: G (225) | X = G^-1 (225) | P = cov^-1 (225)
+  double* Jl = psm + 4 * 675;            // prior J0 staged (n * n)
+  // (a) IMU: sqrt_info = LLT(cov^-1).matrixL().transpose()  (imu_factor.h:68).  cov is SPD: its inverse
+  //     is formed from its Cholesky factor (cov = G G^T, cov^-1 = G^-T G^-1), then factored again.
+  for (int j = 1 + wv; j < NF; j += 4) {
+    DevPreint& P = B.pre[(size_t)w * NF + j];
+    double* G = wsc;
+    double* X = wsc + 225;
+    double* Pm = wsc + 450;
+    for (int k = lane; k < 225; k += 64) G[k] = P.cov[k];
+    __builtin_amdgcn_wave_barrier();
+    wave_chol15(G, lane);
+    if (lane < 15) {   // column `lane` of X = G^-1 by forward substitution
+      for (int i = 0; i < 15; ++i) {
+        double s2 = (i == lane) ? 1.0 : 0.0;
+        for (int k = lane; k < i; ++k) s2 -= G[i * 15 + k] * X[k * 15 + lane];
+        X[i * 15 + lane] = i >= lane ? s2 / G[i * 15 + i] : 0.0;
       }
     }
-    // Cholesky (lower) of inv, reading its lower triangle
-    for (int j = 0; j < 15; ++j) {
-      double d = inv[j * 15 + j];
-      for (int k = 0; k < j; ++k) d -= a[j * 15 + k] * a[j * 15 + k];
-      d = sqrt(d);
-      a[j * 15 + j] = d;
-      for (int i = j + 1; i < 15; ++i) {
-        double s = inv[i * 15 + j];
-        for (int k = 0; k < j; ++k) s -= a[i * 15 + k] * a[j * 15 + k];
-        a[i * 15 + j] = s / d;
-      }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < 225; e += 64) {   // P = X^T X
+      const int a = e / 15, b2 = e % 15;
+      double s2 = 0;
+      for (int k = (a > b2 ? a : b2); k < 15; ++k) s2 += X[k * 15 + a] * X[k * 15 + b2];
+      Pm[e] = s2;
     }
-    for (int i = 0; i < 15; ++i)
-      for (int j = 0; j < 15; ++j) P.sqrt_info[i * 15 + j] = (j >= i) ? a[j * 15 + i] : 0.0;  // L^T
+    __builtin_amdgcn_wave_barrier();
+    wave_chol15(Pm, lane);
+    for (int e = lane; e < 225; e += 64) {
+      const int i = e / 15, jj = e % 15;
+      P.sqrt_info[e] = (jj >= i) ? Pm[jj * 15 + i] : 0.0;   // L^T
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   // (b) states: Rs = normalized(q).toRotationMatrix(); para = Quaterniond(Rs)   (vector2double, estimator.cpp:650-705)
   if (tid < NF + 1) {
@@ -84,15 +100,21 @@ __global__ __launch_bounds__(256) void k_prep(DevBatch B) {
     Plk Lw = plk_to_pose(Lc, Rwc, twc);
     plk_to_orth(Lw, B.orth + ((size_t)w * B.maxL + l) * 4);
   }
-  // (d) prior: H = J0^T J0 and the column map
+  // (d) prior: H = J0^T J0 (J0 staged in LDS) and the column map
   const int n = B.pr_n[w];
   if (n > 0) {
     const double* J0 = B.pr_J0 + (size_t)w * MAXPN * MAXPN;
     double* H = B.pr_H + (size_t)w * MAXPN * MAXPN;
+    const bool fits = n <= PREP_NMAX;
+    if (fits) {
+      for (int idx = tid; idx < n * n; idx += blockDim.x) Jl[idx] = J0[idx];
+      __syncthreads();
+    }
+    const double* Js = fits ? Jl : J0;
     for (int idx = tid; idx < n * n; idx += blockDim.x) {
       int a = idx / n, b = idx % n;
       double s = 0;
-      for (int k = 0; k < n; ++k) s += J0[(size_t)k * n + a] * J0[(size_t)k * n + b];
+      for (int k = 0; k < n; ++k) s += Js[(size_t)k * n + a] * Js[(size_t)k * n + b];
       H[idx] = s;
     }
     if (tid < B.pr_nb[w]) {
@@ -146,15 +168,18 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   double* gv = Hv + NV * NV;       // NV
   double* xp = gv + NV;            // 12*7 poses + ex
   double* xs = xp + 84;            // 11*9
+  // [imuJ | imur | lacc] is one region: the point phase (which runs before the IMU and line phases)
+  // uses it as MFMA staging space (8 waves x 32 rows x 20 doubles)
   double* imuJ = xs + 99;          // 10*450 whitened Jacobians
   double* imur = imuJ + 4500;      // 10*15 whitened residuals
-  double* prr = imur + 150;        // MAXPN prior residual
+  double* lacc = imur + 150;       // maxL * 38 per-line accumulators
+  const int stg_doubles = max(LIN_STAGE, 4650 + 38 * B.maxL);
+  double* prr = imuJ + stg_doubles;  // MAXPN prior residual
   double* prdx = prr + MAXPN;      // MAXPN
   double* prg = prdx + MAXPN;      // MAXPN  J0^T r
-  double* red = prg + MAXPN;       // 17
+  double* red = prg + MAXPN;       // 18
   int* invmap = (int*)(red + 18);  // NC
-  int* imuact = invmap + NC;       // 10 (+2 pad)
-  double* lacc = (double*)(imuact + 13);  // maxL * 38 per-line accumulators (NC + 13 ints keeps it 8-byte aligned)
+  int* imuact = invmap + NC;       // 10
 
   const int nP = B.nP[w], nL = B.nL[w];
   // the marginalisation evaluates every block, constant or not (marginalization_factor.cpp:3-69)
@@ -197,7 +222,150 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     }
   }
 
-  VPL_STAMP(B, w, 17);
+  VPL_STAMP(B, w, 18);
+  // ---- visual factors ----------------------------------------------------------------------
+  // Wave-uniform rounds: in every round each lane linearises (at most) one factor; the extrinsic
+  // block, which every factor touches, is reduced across the wave with DPP/shuffles and added once
+  // per wave, the pose blocks go to the LDS Hessian with ds_add_f64, landmark-local sums stay in
+  // registers (points: one lane per track) or in LDS accumulators (lines: one lane per observation).
+  const double* xe = xp + 77;
+  const double hub = B.opt.huber_delta;
+  const int lane = tid & 63;
+  // zero the dense W rows first (frames a track does not observe must read as zero)
+  {
+    double* Wp0 = B.Wp + (size_t)w * B.maxP * NV;
+    for (int i = tid; i < nP * NV; i += T) Wp0[i] = 0.0;
+    double* Wl0 = B.Wl + (size_t)w * B.maxL * 4 * NV;
+    for (int i = tid; i < nL * 4 * NV; i += T) Wl0[i] = 0.0;
+  }
+  __syncthreads();
+
+  VPL_STAMP(B, w, 23);
+  // points: wave `wvi` owns the tracks that START in frame wvi (+8 for longer windows), so in a round
+  // (observation index k) every lane of the wave works on the same pair of frames (s, j = s + k) and all
+  // six 6x6 blocks a point factor touches are wave-uniform.  The sum over the wave of J^T [J | r]
+  // (19 x 19, J = [J_s J_j J_e]) is a rank-2*lanes update: lanes stage their two Jacobian rows in LDS
+  // (16 lanes = 32 rows per pass) and the FP64 matrix cores reduce them (3 tiles of 16x16, K = 4 per
+  // instruction); each lane then adds its accumulator entries to the LDS Hessian once per round.
+  {
+    const int wvi = tid >> 6, nwv = T >> 6;
+    const int* plist = B.ps_list + (size_t)w * B.maxP;     // track ids sorted by start frame
+    const int* pcnt = B.ps_cnt + (size_t)w * (NF + 1);     // prefix offsets per start frame
+    double* stg = imuJ + wvi * (32 * 20);                  // this wave's staging tile: 32 rows x 20
+    const int m16 = lane & 15, kk = lane >> 4;
+    for (int s = wvi; s < NF; s += nwv) {
+      const int b0 = pcnt[s], b1 = pcnt[s + 1];
+      if (MARG && s != 0) continue;
+      for (int q0 = b0; q0 < b1; q0 += 64) {
+        const int qi = q0 + lane;
+        const bool live = qi < b1;
+        const int p = live ? plist[qi] : 0;
+        const size_t pi = (size_t)w * B.maxP + p;
+        const int no = live ? B.pt_nobs[pi] : 0, off = live ? B.pt_off[pi] : 0;
+        int nomax = no;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nomax = max(nomax, __shfl_xor(nomax, o, 64));
+        const int nlive = min(64, b1 - q0);
+        double* Wrow = B.Wp + pi * NV;
+        const double lam = live ? B.invd[pi] : 1.0;
+        const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + off) * 3;
+        double hll = 0, gll = 0, Wi[6], We[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { Wi[k] = 0.0; We[k] = 0.0; }
+        for (int k = 1; k < nomax; ++k) {
+          const bool act = live && k < no;
+          double r[2] = {0, 0}, Ji[12], Jj[12], Je[12], Jl[2] = {0, 0};
+#pragma unroll
+          for (int q = 0; q < 12; ++q) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
+          const int j = s + k;
+          if (act) {
+            const double* oj = o0 + 3 * k;
+            projection_factor(xp + 7 * s, xp + 7 * j, xe, lam, V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]},
+                              B.opt.sqrt_info_point, r, true, Ji, Jj, Je, Jl);
+            double sc;
+            cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
+            r[0] *= sc; r[1] *= sc; Jl[0] *= sc; Jl[1] *= sc;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) { Ji[q] *= sc; Jj[q] *= sc; Je[q] *= sc; }
+            if (!ex_free) {
+#pragma unroll
+              for (int q = 0; q < 12; ++q) Je[q] = 0.0;
+            }
+            hll += Jl[0] * Jl[0] + Jl[1] * Jl[1];
+            gll += Jl[0] * r[0] + Jl[1] * r[1];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+              Wi[a] += Jl[0] * Ji[a] + Jl[1] * Ji[6 + a];
+              We[a] += Jl[0] * Je[a] + Jl[1] * Je[6 + a];
+              Wrow[6 * j + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];
+            }
+          }
+          // ---- wave reduction of [Js Jj Je r]^T [Js Jj Je r] on the matrix cores ----
+          v4d_lin c00 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+          for (int l0 = 0; l0 < nlive; l0 += 16) {
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= l0 && lane < l0 + 16) {
+              double* d0 = stg + (2 * (lane - l0)) * 20;
+#pragma unroll
+              for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                  d0[rr * 20 + a] = Ji[6 * rr + a];
+                  d0[rr * 20 + 6 + a] = Jj[6 * rr + a];
+                  d0[rr * 20 + 12 + a] = Je[6 * rr + a];
+                }
+                d0[rr * 20 + 18] = r[rr];
+                d0[rr * 20 + 19] = 0.0;
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+              const double* row = stg + (4 * ks + kk) * 20;
+              const double lo = row[m16];
+              const double hi = m16 < 4 ? row[16 + m16] : 0.0;
+              c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, c00, 0, 0, 0);
+              c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, c10, 0, 0, 0);
+              c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, c11, 0, 0, 0);
+            }
+          }
+          // accumulator entry (row a = kk + 4 v (+16), col b = m16 (+16)) -> LDS Hessian / gradient
+          {
+            const double v00[4] = {c00.x, c00.y, c00.z, c00.w}, v10[4] = {c10.x, c10.y, c10.z, c10.w},
+                         v11[4] = {c11.x, c11.y, c11.z, c11.w};
+            auto visof = [&](int a) { return a < 6 ? 6 * s + a : (a < 12 ? 6 * j + (a - 6) : 66 + (a - 12)); };
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int a0 = kk + 4 * v, bcol = m16;
+              if (a0 >= bcol) lds_add(&Hv[visof(a0) * NV + visof(bcol)], v00[v]);
+              const int a1 = 16 + kk + 4 * v;
+              if (a1 < 18) lds_add(&Hv[visof(a1) * NV + visof(bcol)], v10[v]);
+              else if (a1 == 18) lds_add(&gv[visof(bcol)], v10[v]);
+              const int b1c = 16 + m16;
+              if (b1c < 18) {
+                if (a1 < 18 && a1 >= b1c) lds_add(&Hv[visof(a1) * NV + visof(b1c)], v11[v]);
+                else if (a1 == 18) lds_add(&gv[visof(b1c)], v11[v]);
+              }
+            }
+          }
+        }
+        if (live) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) { Wrow[6 * s + a] = Wi[a]; Wrow[66 + a] = We[a]; }
+          B.Hpp[pi] = hll;
+          B.gp[pi] = gll;
+        }
+      }
+    }
+    if (MARG) {   // tracks that do not start in frame 0 take no part in the marginalisation
+      for (int p = tid; p < nP; p += T) {
+        const size_t pi = (size_t)w * B.maxP + p;
+        if (B.pt_start[pi] != 0) { B.Hpp[pi] = 0.0; B.gp[pi] = 0.0; }
+      }
+    }
+  }
+  __syncthreads();   // staging space is handed over to the IMU / line phases
+  VPL_STAMP(B, w, 24);
   // ---- IMU factors: raw residual / Jacobian per factor, then cooperative whitening ------
   if (tid < 10) {
     const int j = tid + 1;
@@ -244,99 +412,9 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     cost += 0.5 * s;
   }
 
-  VPL_STAMP(B, w, 18);
-  // ---- visual factors ----------------------------------------------------------------------
-  // Wave-uniform rounds: in every round each lane linearises (at most) one factor; the extrinsic
-  // block, which every factor touches, is reduced across the wave with DPP/shuffles and added once
-  // per wave, the pose blocks go to the LDS Hessian with ds_add_f64, landmark-local sums stay in
-  // registers (points: one lane per track) or in LDS accumulators (lines: one lane per observation).
-  const double* xe = xp + 77;
-  const double hub = B.opt.huber_delta;
-  const int lane = tid & 63;
-  // zero the dense W rows first (frames a track does not observe must read as zero)
-  {
-    double* Wp0 = B.Wp + (size_t)w * B.maxP * NV;
-    for (int i = tid; i < nP * NV; i += T) Wp0[i] = 0.0;
-    double* Wl0 = B.Wl + (size_t)w * B.maxL * 4 * NV;
-    for (int i = tid; i < nL * 4 * NV; i += T) Wl0[i] = 0.0;
-    for (int i = tid; i < nL * 38; i += T) lacc[i] = 0.0;
-  }
+  for (int i = tid; i < nL * 38; i += T) lacc[i] = 0.0;
   __syncthreads();
-
-  // points: one lane per track; rounds over the observation index k (wave-uniform trip count)
-  for (int p0 = 0; p0 < nP; p0 += T) {
-    const int p = p0 + tid;
-    const bool live = p < nP;
-    const size_t pi = (size_t)w * B.maxP + (live ? p : 0);
-    const int s = live ? B.pt_start[pi] : 0, no = live ? B.pt_nobs[pi] : 0, off = live ? B.pt_off[pi] : 0;
-    const bool use = live && (!MARG || s == 0);
-    int nomax = use ? no : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nomax = max(nomax, __shfl_xor(nomax, o, 64));
-    double* Wrow = B.Wp + pi * NV;
-    const double lam = live ? B.invd[pi] : 1.0;
-    const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + off) * 3;
-    double hll = 0, gll = 0, Wi[6], We[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { Wi[k] = 0.0; We[k] = 0.0; }
-    for (int k = 1; k < nomax; ++k) {
-      const bool act = use && k < no;
-      double r[2] = {0, 0}, Ji[12], Jj[12], Je[12], Jl[2] = {0, 0};
-#pragma unroll
-      for (int q = 0; q < 12; ++q) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
-      const int j = s + k;
-      if (act) {
-        const double* oj = o0 + 3 * k;
-        projection_factor(xp + 7 * s, xp + 7 * j, xe, lam, V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]},
-                          B.opt.sqrt_info_point, r, true, Ji, Jj, Je, Jl);
-        double sc;
-        cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
-        r[0] *= sc; r[1] *= sc; Jl[0] *= sc; Jl[1] *= sc;
-#pragma unroll
-        for (int q = 0; q < 12; ++q) { Ji[q] *= sc; Jj[q] *= sc; Je[q] *= sc; }
-        if (!ex_free) {
-#pragma unroll
-          for (int q = 0; q < 12; ++q) Je[q] = 0.0;
-        }
-        hll += Jl[0] * Jl[0] + Jl[1] * Jl[1];
-        gll += Jl[0] * r[0] + Jl[1] * r[1];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          Wi[a] += Jl[0] * Ji[a] + Jl[1] * Ji[6 + a];
-          We[a] += Jl[0] * Je[a] + Jl[1] * Je[6 + a];
-          Wrow[6 * j + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];
-        }
-        acc_diag(Hv, j, Jj);
-        acc_off(Hv, j, s, Jj, Ji);
-        acc_off(Hv, 11, j, Je, Jj);
-        acc_g(gv, j, Jj, r);
-        acc_diag(Hv, s, Ji);
-        acc_off(Hv, 11, s, Je, Ji);
-        acc_g(gv, s, Ji, r);
-      }
-      // extrinsic block: reduce over the wave, one LDS add per wave
-      int t = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const double gev = wave_sum(Je[a] * r[0] + Je[6 + a] * r[1]);
-        if (lane == 0) lds_add(&gv[66 + a], gev);
-#pragma unroll
-        for (int c = 0; c <= a; ++c, ++t) {
-          const double v = wave_sum(Je[a] * Je[c] + Je[6 + a] * Je[6 + c]);
-          if (lane == 0) lds_add(&Hv[(66 + a) * NV + 66 + c], v);
-        }
-      }
-    }
-    if (live) {
-      if (use) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) { Wrow[6 * s + a] = Wi[a]; Wrow[66 + a] = We[a]; }
-      }
-      B.Hpp[pi] = hll;
-      B.gp[pi] = gll;
-    }
-  }
-
+  VPL_STAMP(B, w, 22);
   // lines: one lane per (track, observation); per-track sums in the LDS accumulators lacc[l][38]
   //        = H4 (10, packed lower) | g4 (4) | W_ext (4 x 6)
   {
@@ -512,8 +590,9 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   }
 }
 
-constexpr size_t LIN_SMEM_BASE = (size_t)(NV * NV + NV + 84 + 99 + 4500 + 150 + 3 * MAXPN + 18) * sizeof(double) +
-                                 (size_t)(NC + 12 + 1) * sizeof(int);
-inline size_t lin_smem(int maxL) { return LIN_SMEM_BASE + (size_t)maxL * 38 * sizeof(double); }
+inline size_t lin_smem(int maxL) {
+  const int stg = LIN_STAGE > 4650 + 38 * maxL ? LIN_STAGE : 4650 + 38 * maxL;
+  return (size_t)(NV * NV + NV + 84 + 99 + stg + 3 * MAXPN + 18) * sizeof(double) + (size_t)(NC + 12) * sizeof(int);
+}
 
 }  // namespace vpl

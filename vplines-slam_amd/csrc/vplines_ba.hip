@@ -171,6 +171,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(plk, W * B.maxL * 6); AL(gauge, W * 4);
   AL(nP, W); AL(nL, W);
   AL(pt_start, W * B.maxP); AL(pt_nobs, W * B.maxP); AL(pt_off, W * B.maxP); AL(pt_obs, W * B.maxPO * 3);
+  AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1));
   AL(ln_start, W * B.maxL); AL(ln_nobs, W * B.maxL); AL(ln_off, W * B.maxL); AL(ln_obs, W * B.maxLO * 8);
   AL(nLO, W); AL(lo_ln, W * B.maxLO);
   AL(pre, W * NF);
@@ -194,6 +195,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   hipFuncSetAttribute((const void*)k_lin<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxL));
   hipFuncSetAttribute((const void*)k_lin<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxL));
   hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
+  hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SMEM);
   hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
   (void)hipGetLastError();
   vpl_ba_default_options(&c->opt);
@@ -375,6 +377,7 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
   std::vector<int> nP(W), nL(W), pt_start(W * B.maxP, 0), pt_nobs(W * B.maxP, 0), pt_off(W * B.maxP, 0);
   std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0);
   std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0);
+  std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
   std::vector<DevPreint> pre(W * NF);
   std::vector<int> pr_n(W, 0), pr_nb(W, 0), pr_kind(W * MAXPB, 0), pr_frame(W * MAXPB, 0), pr_idx(W * MAXPB, 0);
@@ -406,6 +409,15 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
       invd[w * B.maxP + p] = v.inv_depth[p];
       if (s == 0) { for (int k = 1; k < no; ++k) pose_touched[k] = true; any_landmark0 = true; m += 1; }
       off += no;
+    }
+    {   // counting sort of the point tracks by start frame
+      int cnt[NF + 1] = {0};
+      for (int p = 0; p < v.n_points; ++p) cnt[v.point_start[p] + 1]++;
+      for (int f = 0; f < NF; ++f) cnt[f + 1] += cnt[f];
+      for (int f = 0; f <= NF; ++f) ps_cnt[w * (NF + 1) + f] = cnt[f];
+      int pos[NF + 1];
+      for (int f = 0; f <= NF; ++f) pos[f] = cnt[f];
+      for (int p = 0; p < v.n_points; ++p) ps_list[w * B.maxP + pos[v.point_start[p]]++] = p;
     }
     off = 0;
     for (int l = 0; l < v.n_lines; ++l) {
@@ -471,6 +483,7 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
   HIPCHK(c, up(c, B.nP, nP)); HIPCHK(c, up(c, B.nL, nL));
   HIPCHK(c, up(c, B.pt_start, pt_start)); HIPCHK(c, up(c, B.pt_nobs, pt_nobs)); HIPCHK(c, up(c, B.pt_off, pt_off));
   HIPCHK(c, up(c, B.pt_obs, pt_obs));
+  HIPCHK(c, up(c, B.ps_list, ps_list)); HIPCHK(c, up(c, B.ps_cnt, ps_cnt));
   HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
   HIPCHK(c, up(c, B.ln_obs, ln_obs));
   HIPCHK(c, up(c, B.nLO, nLO)); HIPCHK(c, up(c, B.lo_ln, lo_ln));
@@ -502,7 +515,7 @@ int vpl_ba_solve(vpl_ctx* c) {
   DevBatch& B = c->B;
   const dim3 grid(c->nW);
   hipStream_t s = c->stream;
-  { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(256), 0, s, B); }
+  { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(256), PREP_SMEM, s, B); }
   { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<false>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
   for (int it = 0; it < c->opt.num_iterations; ++it) {
     { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), SOLVE_SMEM, s, B); }
