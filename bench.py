@@ -78,10 +78,10 @@ def main():
 
     # ---- setup (untimed): windows A (preceding window, no prior) and B (the timed batch) ----
     t_setup = time.time()
-    base = rank * nW
-    A = [v.workload.generate(v.workload.seed_for(3, 2 * (base + i)), cfg, 0.37 * (base + i)) for i in range(nW)]
-    B = [v.workload.generate(v.workload.seed_for(3, 2 * (base + i) + 1), cfg, 0.37 * (base + i) + cfg.kf_dt)
-         for i in range(nW)]
+    lo, hi = v.shard.window_range(rank, world, nW)
+    seeds = [v.shard.window_seeds(3, g) for g in range(lo, hi)]
+    A = [v.workload.generate(sa, cfg, t) for (sa, sb, t) in seeds]
+    B = [v.workload.generate(sb, cfg, t + cfg.kf_dt) for (sa, sb, t) in seeds]
     pre = ctx.preintegrate(*v.workload.imu_batch_arrays(A + B), opt)     # IntegrationBase on device
     v.workload.set_preintegrations(A + B, pre)
     priors, _ = ctx.solve_windows(A, opt)                                # warm-up solve -> priors for B
@@ -113,9 +113,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = v.shard.reduce_max(dist, elapsed, dev)
     value = world * nW * args.steps / elapsed
 
     # ---- per-kernel device time with HIP events on the launch stream (separate, un-timed pass) ----

@@ -10,3 +10,4 @@ from .capi import (  # noqa: F401
     BaOptions, Preintegration, Prior, Window, SolveReport, Context, default_options, load_hip_library,
 )
 from . import workload  # noqa: F401
+from . import shard  # noqa: F401
