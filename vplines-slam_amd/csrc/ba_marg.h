@@ -77,118 +77,140 @@ __global__ __launch_bounds__(128) void k_gauge(DevBatch B) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Block-cooperative cyclic Jacobi eigen-solver for a symmetric matrix held in LDS.
-// The matrix is padded to an even dimension m (dummy row/column of zeros when n is odd) with row
-// stride ld.  Parallel round-robin ordering: m/2 disjoint rotations per step; every step is ONE pass
-// over 2x2 blocks B' = R_P^T B R_Q (double buffered between A0/A1) plus the column update of V, so a
-// step costs two barriers.  On exit *Aout points at the buffer whose diagonal holds the eigenvalues;
-// V's columns are the eigenvectors.
-__device__ double* jacobi_eig(double* A0, double* A1, double* V, int m, int ld, double* cs, int* prm, double* red, int* nsweeps) {
-  const int tid = threadIdx.x, T = blockDim.x;
-  const int half = m / 2;
-  for (int i = tid; i < m * m; i += T) V[(i / m) * ld + (i % m)] = (i / m == i % m) ? 1.0 : 0.0;
-  // the task list of a step does not depend on the step: decode it once (no integer divisions inside)
-  constexpr int MAXT = 8;
-  const int nblk = half * (half + 1) / 2;        // 2x2 blocks with P >= Q (the mirror is written too)
-  const int ntask = nblk + half * m;
-  int tP[MAXT], tQ[MAXT];                        // A task: (P, Q) ; V task: (P, -1 - k)
-  int nt = 0;
-  for (int it = tid; it < ntask && nt < MAXT; it += T, ++nt) {
-    if (it < nblk) {
-      int P, Q;
-      tri_decode(it, P, Q);
-      tP[nt] = P; tQ[nt] = Q;
-    } else {
-      const int it2 = it - nblk;
-      tP[nt] = it2 / m;
-      tQ[nt] = -1 - (it2 % m);
-    }
-  }
-  double* cur = A0;
-  double* nxt = A1;
-  // Convergence: the classical relative criterion -- a sweep in which no pair needed a rotation
-  // (|a_pq| <= 1e-15 sqrt(|a_pp a_qq|)).  The matrices here are strongly graded (eigenvalues from
-  // 1e-8 to 1e10) and the pseudo-inverse / 1/sqrt(lambda) of the small ones is what is consumed,
-  // so relative (not Frobenius) accuracy is required; graded inputs take 12-20 sweeps.
-  int* rotflag = prm + 2 * half;   // prm holds 2*half ints; one spare slot follows (m + 1 allocated)
-  for (int sweep = 0; sweep < 40; ++sweep) {
-    __syncthreads();
-    const int had = (sweep == 0) ? 1 : *rotflag;
-    __syncthreads();
-    if (nsweeps && threadIdx.x == 0) *nsweeps = sweep;
-    if (!had) break;
-    if (tid == 0) *rotflag = 0;
-    __syncthreads();
-    for (int step = 0; step < m - 1; ++step) {
-      if (tid < half) {   // round-robin pairing: player 0 fixed, the others rotate
-        int a = tid == 0 ? 0 : 1 + (tid - 1 + step) % (m - 1);
-        int b = tid == 0 ? 1 + (m - 2 + step) % (m - 1) : 1 + (m - 2 - tid + step) % (m - 1);
-        const int p = min(a, b), q = max(a, b);
-        double c = 1.0, s = 0.0;
-        const double apq = cur[p * ld + q], app = cur[p * ld + p], aqq = cur[q * ld + q];
-        if (fabs(apq) > 1e-15 * sqrt(fabs(app * aqq)) && apq != 0.0) {
-          *rotflag = 1;
-          const double theta = (aqq - app) / (2.0 * apq);
-          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-          c = 1.0 / sqrt(t * t + 1.0);
-          s = t * c;
-        }
-        prm[2 * tid] = p; prm[2 * tid + 1] = q;
-        cs[2 * tid] = c; cs[2 * tid + 1] = s;
+// Spectral factor of a symmetric positive semi-definite matrix held in LDS (full storage, row stride ld):
+//     A = B B^T,  B = P^T G,  columns of G mutually orthogonal,  |g_k|^2 = lambda_k (eigenvalues of A).
+// Step 1: Cholesky with diagonal pivoting, P A P^T = L L^T (stops when no positive pivot is left).
+// Step 2: one-sided (Hestenes) Jacobi on the columns of L until they are orthogonal: G = L J.
+// The Cholesky factor of a graded PSD matrix is what makes Jacobi converge in a few sweeps and to high
+// RELATIVE accuracy of the small eigenvalues (Demmel & Veselic), which the marginalisation needs because it
+// consumes 1/lambda (pseudo-inverse) and 1/sqrt(lambda).  Round-robin ordering, 8 lanes per column pair,
+// one barrier per step.  On exit: A holds G (n x rank), lam[k] = |g_k|^2, perm[t] = original index of row t.
+// Returns the rank.  Needs blockDim.x >= 8 * ((n + 1) / 2).
+__device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* lam, double* red, int* iflag) {
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
+  for (int i = tid; i < n; i += T) perm[i] = i;
+  __syncthreads();
+  int rank = n;
+  for (int k = 0; k < n; ++k) {
+    // pivot: largest remaining diagonal (first index on ties), found by wave 0
+    if (tid < 64) {
+      double best = -1.0;
+      int bi = k;
+      for (int i = k + lane; i < n; i += 64) {
+        const double d = A[i * ld + i];
+        if (d > best) { best = d; bi = i; }
       }
-      __syncthreads();
 #pragma unroll
-      for (int k2 = 0; k2 < MAXT; ++k2) {
-        if (k2 >= nt) break;
-        const int P = tP[k2], Q = tQ[k2];
-        const int p = prm[2 * P], q = prm[2 * P + 1];
-        const double c1 = cs[2 * P], s1 = cs[2 * P + 1];
-        if (Q >= 0) {
-          const int r = prm[2 * Q], u = prm[2 * Q + 1];
-          const double c2 = cs[2 * Q], s2 = cs[2 * Q + 1];
-          const double bpr = cur[p * ld + r], bpu = cur[p * ld + u], bqr = cur[q * ld + r], bqu = cur[q * ld + u];
-          // columns: [x_r, x_u] <- [c2 x_r - s2 x_u, s2 x_r + c2 x_u] ; rows likewise with (c1, s1)
-          const double tpr = c2 * bpr - s2 * bpu, tpu = s2 * bpr + c2 * bpu;
-          const double tqr = c2 * bqr - s2 * bqu, tqu = s2 * bqr + c2 * bqu;
-          const double npr = c1 * tpr - s1 * tqr, npu = c1 * tpu - s1 * tqu;
-          const double nqr = s1 * tpr + c1 * tqr, nqu = s1 * tpu + c1 * tqu;
-          nxt[p * ld + r] = npr; nxt[p * ld + u] = npu; nxt[q * ld + r] = nqr; nxt[q * ld + u] = nqu;
-          nxt[r * ld + p] = npr; nxt[u * ld + p] = npu; nxt[r * ld + q] = nqr; nxt[u * ld + q] = nqu;
-        } else {
-          const int k = -1 - Q;
-          const double vkp = V[k * ld + p], vkq = V[k * ld + q];
-          V[k * ld + p] = c1 * vkp - s1 * vkq;
-          V[k * ld + q] = s1 * vkp + c1 * vkq;
-        }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
       }
-      __syncthreads();
-      double* t = cur; cur = nxt; nxt = t;
+      if (lane == 0) { iflag[0] = bi; red[0] = best; }
     }
+    __syncthreads();
+    const int p = iflag[0];
+    const double piv = red[0];
+    if (!(piv > 0.0)) { rank = k; break; }
+    if (p != k) {   // symmetric swap k <-> p (rows, then columns), full storage
+      for (int c = tid; c < n; c += T) { const double t = A[k * ld + c]; A[k * ld + c] = A[p * ld + c]; A[p * ld + c] = t; }
+      __syncthreads();
+      for (int r = tid; r < n; r += T) { const double t = A[r * ld + k]; A[r * ld + k] = A[r * ld + p]; A[r * ld + p] = t; }
+      if (tid == 0) { const int t = perm[k]; perm[k] = perm[p]; perm[p] = t; }
+      __syncthreads();
+    }
+    const double lkk = sqrt(piv);
+    const double inv = 1.0 / lkk;
+    // trailing update with the unscaled column, then scale the column
+    for (int it = tid; it < (n - k - 1) * (n - k - 1); it += T) {
+      const int i = k + 1 + it / (n - k - 1), j = k + 1 + it % (n - k - 1);
+      A[i * ld + j] -= A[i * ld + k] * A[j * ld + k] / piv;
+    }
+    __syncthreads();
+    for (int i = k + tid; i < n; i += T) {
+      A[i * ld + k] = (i == k) ? lkk : A[i * ld + k] * inv;
+      if (i > k) A[k * ld + i] = 0.0;   // upper part of row k is not part of L
+    }
+    __syncthreads();
   }
   __syncthreads();
-  return cur;
+  // columns rank..n-1 do not exist
+  for (int it = tid; it < n * (n - rank); it += T) A[(it / (n - rank)) * ld + rank + it % (n - rank)] = 0.0;
+  __syncthreads();
+  // ---- one-sided Jacobi on the rank columns ----
+  const int m = (rank + 1) & ~1, half = m / 2;
+  const int P = tid >> 3, sub = tid & 7;
+  for (int sweep = 0; sweep < 40 && rank > 1; ++sweep) {
+    if (tid == 0) iflag[1] = 0;
+    __syncthreads();
+    for (int step = 0; step < m - 1; ++step) {
+      if (P < half) {
+        const int a = P == 0 ? 0 : 1 + (P - 1 + step) % (m - 1);
+        const int b = P == 0 ? 1 + (m - 2 + step) % (m - 1) : 1 + (m - 2 - P + step) % (m - 1);
+        const int ci = min(a, b), cj = max(a, b);
+        double gi[10], gj[10];
+        double al = 0, be = 0, ga = 0;
+        if (cj < rank) {
+#pragma unroll
+          for (int q = 0; q < 10; ++q) {
+            const int r = sub + 8 * q;
+            gi[q] = r < n ? A[r * ld + ci] : 0.0;
+            gj[q] = r < n ? A[r * ld + cj] : 0.0;
+            al += gi[q] * gi[q]; be += gj[q] * gj[q]; ga += gi[q] * gj[q];
+          }
+        }
+        al += __shfl_xor(al, 1, 64); al += __shfl_xor(al, 2, 64); al += __shfl_xor(al, 4, 64);
+        be += __shfl_xor(be, 1, 64); be += __shfl_xor(be, 2, 64); be += __shfl_xor(be, 4, 64);
+        ga += __shfl_xor(ga, 1, 64); ga += __shfl_xor(ga, 2, 64); ga += __shfl_xor(ga, 4, 64);
+        if (cj < rank && fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
+          const double zeta = (be - al) / (2.0 * ga);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+          for (int q = 0; q < 10; ++q) {
+            const int r = sub + 8 * q;
+            if (r < n) {
+              A[r * ld + ci] = c * gi[q] - sn * gj[q];
+              A[r * ld + cj] = sn * gi[q] + c * gj[q];
+            }
+          }
+          if (sub == 0) iflag[1] = 1;
+        }
+      }
+      __syncthreads();
+    }
+    if (!iflag[1]) break;
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += T) {
+    double s2 = 0;
+    if (k < rank)
+      for (int r = 0; r < n; ++r) s2 += A[r * ld + k] * A[r * ld + k];
+    lam[k] = s2;
+  }
+  __syncthreads();
+  return rank;
 }
 
 constexpr int MARG_THREADS = 512;
 constexpr double kMargEps = 1e-8;   // marginalization_factor.h:67
 constexpr int MTROWS = 32;          // landmark rows staged per elimination pass
+static_assert(MAXKEEP <= 80, "psd_spectral_factor keeps 10 rows per lane (8 lanes per column pair)");
 
 // LDS layout of k_marg (doubles), shared by host (size) and device (offsets)
 struct MargLayout {
-  int m, ldm, EB, nd, ldd, WS, total;
+  int ldm, EB, nd, ldd, total;
 };
 __host__ __device__ inline MargLayout marg_layout(int n) {
   MargLayout L;
-  L.m = (n + 1) & ~1;
-  if (L.m < 2) L.m = 2;
-  L.ldm = L.m + 1;
-  L.EB = L.m * L.ldm;
+  const int nn = n < 2 ? 2 : n;
+  L.ldm = nn | 1;                       // odd row stride
+  L.EB = nn * L.ldm;
   L.nd = 15 + n;
-  L.ldd = L.nd + 1;
-  const int need = L.nd * L.ldd + MTROWS * 74 + 3 * 16 * 17;
-  L.WS = need > 2 * L.EB ? need : 2 * L.EB;
-  // A0 | workspace | bv(nd) | tmp(nd*16) | cs(m) | red(20) | ints: prm(m) dmap(nd) lst(2*1024)
-  L.total = L.EB + L.WS + L.nd + L.nd * 16 + L.m + 20 + (L.m + 2 + L.nd + 2048 + 8) / 2 + 4;
+  L.ldd = L.nd | 1;
+  // G (kept block) | Ad (nd x ldd) | tile | E15 (15 x 17) | bv(nd) | tmp(nd*16) | lam(nn) | red(24) | ints
+  L.total = L.EB + L.nd * L.ldd + MTROWS * 74 + 16 * 17 + L.nd + L.nd * 16 + nn + 16 + 24 + (nn + L.nd + 2048 + 16) / 2 + 4;
   return L;
 }
 
@@ -199,21 +221,20 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   const int nb = B.mg_nb[w];
   const int n = B.mg_n[w];
   const MargLayout L = marg_layout(n);
-  const int nd = L.nd, ldd = L.ldd, m = L.m, ldm = L.ldm;
-  double* A0 = sm;                       // m x ldm : kept block / eigen buffer 0
-  double* WSP = A0 + L.EB;               // workspace
-  double* Ad = WSP;                      // nd x ldd dense pre-marginalisation matrix
+  const int nd = L.nd, ldd = L.ldd, ldm = L.ldm;
+  double* G = sm;                        // n x ldm : kept block -> spectral factor
+  double* Ad = G + L.EB;                 // nd x ldd dense pre-marginalisation matrix
   double* tile = Ad + nd * ldd;          // MTROWS x 74
-  double* E0 = tile + MTROWS * 74;       // 3 x (16 x 17) buffers for the 15x15 eigen problem
-  double* bv = WSP + L.WS;               // nd
+  double* E15 = tile + MTROWS * 74;      // 15 x 17: Amm -> its spectral factor
+  double* bv = E15 + 16 * 17;            // nd
   double* tmp = bv + nd;                 // nd * 16
-  double* cs = tmp + nd * 16;            // m
-  double* red = cs + m;                  // 20
-  int* prm = (int*)(red + 20);           // m
-  int* dmap = prm + m + 2;               // nd
-  int* lst = dmap + nd;                  // 2 x 1024
+  double* lam = tmp + nd * 16;           // max(n, 15) + 1
+  double* red = lam + (n < 2 ? 2 : n) + 16;   // 24
+  int* perm = (int*)(red + 24);          // max(n, 15)
+  int* dmap = perm + (n < 16 ? 16 : n) + (n & 1);   // nd
+  int* lst = dmap + nd + (nd & 1);       // 2 x 1024
   constexpr int LOFF = 1024;
-  __shared__ int s_np0, s_nl0;
+  __shared__ int s_np0, s_nl0, s_flag[4];
 
   // dense order: [sb_0 (9), pose_0 (6) | kept blocks in canonical order]  (the reference moves the
   // pose-like marginalised blocks behind the landmarks in descending index order, :291-309)
@@ -313,77 +334,73 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   }
 
   // ---- marginalise the 15 dims of frame 0 through the eigen pseudo-inverse (:329-346) ----------
-  double* Em0 = E0;
-  double* Em1 = E0 + 16 * 17;
-  double* Vmm = E0 + 2 * 16 * 17;
-  for (int it = tid; it < 16 * 16; it += T) {
-    const int i = it / 16, j = it % 16;
-    Em0[i * 17 + j] = (i < 15 && j < 15) ? 0.5 * (Ad[i * ldd + j] + Ad[j * ldd + i]) : 0.0;
-  }
-  __syncthreads();
-  double* Emm = jacobi_eig(Em0, Em1, Vmm, 16, 17, cs, prm, red, nullptr);
-  double* Ainv = (Emm == Em0) ? Em1 : Em0;   // the other buffer is free now
+  //      Amm^+ = sum_{lambda_k > eps} b_k b_k^T / lambda_k^2   with Amm = B B^T, b_k orthogonal, |b_k|^2 = lambda_k
   for (int it = tid; it < 225; it += T) {
     const int i = it / 15, j = it % 15;
-    double s = 0;
-    for (int k = 0; k < 15; ++k) {
-      const double lam = Emm[k * 17 + k];
-      if (lam > kMargEps) s += Vmm[i * 17 + k] * Vmm[j * 17 + k] / lam;
-    }
-    Ainv[i * 17 + j] = s;
+    E15[i * 17 + j] = 0.5 * (Ad[i * ldd + j] + Ad[j * ldd + i]);
   }
   __syncthreads();
-  // tmp = Arm * Amm_inv  (n x 15)
+  psd_spectral_factor(E15, 15, 17, perm, lam, red, s_flag);
+  // tmp(n x 15) = Arm * Amm^+ :  first Y = Arm * B (n x 15), then tmp = (Y ./ lambda^2) * B^T
+  double* Y = tile;   // n x 16 scratch (tile is free now)
   for (int it = tid; it < n * 15; it += T) {
-    const int i = it / 15, j = it % 15;
+    const int i = it / 15, k = it % 15;
     double s = 0;
-    for (int k = 0; k < 15; ++k) s += Ad[(15 + i) * ldd + k] * Ainv[k * 17 + j];
-    tmp[i * 16 + j] = s;
+    for (int t = 0; t < 15; ++t) s += Ad[(15 + i) * ldd + perm[t]] * E15[t * 17 + k];
+    Y[i * 16 + k] = lam[k] > kMargEps ? s / (lam[k] * lam[k]) : 0.0;
   }
   __syncthreads();
-  // A0 <- Arr - tmp * Amr (padded to m x m with zeros) ; b <- brr - tmp * bmm
+  for (int it = tid; it < n * 15; it += T) {
+    const int i = it / 15, t = it % 15;   // column perm[t] of tmp
+    double s = 0;
+    for (int k = 0; k < 15; ++k) s += Y[i * 16 + k] * E15[t * 17 + k];
+    tmp[i * 16 + perm[t]] = s;
+  }
+  __syncthreads();
+  // G <- Arr - tmp * Amr ; b <- brr - tmp * bmm
   double* Aout = B.mg_A + (size_t)w * MAXKEEP * MAXKEEP;
   double* bout = B.mg_b + (size_t)w * MAXKEEP;
-  for (int it = tid; it < m * m; it += T) {
-    const int i = it / m, j = it % m;
-    double v = 0.0;
-    if (i < n && j < n) {
-      double s = 0;
-      for (int k = 0; k < 15; ++k) s += tmp[i * 16 + k] * Ad[k * ldd + 15 + j];
-      v = Ad[(15 + i) * ldd + 15 + j] - s;
-      Aout[i * n + j] = v;
-    }
-    A0[i * ldm + j] = v;
+  for (int it = tid; it < n * n; it += T) {
+    const int i = it / n, j = it % n;
+    double s = 0;
+    for (int k = 0; k < 15; ++k) s += tmp[i * 16 + k] * Ad[k * ldd + 15 + j];
+    const double v = Ad[(15 + i) * ldd + 15 + j] - s;
+    Aout[i * n + j] = v;
+    G[i * ldm + j] = v;
   }
   for (int i = tid; i < n; i += T) {
     double s = 0;
     for (int k = 0; k < 15; ++k) s += tmp[i * 16 + k] * bv[k];
-    const double v = bv[15 + i] - s;
-    cs[i] = v;
+    bout[i] = bv[15 + i] - s;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += T) { bv[i] = cs[i]; bout[i] = cs[i]; }
+  for (int i = tid; i < n; i += T) bv[i] = bout[i];
+  // the reference eigen-decomposes A as it is; symmetrise the copy the factorisation works on
+  for (int it = tid; it < n * n; it += T) {
+    const int i = it / n, j = it % n;
+    if (i > j) G[i * ldm + j] = 0.5 * (G[i * ldm + j] + G[j * ldm + i]);
+  }
   __syncthreads();
-  // ---- eigen decomposition of the kept block (:349-357): workspace now holds A1 and V ------------
-  double* A1 = WSP;
-  double* V = WSP + L.EB;
-  double* Af = jacobi_eig(A0, A1, V, m, ldm, cs, prm, red, B.mg_m + w);
+  for (int it = tid; it < n * n; it += T) {
+    const int i = it / n, j = it % n;
+    if (i < j) G[i * ldm + j] = G[j * ldm + i];
+  }
+  __syncthreads();
+  // ---- spectral factor of the kept block (:349-357): J0 = sqrt(S) V^T = B^T, r0 = S^-1/2 V^T b ------
+  psd_spectral_factor(G, n, ldm, perm, lam, red, s_flag);
   double* J0 = B.mg_J0 + (size_t)w * MAXKEEP * MAXKEEP;
   double* r0 = B.mg_r0 + (size_t)w * MAXKEEP;
-  // the reference's SelfAdjointEigenSolver returns eigenvalues ascending; the row order of J0 is
-  // irrelevant to the prior it defines (an orthogonal transform of the residual), kept in Jacobi order.
   for (int it = tid; it < n * n; it += T) {
-    const int k = it / n, i = it % n;
-    const double lam = Af[k * ldm + k];
-    const double S = lam > kMargEps ? lam : 0.0;
-    J0[it] = sqrt(S) * V[i * ldm + k];
+    const int k = it / n, t = it % n;   // J0[k][perm[t]] = G[t][k]
+    J0[k * n + perm[t]] = lam[k] > kMargEps ? G[t * ldm + k] : 0.0;
   }
   for (int k = tid; k < n; k += T) {
-    const double lam = Af[k * ldm + k];
-    const double Sinv = lam > kMargEps ? 1.0 / lam : 0.0;
     double vb = 0;
-    for (int i = 0; i < n; ++i) vb += V[i * ldm + k] * bv[i];
-    r0[k] = sqrt(Sinv) * vb;
+    if (lam[k] > kMargEps) {
+      for (int t = 0; t < n; ++t) vb += G[t * ldm + k] * bv[perm[t]];
+      vb /= lam[k];
+    }
+    r0[k] = vb;
   }
   // x0 of the kept blocks: the linearisation point (preMarginalize copies, :110-129)
   if (tid < nb) {

@@ -627,10 +627,6 @@ int vpl_ba_debug_stamps(vpl_ctx* c, int w, long long* out) {
   HIPCHK(c, hipMemcpy(out, c->B.dbg + (size_t)w * 64, 64 * 8, hipMemcpyDeviceToHost));
   return VPL_OK;
 }
-int vpl_ba_debug_sweeps(vpl_ctx* c, int* out) {
-  HIPCHK(c, hipMemcpy(out, c->B.mg_m, c->nW * 4, hipMemcpyDeviceToHost));
-  return VPL_OK;
-}
 
 int vpl_ba_enable_kernel_timing(vpl_ctx* c, int enable) {
   if (!c) return VPL_E_INVALID;
