@@ -1,0 +1,411 @@
+// TEST INFRASTRUCTURE -- CPU oracle (see smallmat.h).
+// Restates the EDLines line extractor of the reference's line front-end:
+//   EDLineDetector::EdgeDrawing          line_matching/src/edline_detector.cpp:81-710
+//   EDLineDetectorParallel::operator()   :960-1174   (LeastSquaresLineFit :729-891, LineValidation :893-958)
+//   EDLineDetector::EDline               :1176-1198  ; nfa / log_gamma  edline_detector.h:186-348
+// Only the production configuration is restated: smoothed = true (no Gaussian blur,
+// feature_tracker/src/line_feature_tracker.cpp:87 -> edline_detector.cpp:82-86).
+//
+// OpenCV 3.4 (third party, not in the tree) supplies Sobel / absdiff / add / threshold / Mat division /
+// compare / the float GEMM of the line fit.  Their arithmetic is restated from the published behaviour:
+//   Sobel 3x3, CV_8U -> CV_16S, BORDER_REFLECT_101, exact integer;
+//   threshold(THRESH_TOZERO) on CV_16S: dst = src > thresh ? src : 0;
+//   Mat / 4 on CV_16S: saturate_cast<short>(src * 0.25) = round half to even;
+//   Mat_<float> products (gemm, small sizes): products and sums in double, result cast to float.
+// PARITY UNPINNED: the reference holds no numeric fixture for this path (only rendered pictures).
+#include <array>
+#include <cmath>
+#include <cfloat>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace orc {
+
+struct EDParam {
+  int gradientThreshold;    // 30 in production (line_feature_tracker_node.cpp:203)
+  int anchorThreshold;      // 5
+  int scanIntervals;        // 2
+  int minLineLen;           // 35
+  double lineFitErrThreshold;  // 1.8
+};
+
+struct EDLine {
+  float endpoint[4];
+  double equation[3];
+  float center[2];
+  float length;
+};
+
+static inline int refl101(int i, int n) {   // BORDER_REFLECT_101
+  if (i < 0) return -i;
+  if (i >= n) return 2 * n - 2 - i;
+  return i;
+}
+static inline short div4_half_even(short v) { return (short)std::nearbyint((double)v * 0.25); }
+
+// edline_detector.cpp:125-136
+void ed_gradient(const uint8_t* img, int W, int H, int gradTh, short* dx, short* dy, short* gImg, uint8_t* dirImg) {
+  for (int y = 0; y < H; ++y) {
+    const uint8_t* r0 = img + (size_t)refl101(y - 1, H) * W;
+    const uint8_t* r1 = img + (size_t)y * W;
+    const uint8_t* r2 = img + (size_t)refl101(y + 1, H) * W;
+    for (int x = 0; x < W; ++x) {
+      const int xm = refl101(x - 1, W), xp = refl101(x + 1, W);
+      const int gx = (r0[xp] + 2 * r1[xp] + r2[xp]) - (r0[xm] + 2 * r1[xm] + r2[xm]);
+      const int gy = (r2[xm] + 2 * r2[x] + r2[xp]) - (r0[xm] + 2 * r0[x] + r0[xp]);
+      const size_t i = (size_t)y * W + x;
+      dx[i] = (short)gx;
+      dy[i] = (short)gy;
+      const int ax = gx < 0 ? -gx : gx, ay = gy < 0 ? -gy : gy;
+      const int sum = ax + ay;
+      const short t = sum > gradTh + 1 ? (short)sum : (short)0;   // THRESH_TOZERO at gradienThreshold_ + 1
+      gImg[i] = div4_half_even(t);
+      dirImg[i] = ax < ay ? 255 : 0;   // Horizontal = 255 if |dx| < |dy|
+    }
+  }
+}
+
+// edline_detector.cpp:148-164 ; scan order: w outer, h inner
+int ed_anchors(const short* g, const uint8_t* dir, int W, int H, int scan, int anchorTh, unsigned* ax, unsigned* ay, int cap) {
+  int n = 0;
+  for (int w = 1; w < W - 1; w += scan)
+    for (int h = 1; h < H - 1; h += scan) {
+      const int i = h * W + w;
+      bool a;
+      if (dir[i] == 255) a = g[i] >= g[i - W] + anchorTh && g[i] >= g[i + W] + anchorTh;
+      else a = g[i] >= g[i - 1] + anchorTh && g[i] >= g[i + 1] + anchorTh;
+      if (a) {
+        if (n < cap) { ax[n] = w; ay[n] = h; }
+        ++n;
+      }
+    }
+  return n;
+}
+
+namespace {
+enum { UpDir = 1, RightDir = 2, DownDir = 3, LeftDir = 4 };
+struct Walker {
+  const short* g;
+  const uint8_t* dir;
+  uint8_t* edge;
+  int W, H;
+  unsigned lastX = 0, lastY = 0;   // persist across walks exactly like the reference's locals
+  // one walk (the body that appears four times at :209-647), appending to (px, py)
+  void walk(unsigned x, unsigned y, unsigned char lastDirection, std::vector<unsigned>& px, std::vector<unsigned>& py) {
+    int idx = y * W + x;
+    while (g[idx] > 0 && !edge[idx]) {
+      edge[idx] = 1;
+      px.push_back(x);
+      py.push_back(y);
+      unsigned char shouldGo = 0;
+      if (dir[idx] == 255) {
+        if (lastDirection == UpDir || lastDirection == DownDir) shouldGo = x > lastX ? RightDir : LeftDir;
+        lastX = x; lastY = y;
+        if (lastDirection == RightDir || shouldGo == RightDir) {
+          if (x == (unsigned)W - 1 || y == 0 || y == (unsigned)H - 1) break;
+          const unsigned char g1 = (unsigned char)g[idx - W + 1], g2 = (unsigned char)g[idx + 1], g3 = (unsigned char)g[idx + W + 1];
+          if (g1 >= g2 && g1 >= g3) { x = x + 1; y = y - 1; }
+          else if (g3 >= g2 && g3 >= g1) { x = x + 1; y = y + 1; }
+          else x = x + 1;
+          lastDirection = RightDir;
+        } else if (lastDirection == LeftDir || shouldGo == LeftDir) {
+          if (x == 0 || y == 0 || y == (unsigned)H - 1) break;
+          const unsigned char g1 = (unsigned char)g[idx - W - 1], g2 = (unsigned char)g[idx - 1], g3 = (unsigned char)g[idx + W - 1];
+          if (g1 >= g2 && g1 >= g3) { x = x - 1; y = y - 1; }
+          else if (g3 >= g2 && g3 >= g1) { x = x - 1; y = y + 1; }
+          else x = x - 1;
+          lastDirection = LeftDir;
+        }
+      } else {
+        if (lastDirection == RightDir || lastDirection == LeftDir) shouldGo = y > lastY ? DownDir : UpDir;
+        lastX = x; lastY = y;
+        if (lastDirection == DownDir || shouldGo == DownDir) {
+          if (x == 0 || x == (unsigned)W - 1 || y == (unsigned)H - 1) break;
+          const unsigned char g1 = (unsigned char)g[idx + W + 1], g2 = (unsigned char)g[idx + W], g3 = (unsigned char)g[idx + W - 1];
+          if (g1 >= g2 && g1 >= g3) { x = x + 1; y = y + 1; }
+          else if (g3 >= g2 && g3 >= g1) { x = x - 1; y = y + 1; }
+          else y = y + 1;
+          lastDirection = DownDir;
+        } else if (lastDirection == UpDir || shouldGo == UpDir) {
+          if (x == 0 || x == (unsigned)W - 1 || y == 0) break;
+          const unsigned char g1 = (unsigned char)g[idx - W + 1], g2 = (unsigned char)g[idx - W], g3 = (unsigned char)g[idx - W - 1];
+          if (g1 >= g2 && g1 >= g3) { x = x + 1; y = y - 1; }
+          else if (g3 >= g2 && g3 >= g1) { x = x - 1; y = y - 1; }
+          else y = y - 1;
+          lastDirection = UpDir;
+        }
+      }
+      idx = y * W + x;
+    }
+  }
+};
+}  // namespace
+
+// edline_detector.cpp:166-707 : returns chains as (xCors, yCors, sId)
+void ed_route(const short* g, const uint8_t* dir, int W, int H, const unsigned* ax, const unsigned* ay, int nAnchors,
+              int minLineLen, uint8_t* edge, std::vector<unsigned>& xC, std::vector<unsigned>& yC, std::vector<unsigned>& sId) {
+  std::memset(edge, 0, (size_t)W * H);
+  Walker wk{g, dir, edge, W, H};
+  xC.clear(); yC.clear(); sId.clear();
+  std::vector<unsigned> fx, fy, sx, sy;
+  for (int i = 0; i < nAnchors; ++i) {
+    const unsigned x = ax[i], y = ay[i];
+    const int idx = y * W + x;
+    if (edge[idx]) continue;
+    fx.clear(); fy.clear(); sx.clear(); sy.clear();
+    const bool horiz = dir[idx] == 255;
+    wk.walk(x, y, horiz ? RightDir : DownDir, fx, fy);
+    edge[idx] = 0;   // the anchor is un-marked so that the second walk starts on it (:326, :535)
+    wk.walk(x, y, horiz ? LeftDir : UpDir, sx, sy);
+    if ((int)(fx.size() + sx.size()) < minLineLen + 1) continue;   // short edge dropped (its pixels stay marked)
+    sId.push_back((unsigned)xC.size());
+    for (int k = (int)fx.size() - 1; k >= 0; --k) { xC.push_back(fx[k]); yC.push_back(fy[k]); }   // first part reversed
+    for (size_t k = 1; k < sx.size(); ++k) { xC.push_back(sx[k]); yC.push_back(sy[k]); }          // second part without the anchor
+  }
+  sId.push_back((unsigned)xC.size());
+}
+
+// ---- NFA (edline_detector.h:186-348) -------------------------------------------------------------------
+static double log_gamma_lanczos(double x) {
+  static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+  double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5);
+  double b = 0.0;
+  for (int n = 0; n < 7; n++) {
+    a -= std::log(x + (double)n);
+    b += q[n] * std::pow(x, (double)n);
+  }
+  return a + std::log(b);
+}
+static double log_gamma_windschitl(double x) {
+  return 0.918938533204673 + (x - 0.5) * std::log(x) - x + 0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0)));
+}
+static double log_gamma(double x) { return x > 15.0 ? log_gamma_windschitl(x) : log_gamma_lanczos(x); }
+static bool double_equal(double a, double b) {
+  if (a == b) return true;
+  double abs_diff = std::fabs(a - b), aa = std::fabs(a), bb = std::fabs(b);
+  double abs_max = aa > bb ? aa : bb;
+  if (abs_max < DBL_MIN) abs_max = DBL_MIN;
+  return (abs_diff / abs_max) <= (100.0 * DBL_EPSILON);
+}
+double ed_nfa(int n, int k, double p, double logNT) {
+  const double tolerance = 0.1;
+  if (n == 0 || k == 0) return -logNT;
+  if (n == k) return -logNT - (double)n * std::log10(p);
+  const double p_term = p / (1.0 - p);
+  const double log1term = log_gamma((double)n + 1.0) - log_gamma((double)k + 1.0) - log_gamma((double)(n - k) + 1.0) +
+                          (double)k * std::log(p) + (double)(n - k) * std::log(1.0 - p);
+  double term = std::exp(log1term);
+  if (double_equal(term, 0.0)) {
+    if ((double)k > (double)n * p) return -log1term / 2.30258509299404568402 - logNT;
+    return -logNT;
+  }
+  double bin_tail = term;
+  for (int i = k + 1; i <= n; i++) {
+    const double bin_term = (double)(n - i + 1) / (double)i;
+    const double mult_term = bin_term * p_term;
+    term *= mult_term;
+    bin_tail += term;
+    if (bin_term < 1.0) {
+      const double err = term * ((1.0 - std::pow(mult_term, (double)(n - i + 1))) / (1.0 - mult_term) - 1.0);
+      if (err < tolerance * std::fabs(-std::log10(bin_tail) - logNT) * bin_tail) break;
+    }
+  }
+  return -std::log10(bin_tail) - logNT;
+}
+
+namespace {
+struct Fitter {
+  const unsigned* xC;
+  const unsigned* yC;
+  const uint8_t* dir;
+  const short* dx;
+  const short* dy;
+  int W, H, minLineLen;
+  double thr, logNT;
+  float ATA[4], ATV[2];   // cv::Mat_<float>
+
+  bool horiz(unsigned off) const { return dir[yC[off] * W + xC[off]] == 255; }
+  void solve(double eq[2]) const {
+    const double coef = 1.0 / (double(ATA[0]) * double(ATA[3]) - double(ATA[1]) * double(ATA[2]));
+    eq[0] = coef * (double(ATA[3]) * double(ATV[0]) - double(ATA[1]) * double(ATV[1]));
+    eq[1] = coef * (double(ATA[0]) * double(ATV[1]) - double(ATA[2]) * double(ATV[0]));
+  }
+  // :729-807 initial fit over minLineLen pixels; float inputs, double accumulation, float result (cv::gemm)
+  double fit_initial(unsigned offS, double eq[2]) {
+    const bool hz = horiz(offS);
+    double s_uu = 0, s_u = 0, s_uv = 0, s_v = 0;
+    for (int i = 0; i < minLineLen; ++i) {
+      const double u = (double)(float)(hz ? xC[offS + i] : yC[offS + i]);
+      const double v = (double)(float)(hz ? yC[offS + i] : xC[offS + i]);
+      s_uu += u * u; s_u += u; s_uv += u * v; s_v += v;
+    }
+    ATA[0] = (float)s_uu; ATA[1] = (float)s_u; ATA[2] = (float)s_u; ATA[3] = (float)(double)minLineLen;
+    ATV[0] = (float)s_uv; ATV[1] = (float)s_v;
+    solve(eq);
+    double err = 0;
+    for (int i = 0; i < minLineLen; ++i) {
+      const double u = (double)(hz ? xC[offS + i] : yC[offS + i]), v = (double)(hz ? yC[offS + i] : xC[offS + i]);
+      const double c = v - u * eq[0] - eq[1];
+      err += c * c;
+    }
+    return std::sqrt(err);
+  }
+  // :809-891 incremental update with the points [newS, offE)
+  void fit_update(unsigned offS_init, unsigned newS, unsigned offE, double eq[2]) {
+    const int newLength = (int)offE - (int)newS;
+    if ((int)offE - (int)offS_init <= 0 || newLength <= 0) return;   // the reference prints and returns -1, equation unchanged
+    const bool hz = horiz(offS_init);
+    double s_uu = 0, s_u = 0, s_uv = 0, s_v = 0;
+    for (unsigned o = newS; o < offE; ++o) {
+      const double u = (double)(float)(hz ? xC[o] : yC[o]);
+      const double v = (double)(float)(hz ? yC[o] : xC[o]);
+      s_uu += u * u; s_u += u; s_uv += u * v; s_v += v;
+    }
+    const float t00 = (float)s_uu, t01 = (float)s_u, t11 = (float)(double)newLength, v0 = (float)s_uv, v1 = (float)s_v;
+    ATA[0] = ATA[0] + t00; ATA[1] = ATA[1] + t01; ATA[2] = ATA[2] + t01; ATA[3] = ATA[3] + t11;
+    ATV[0] = ATV[0] + v0; ATV[1] = ATV[1] + v1;
+    solve(eq);
+  }
+  // :893-958
+  bool validate(unsigned offS, unsigned offE, const double leq[3]) const {
+    const int n = (int)offE - (int)offS;
+    int mgx = 0, mgy = 0;
+    std::vector<double> pd;
+    for (int i = 0; i < n; ++i) {
+      const int idx = yC[offS + i] * W + xC[offS + i];
+      mgx += dx[idx];
+      mgy += dy[idx];
+      pd.push_back(std::atan2(-(double)dx[idx], (double)dy[idx]));
+    }
+    const double ddx = std::fabs(leq[1]), ddy = std::fabs(leq[0]);
+    if (mgx == 0 && mgy == 0) return false;
+    float direction = 0.f;   // the reference leaves it uninitialised when no branch fires; all four cover every non-zero case
+    if (mgx > 0 && mgy >= 0) direction = (float)std::atan2(-ddy, ddx);
+    if (mgx <= 0 && mgy > 0) direction = (float)std::atan2(ddy, ddx);
+    if (mgx < 0 && mgy <= 0) direction = (float)std::atan2(ddy, -ddx);
+    if (mgx >= 0 && mgy < 0) direction = (float)std::atan2(-ddy, -ddx);
+    if (std::fabs(direction) < 0.15 || M_PI - std::fabs(direction) < 0.15)
+      if (std::fabs(leq[2]) < 10 || std::fabs(H - std::fabs(leq[2])) < 10) return false;
+    if (std::fabs(std::fabs(direction) - M_PI * 0.5) < 0.15)
+      if (std::fabs(leq[2]) < 10 || std::fabs(W - std::fabs(leq[2])) < 10) return false;
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+      const double dd = std::fabs(direction - pd[i]);
+      if (std::fabs(2 * M_PI - dd) < 0.392699 || dd < 0.392699) k++;
+    }
+    return ed_nfa(n, k, 0.125, logNT) > 0;
+  }
+};
+}  // namespace
+
+// EDLineDetectorParallel::operator() over all chains, sequentially (the reference's thread order is not
+// deterministic: lines are compared as a set)
+void ed_fit(const unsigned* xC, const unsigned* yC, const unsigned* sId, int nEdges, const uint8_t* dir, const short* dx,
+            const short* dy, int W, int H, const EDParam& P, std::vector<EDLine>& lines) {
+  Fitter F{xC, yC, dir, dx, dy, W, H, P.minLineLen, P.lineFitErrThreshold,
+           2.0 * (std::log10((double)W) + std::log10((double)H))};
+  const unsigned minLineLen = P.minLineLen;
+  for (int e = 0; e < nEdges; ++e) {
+    unsigned offS = sId[e], offE = sId[e + 1];
+    while (offE > offS + minLineLen) {
+      double eq[2] = {0, 0}, lineFitErr = 0;
+      while (offE > offS + minLineLen) {
+        lineFitErr = F.fit_initial(offS, eq);
+        if (lineFitErr <= P.lineFitErrThreshold) break;
+        offS += 2;   // SkipEdgePoint
+      }
+      if (lineFitErr > P.lineFitErrThreshold) break;
+      const bool hz = F.horiz(offS);
+      const unsigned offS_init = offS;
+      bool bExtended = true, bFirstTry = true;
+      int numOfOutlier = 0, tryTimes = 0;
+      unsigned newOffsetS = 0;
+      double coef1 = 0;
+      while (bExtended) {
+        tryTimes++;
+        if (bFirstTry) { bFirstTry = false; offS += minLineLen; }
+        else F.fit_update(offS_init, newOffsetS, offS, eq);
+        coef1 = 1 / std::sqrt(eq[0] * eq[0] + 1);
+        numOfOutlier = 0;
+        newOffsetS = offS;
+        while (offE > offS) {
+          const double d = hz ? std::fabs(eq[0] * xC[offS] - yC[offS] + eq[1]) * coef1
+                              : std::fabs(xC[offS] - eq[0] * yC[offS] - eq[1]) * coef1;
+          offS++;
+          if (d > P.lineFitErrThreshold) {
+            numOfOutlier++;
+            if (numOfOutlier > 3) break;
+          } else {
+            numOfOutlier = 0;
+          }
+        }
+        offS -= numOfOutlier;
+        if (offS - newOffsetS > 0 && tryTimes < 6) {} else bExtended = false;
+      }
+      double leq[3];
+      if (hz) { leq[0] = eq[0] * coef1; leq[1] = -1 * coef1; leq[2] = eq[1] * coef1; }
+      else { leq[0] = 1 * coef1; leq[1] = -eq[0] * coef1; leq[2] = -eq[1] * coef1; }
+      if (F.validate(offS_init, offS, leq)) {
+        EDLine L;
+        for (int k = 0; k < 3; ++k) L.equation[k] = leq[k];
+        const double a1 = leq[1] * leq[1], a2 = leq[0] * leq[0], a3 = leq[0] * leq[1], a4 = leq[2] * leq[0], a5 = leq[2] * leq[1];
+        unsigned Px = xC[offS_init], Py = yC[offS_init];
+        const float x1 = (float)(a1 * Px - a3 * Py - a4), y1 = (float)(a2 * Py - a3 * Px - a5);
+        Px = xC[offS - 1]; Py = yC[offS - 1];
+        const float x2 = (float)(a1 * Px - a3 * Py - a4), y2 = (float)(a2 * Py - a3 * Px - a5);
+        L.endpoint[0] = x1; L.endpoint[1] = y1; L.endpoint[2] = x2; L.endpoint[3] = y2;
+        L.center[0] = (float)((x1 + x2) / 2.0);
+        L.center[1] = (float)((y1 + y2) / 2.0);
+        L.length = (float)std::sqrt(std::pow((double)(x2 - x1), 2) + std::pow((double)(y2 - y1), 2));
+        lines.push_back(L);
+      }
+    }
+  }
+}
+
+}  // namespace orc
+
+using namespace orc;
+extern "C" {
+// Whole EDline() on one 8-bit image.  Optional outputs (may be NULL): dx, dy, gImg [W*H shorts], dirImg [W*H],
+// anchors (x,y pairs, cap entries) + *nAnchors, chains (xC,yC cap entries, sId cap/20 entries) + *nEdges.
+// lines: cap_lines * 10 doubles = x1,y1,x2,y2, eq0,eq1,eq2, cx,cy, length ; returns the number of lines.
+int orc_edlines(const uint8_t* img, int W, int H, int gradTh, int anchorTh, int scan, int minLineLen, double fitErr,
+                short* dx_o, short* dy_o, short* g_o, uint8_t* dir_o, unsigned* anchors_o, int* nAnchors_o,
+                unsigned* chainX_o, unsigned* chainY_o, unsigned* sId_o, int* nEdges_o, int cap_px, double* lines_o, int cap_lines) {
+  const size_t N = (size_t)W * H;
+  std::vector<short> dx(N), dy(N), g(N);
+  std::vector<uint8_t> dir(N), edge(N);
+  ed_gradient(img, W, H, gradTh, dx.data(), dy.data(), g.data(), dir.data());
+  const int cap = (int)(N / 5);
+  std::vector<unsigned> ax(cap), ay(cap);
+  int nA = ed_anchors(g.data(), dir.data(), W, H, scan, anchorTh, ax.data(), ay.data(), cap);
+  if (nA > cap) nA = cap;
+  std::vector<unsigned> xC, yC, sId;
+  ed_route(g.data(), dir.data(), W, H, ax.data(), ay.data(), nA, minLineLen, edge.data(), xC, yC, sId);
+  const int nE = (int)sId.size() - 1;
+  EDParam P{gradTh, anchorTh, scan, minLineLen, fitErr};
+  std::vector<EDLine> lines;
+  ed_fit(xC.data(), yC.data(), sId.data(), nE, dir.data(), dx.data(), dy.data(), W, H, P, lines);
+  if (dx_o) std::memcpy(dx_o, dx.data(), N * 2);
+  if (dy_o) std::memcpy(dy_o, dy.data(), N * 2);
+  if (g_o) std::memcpy(g_o, g.data(), N * 2);
+  if (dir_o) std::memcpy(dir_o, dir.data(), N);
+  if (anchors_o) for (int i = 0; i < nA && i < cap_px; ++i) { anchors_o[2 * i] = ax[i]; anchors_o[2 * i + 1] = ay[i]; }
+  if (nAnchors_o) *nAnchors_o = nA;
+  if (chainX_o) for (size_t i = 0; i < xC.size() && (int)i < cap_px; ++i) { chainX_o[i] = xC[i]; chainY_o[i] = yC[i]; }
+  if (sId_o) for (size_t i = 0; i < sId.size(); ++i) sId_o[i] = sId[i];
+  if (nEdges_o) *nEdges_o = nE;
+  int n = 0;
+  for (auto& L : lines) {
+    if (n >= cap_lines) break;
+    double* o = lines_o + 10 * n++;
+    for (int k = 0; k < 4; ++k) o[k] = L.endpoint[k];
+    for (int k = 0; k < 3; ++k) o[4 + k] = L.equation[k];
+    o[7] = L.center[0]; o[8] = L.center[1]; o[9] = L.length;
+  }
+  return (int)lines.size();
+}
+double orc_nfa(int n, int k, double p, double logNT) { return ed_nfa(n, k, p, logNT); }
+}

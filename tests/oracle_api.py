@@ -166,3 +166,31 @@ def solve_windows(windows, opt, threads=1):
     for i, w in enumerate(windows):
         w.from_c(cw[i])
     return priors, reps
+
+
+# ---- line front-end (EDLines) ---------------------------------------------------------------------------
+def edlines(img, grad_th=30, anchor_th=5, scan=2, min_len=35, fit_err=1.8, want_stages=False, cap_lines=4096):
+    """EDLineDetector::EDline with smoothed=true on one uint8 image. Returns lines [n,10] (x1,y1,x2,y2,eq0..2,cx,cy,len)
+    and, if want_stages, a dict of the intermediate images / anchors / chains."""
+    lib = load()
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    N = W * H
+    cap = N // 5
+    dx = np.zeros(N, np.int16); dy = np.zeros(N, np.int16); g = np.zeros(N, np.int16); d = np.zeros(N, np.uint8)
+    anchors = np.zeros((cap, 2), np.uint32); nA = C.c_int(0)
+    cx = np.zeros(2 * cap, np.uint32); cy = np.zeros(2 * cap, np.uint32); sid = np.zeros(cap // 20 + 2, np.uint32); nE = C.c_int(0)
+    lines = np.zeros((cap_lines, 10))
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    lib.orc_edlines.restype = C.c_int
+    n = lib.orc_edlines(P(img, C.c_uint8), W, H, grad_th, anchor_th, scan, min_len, C.c_double(fit_err),
+                        P(dx, C.c_int16), P(dy, C.c_int16), P(g, C.c_int16), P(d, C.c_uint8), P(anchors, C.c_uint32),
+                        C.byref(nA), P(cx, C.c_uint32), P(cy, C.c_uint32), P(sid, C.c_uint32), C.byref(nE), 2 * cap,
+                        P(lines, C.c_double), cap_lines)
+    lines = lines[:min(n, cap_lines)]
+    if not want_stages:
+        return lines
+    ne = nE.value
+    npx = int(sid[ne])
+    return lines, dict(dx=dx.reshape(H, W), dy=dy.reshape(H, W), g=g.reshape(H, W), dir=d.reshape(H, W),
+                       anchors=anchors[:nA.value], chain_x=cx[:npx], chain_y=cy[:npx], sid=sid[:ne + 1])

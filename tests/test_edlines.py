@@ -1,0 +1,139 @@
+"""Line front-end (EDLines).
+CPU: the oracle's gradient stage against an independent NumPy restatement (integer-exact), structural
+properties of the routing and of the extracted lines on the two EuRoC MH_04 fixtures.
+GPU: every stage of the HIP extractor against the oracle: gradient / direction / anchors / edge chains
+bit-exact, lines as a set."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_api as o
+import vplines_slam_amd as v
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+IMGS = [np.load(os.path.join(HERE, "golden", "mh04_%d.npy" % i)) for i in (1, 2)]
+
+
+def numpy_gradient(img, grad_th=30):
+    """independent restatement of edline_detector.cpp:125-136 with array ops"""
+    a = np.pad(img.astype(np.int32), 1, mode="reflect")   # numpy 'reflect' == BORDER_REFLECT_101
+    gx = (a[:-2, 2:] + 2 * a[1:-1, 2:] + a[2:, 2:]) - (a[:-2, :-2] + 2 * a[1:-1, :-2] + a[2:, :-2])
+    gy = (a[2:, :-2] + 2 * a[2:, 1:-1] + a[2:, 2:]) - (a[:-2, :-2] + 2 * a[:-2, 1:-1] + a[:-2, 2:])
+    s = np.abs(gx) + np.abs(gy)
+    t = np.where(s > grad_th + 1, s, 0)
+    g = np.rint(t * 0.25).astype(np.int16)                 # np.rint rounds half to even, like cv::saturate_cast
+    d = np.where(np.abs(gx) < np.abs(gy), 255, 0).astype(np.uint8)
+    return gx.astype(np.int16), gy.astype(np.int16), g, d
+
+
+def test_oracle_gradient_stage_is_integer_exact():
+    for img in IMGS:
+        _, st = o.edlines(img, want_stages=True)
+        gx, gy, g, d = numpy_gradient(img)
+        assert np.array_equal(st["dx"], gx) and np.array_equal(st["dy"], gy)
+        assert np.array_equal(st["g"], g) and np.array_equal(st["dir"], d)
+
+
+def test_oracle_routing_and_lines_properties():
+    img = IMGS[0]
+    lines, st = o.edlines(img, want_stages=True)
+    H, W = img.shape
+    # anchors sit on the odd lattice, in the reference's scan order (w outer, h inner)
+    a = st["anchors"].astype(np.int64)
+    assert np.all(a[:, 0] % 2 == 1) and np.all(a[:, 1] % 2 == 1)
+    key = a[:, 0] * 10000 + a[:, 1]
+    assert np.all(np.diff(key) > 0)
+    # chains: 8-connected, every pixel has a positive thresholded gradient, no pixel is used twice inside a chain
+    sid = st["sid"].astype(np.int64)
+    cx, cy = st["chain_x"].astype(np.int64), st["chain_y"].astype(np.int64)
+    assert np.all(st["g"][cy, cx] > 0)
+    for e in range(len(sid) - 1):
+        xs, ys = cx[sid[e]:sid[e + 1]], cy[sid[e]:sid[e + 1]]
+        assert len(xs) >= 35
+        assert np.all(np.maximum(np.abs(np.diff(xs)), np.abs(np.diff(ys))) == 1)
+        assert len(set(zip(xs.tolist(), ys.tolist()))) == len(xs)
+    # lines: unit normal, endpoints on the line, length consistent, longer than ~minLineLen
+    assert len(lines) > 50
+    n = np.hypot(lines[:, 4], lines[:, 5])
+    assert np.abs(n - 1).max() < 1e-12
+    for k in (0, 2):
+        res = lines[:, 4] * lines[:, k] + lines[:, 5] * lines[:, k + 1] + lines[:, 6]
+        assert np.abs(res).max() < 1e-3
+    assert np.abs(np.hypot(lines[:, 2] - lines[:, 0], lines[:, 3] - lines[:, 1]) - lines[:, 9]).max() < 1e-3
+    assert lines[:, 9].min() > 30
+    # idempotence / determinism
+    lines2 = o.edlines(img)
+    assert np.array_equal(lines, lines2)
+
+
+def test_oracle_edge_cases():
+    flat = np.full((64, 96), 17, np.uint8)
+    lines, st = o.edlines(flat, want_stages=True)
+    assert len(lines) == 0 and len(st["anchors"]) == 0 and np.all(st["g"] == 0)
+    step = np.zeros((64, 96), np.uint8)
+    step[:, 47] = 50                                     # a vertical edge whose gradient peaks in column 47
+    step[:, 48:] = 200                                   # (a perfect step gives a 2-px plateau and no anchor)
+    lines = o.edlines(step, min_len=20)
+    assert len(lines) >= 1
+    assert np.all(np.abs(np.abs(lines[:, 4]) - 1) < 1e-6)   # vertical lines: normal along x
+    assert np.all(np.abs(lines[:, 0] - 47.0) < 1.0)
+    # NFA known answers: n == k and k == 0 closed forms of edline_detector.h:253-254
+    lib = o.load()
+    lib.orc_nfa.restype = __import__("ctypes").c_double
+    lib.orc_nfa.argtypes = [__import__("ctypes").c_int, __import__("ctypes").c_int, __import__("ctypes").c_double, __import__("ctypes").c_double]
+    logNT = 2 * (np.log10(752) + np.log10(480))
+    assert abs(lib.orc_nfa(40, 40, 0.125, logNT) - (-logNT - 40 * np.log10(0.125))) < 1e-12
+    assert abs(lib.orc_nfa(40, 0, 0.125, logNT) + logNT) < 1e-12
+    # against the exact binomial tail (scipy) within the documented 10 % truncation of the series
+    from scipy.stats import binom
+    for (n, k) in [(60, 30), (100, 40), (35, 20)]:
+        exact = -np.log10(binom.sf(k - 1, n, 0.125)) - logNT
+        assert abs(lib.orc_nfa(n, k, 0.125, logNT) - exact) < 0.1 * abs(exact) + 0.05
+
+
+def canon(lines):
+    """canonical order for set comparison: sort by rounded endpoints"""
+    key = np.lexsort((np.round(lines[:, 3], 2), np.round(lines[:, 2], 2), np.round(lines[:, 1], 2), np.round(lines[:, 0], 2)))
+    return lines[key]
+
+
+@pytest.mark.gpu
+def test_gpu_edlines_stages_and_lines_match_oracle():
+    imgs = np.stack(IMGS + [IMGS[0][::-1].copy(), np.ascontiguousarray(IMGS[1][:, ::-1])])   # + flipped variants
+    fe = v.frontend.FrontendContext(device=0, max_images=len(imgs), width=752, height=480, max_lines=1024)
+    out = fe.detect_batch(imgs)
+    for i in range(len(imgs)):
+        lo, st = o.edlines(imgs[i], want_stages=True)
+        sg = fe.debug_stage(i)
+        for k in ("dx", "dy", "g", "dir"):
+            assert np.array_equal(sg[k], st[k]), k
+        assert np.array_equal(sg["anchors"], st["anchors"])
+        assert np.array_equal(sg["sid"], st["sid"])
+        assert np.array_equal(sg["chain_x"], st["chain_x"]) and np.array_equal(sg["chain_y"], st["chain_y"])
+        lg = out[i]
+        assert len(lg) == len(lo), (len(lg), len(lo))
+        a, b = canon(lg), canon(lo)
+        assert np.abs(a[:, :4] - b[:, :4]).max() < 1e-3       # endpoints (float32 in the reference's Line)
+        assert np.abs(a[:, 4:7] - b[:, 4:7]).max() < 1e-9     # line equation (double)
+        assert np.abs(a[:, 9] - b[:, 9]).max() < 1e-3
+    fe.close()
+
+
+@pytest.mark.gpu
+def test_gpu_edlines_parameters_and_degenerate_frames():
+    p = v.frontend.default_param()
+    p.minLineLen, p.lineFitErrThreshold, p.gradientThreshold = 20, 1.4, 50.0
+    rng = np.random.default_rng(3)
+    flat = np.full((480, 752), 9, np.uint8)
+    noise = rng.integers(0, 255, (480, 752), dtype=np.uint8)
+    imgs = np.stack([IMGS[0], flat, noise])
+    fe = v.frontend.FrontendContext(device=0, max_images=3, width=752, height=480, max_lines=2048)
+    out = fe.detect_batch(imgs, p)
+    assert len(out[1]) == 0
+    for i in (0, 2):
+        lo = o.edlines(imgs[i], grad_th=50, min_len=20, fit_err=1.4)
+        assert len(out[i]) == len(lo)
+        if len(lo):
+            assert np.abs(canon(out[i])[:, 4:7] - canon(lo)[:, 4:7]).max() < 1e-9
+    fe.close()

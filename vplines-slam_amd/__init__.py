@@ -11,3 +11,4 @@ from .capi import (  # noqa: F401
 )
 from . import workload  # noqa: F401
 from . import shard  # noqa: F401
+from . import frontend  # noqa: F401

@@ -37,10 +37,7 @@ def build_hip(force=False, verbose=False):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
     deps.append(os.path.join(ROOT, "include", "vplines_ba.h"))
-    for extra in ("vplines_frontend.h",):
-        p = os.path.join(ROOT, "include", extra)
-        if os.path.exists(p):
-            deps.append(p)
+    deps.append(os.path.join(ROOT, "include", "vplines_frontend.h"))
     if not force and not _newer(HIP_LIB, deps):
         return HIP_LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
