@@ -1,5 +1,5 @@
 /*
- * vplines_frontend.h -- C ABI of the MI355X-native line front-end (EDLines extractor).
+ * vplines_frontend.h -- C ABI of the MI355X-native line front-end (EDLines extractor + KLT line matcher).
  *
  * Drop-in boundary for the line detector of multiplefish/VPLines-SLAM:
  *   int EDLineDetector::EDline(cv::Mat& image, std::vector<Line>& lines, bool smoothed)
@@ -67,6 +67,59 @@ int vpl_edlines_detect_batch(vpl_fe_ctx* ctx, int n_images, const uint8_t* image
 int vpl_edlines_debug_stage(vpl_fe_ctx* ctx, int img, int16_t* dx, int16_t* dy, int16_t* gImg, uint8_t* dirImg,
                             uint32_t* anchors, int* n_anchors, uint32_t* chain_x, uint32_t* chain_y, uint32_t* sId,
                             int* n_edges);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * KLT line matching.  Drop-in boundary:
+ *   bool LineMatching::Matching(img_ref, img_cur, lines_ref, lines_cur, line_ref_to_line_cur, K_ref, K_cur, T_cur_ref,
+ *                               illumination_adapt, topological_filter, ...)
+ *        line_matching/src/line_matching.h:21-33, line_matching.cpp:605-690
+ * as called by LineFeatureTracker::match_line_match (feature_tracker/src/line_feature_tracker.cpp:291-314) with
+ * K_ref = K_cur = T_cur_ref = NULL, illumination_adapt = true, topological_filter = true.  The KLT inside is
+ * KLT::calc2D (klt.cpp:491-628) with a 13x13 window, 4 pyramid levels, 30 iterations / eps 0.001, minEig 1e-4.
+ * Images are the frames uploaded with vpl_edlines_upload (a pair names two of them by index); lines are passed by the
+ * caller, as in the reference (they may have been filtered on the host after detection).
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* LineMatching ctor arguments (line_matching.h:14-18), the two Matching() flags, TopologicalFilter defaults (:45-47) */
+typedef struct vpl_match_param {
+  int step;                          /* 10 */
+  float closest_line_threshold;      /* 0.5 */
+  float line_matching_ratio;         /* 0.4 */
+  float line_distance_error_ratio;   /* 3 */
+  float klt_error_threshold;         /* 40 */
+  int illumination_adapt;            /* 1 in the tracker */
+  int topological_filter;            /* 1 in the tracker */
+  float topo_distance_threshold;     /* 15 */
+  float topo_length_tolerate_ratio;  /* 0.2 */
+  float topo_violation_ratio;        /* 0.05 */
+} vpl_match_param;
+
+void vpl_match_default_param(vpl_match_param* p);
+
+/* device buffers for up to max_pairs pairs, max_kps key points per pair (Anchors() output, ~ sum(len/step + 2)) */
+int vpl_match_reserve(vpl_fe_ctx* ctx, int max_pairs, int max_kps);
+
+/* three-phase form.  lines_ref / lines_cur: [n_pairs][max_lines_per_image] (the stride given to vpl_fe_create). */
+int vpl_match_upload(vpl_fe_ctx* ctx, int n_pairs, const int* ref_image, const int* cur_image,
+                     const vpl_line* lines_ref, const int* n_ref, const vpl_line* lines_cur, const int* n_cur);
+int vpl_match_run(vpl_fe_ctx* ctx, const vpl_match_param* param);   /* enqueue; asynchronous */
+/* line_ref_to_line_cur [n_pairs][max_lines] (-1 = unmatched; rows of pairs with matched == 0 are left untouched, as
+ * Matching() leaves its output vector when it returns false); matched [n_pairs] = Matching()'s return value.
+ * VPL_E_CAPACITY if a pair produced more key points than max_kps. */
+int vpl_match_download(vpl_fe_ctx* ctx, int n_pairs, int* line_ref_to_line_cur, int* matched);
+
+/* Matching() for a batch of pairs: images [n_images][H][W] are uploaded, then upload + run + synchronize + download */
+int vpl_line_match_batch(vpl_fe_ctx* ctx, int n_images, const uint8_t* images, int n_pairs, const int* ref_image,
+                         const int* cur_image, const vpl_line* lines_ref, const int* n_ref, const vpl_line* lines_cur,
+                         const int* n_cur, const vpl_match_param* param, int* line_ref_to_line_cur, int* matched);
+
+/* test access (any pointer may be NULL): key points of pair `pair` of the last run (LineMatching::getPointMatchResult,
+ * line_matching.h:60-65): kps_ref, kps_cur [2*n_kps], status, err, kp2line_cur [n_kps] */
+int vpl_match_debug_kps(vpl_fe_ctx* ctx, int pair, int cap, float* kps_ref, float* kps_cur, uint8_t* status, float* err,
+                        int* kp2line_cur, int* n_kps);
+/* pyramid level `level` of image `img` without its border: pixels [h*w], derivative [h*w*2]; *w, *h; returns
+ * VPL_E_INVALID for a level that was not built */
+int vpl_match_debug_level(vpl_fe_ctx* ctx, int img, int level, uint8_t* pixels, int16_t* deriv, int* w, int* h);
 
 #ifdef __cplusplus
 }

@@ -194,3 +194,77 @@ def edlines(img, grad_th=30, anchor_th=5, scan=2, min_len=35, fit_err=1.8, want_
     npx = int(sid[ne])
     return lines, dict(dx=dx.reshape(H, W), dy=dy.reshape(H, W), g=g.reshape(H, W), dir=d.reshape(H, W),
                        anchors=anchors[:nA.value], chain_x=cx[:npx], chain_y=cy[:npx], sid=sid[:ne + 1])
+
+
+# ---- line front-end (KLT line matching) -----------------------------------------------------------------
+class LMLine(C.Structure):
+    _fields_ = [("endpoint", C.c_float * 4), ("equation", C.c_double * 3), ("center", C.c_float * 2),
+                ("length", C.c_float)]
+
+
+class LMParam(C.Structure):
+    _fields_ = [("step", C.c_int), ("closest_line_threshold", C.c_float), ("line_matching_ratio", C.c_float),
+                ("line_distance_error_ratio", C.c_float), ("klt_error_threshold", C.c_float),
+                ("illumination_adapt", C.c_int), ("topological_filter", C.c_int),
+                ("topo_distance_threshold", C.c_float), ("topo_length_tolerate_ratio", C.c_float),
+                ("topo_violation_ratio", C.c_float)]
+
+
+def lm_default_param(illumination_adapt=True, topological_filter=True):
+    """LineMatching() defaults (line_matching.h:14-18,45-47) and the tracker's flags (line_feature_tracker.cpp:307-308)"""
+    return LMParam(10, 0.5, 0.4, 3.0, 40.0, int(illumination_adapt), int(topological_filter), 15.0, 0.2, 0.05)
+
+
+def lines_to_struct(lines10):
+    """[n,10] doubles (x1,y1,x2,y2,eq0..2,cx,cy,len) -> array of LMLine"""
+    n = len(lines10)
+    arr = (LMLine * max(n, 1))()
+    for i in range(n):
+        r = lines10[i]
+        arr[i].endpoint[:] = [float(v) for v in r[0:4]]
+        arr[i].equation[:] = [float(v) for v in r[4:7]]
+        arr[i].center[:] = [float(v) for v in r[7:9]]
+        arr[i].length = float(r[9])
+    return arr
+
+
+def pyr_down(img):
+    lib = load()
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    out = np.zeros(((H + 1) // 2, (W + 1) // 2), np.uint8)
+    lib.orc_lm_pyr_down(img.ctypes.data_as(C.c_void_p), W, H, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def scharr(img):
+    lib = load()
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    out = np.zeros((H, W, 2), np.int16)
+    lib.orc_lm_scharr(img.ctypes.data_as(C.c_void_p), W, H, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def line_match(img_ref, img_cur, lines_ref, lines_cur, prm=None, cap_kps=65536):
+    """LineMatching::Matching. lines_*: [n,10]. Returns (ok, ref_to_cur[n_ref], dict of key-point stage outputs)."""
+    lib = load()
+    prm = prm or lm_default_param()
+    img_ref = np.ascontiguousarray(img_ref, np.uint8)
+    img_cur = np.ascontiguousarray(img_cur, np.uint8)
+    H, W = img_ref.shape
+    lr, lc = lines_to_struct(lines_ref), lines_to_struct(lines_cur)
+    r2c = np.full(max(len(lines_ref), 1), -2, np.int32)
+    nk = C.c_int(0)
+    kr = np.zeros((cap_kps, 2), np.float32); kc = np.zeros((cap_kps, 2), np.float32)
+    st = np.zeros(cap_kps, np.uint8); er = np.zeros(cap_kps, np.float32); k2l = np.zeros(cap_kps, np.int32)
+    vp = C.c_void_p
+    lib.orc_line_match.restype = C.c_int
+    lib.orc_line_match.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.POINTER(LMParam), vp, C.c_int,
+                                   C.POINTER(C.c_int), vp, vp, vp, vp, vp]
+    ok = lib.orc_line_match(img_ref.ctypes.data, img_cur.ctypes.data, W, H, C.addressof(lr), len(lines_ref),
+                            C.addressof(lc), len(lines_cur), C.byref(prm), r2c.ctypes.data, cap_kps, C.byref(nk),
+                            kr.ctypes.data, kc.ctypes.data, st.ctypes.data, er.ctypes.data, k2l.ctypes.data)
+    n = min(nk.value, cap_kps)
+    return bool(ok), r2c[:len(lines_ref)], dict(kps_ref=kr[:n], kps_cur=kc[:n], status=st[:n], err=er[:n],
+                                                kp2line_cur=k2l[:n])

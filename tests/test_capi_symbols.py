@@ -1,5 +1,5 @@
 """The C-ABI shared library loads and exports every function include/vplines_ba.h declares
-(no compute calls: this runs without a GPU)."""
+and include/vplines_frontend.h declare (no compute calls: this runs without a GPU)."""
 import ctypes as C
 import os
 import re
@@ -20,6 +20,10 @@ def test_library_exports_every_declared_symbol():
     names = declared_functions(os.path.join(ROOT, "include", "vplines_ba.h"))
     assert len(names) >= 20
     for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    fe = declared_functions(os.path.join(ROOT, "include", "vplines_frontend.h"))
+    assert len(fe) >= 18
+    for n in fe:
         assert hasattr(lib, n), "missing export: " + n
 
 

@@ -1,4 +1,4 @@
-// C ABI of the MI355X-native line front-end (include/vplines_frontend.h): EDLines extractor.
+// C ABI of the MI355X-native line front-end (include/vplines_frontend.h): EDLines extractor + KLT line matcher.
 // No CPU compute path: every call that computes launches HIP kernels or returns an error code.
 #include <hip/hip_runtime.h>
 
@@ -10,6 +10,7 @@
 #include "vplines_ba.h"        // VPL_E_* codes
 #include "vplines_frontend.h"
 #include "ed_kernels.h"
+#include "lm_kernels.h"
 
 using namespace vpl;
 
@@ -19,6 +20,11 @@ struct vpl_fe_ctx {
   int maxN = 0, W = 0, H = 0, maxLines = 0;
   int n = 0;
   EdBatch B;
+  LmBatch M;
+  int maxPairs = 0, nPairs = 0;
+  bool lmReserved = false, lmAttr = false;
+  int *d_refImg = nullptr, *d_curImg = nullptr, *d_nRef = nullptr, *d_nCur = nullptr;
+  vpl_line *d_linesRef = nullptr, *d_linesCur = nullptr;
   std::vector<void*> allocs;
   std::string err;
 };
@@ -196,6 +202,171 @@ int vpl_edlines_debug_stage(vpl_fe_ctx* c, int img, int16_t* dx, int16_t* dy, in
     FECHK(c, hipMemcpy(chain_x, B.cX + (size_t)img * 2 * B.cap, npx * 4, hipMemcpyDeviceToHost));
     FECHK(c, hipMemcpy(chain_y, B.cY + (size_t)img * 2 * B.cap, npx * 4, hipMemcpyDeviceToHost));
   }
+  return VPL_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// KLT line matching
+// ---------------------------------------------------------------------------------------------------------------
+void vpl_match_default_param(vpl_match_param* p) {
+  p->step = 10; p->closest_line_threshold = 0.5f; p->line_matching_ratio = 0.4f; p->line_distance_error_ratio = 3.f;
+  p->klt_error_threshold = 40.f; p->illumination_adapt = 1; p->topological_filter = 1;
+  p->topo_distance_threshold = 15.f; p->topo_length_tolerate_ratio = 0.2f; p->topo_violation_ratio = 0.05f;
+}
+
+int vpl_match_reserve(vpl_fe_ctx* c, int max_pairs, int max_kps) {
+  if (!c || max_pairs < 1 || max_kps < 1) return VPL_E_INVALID;
+  if (c->lmReserved) return fe_fail(c, VPL_E_INVALID, "vpl_match_reserve called twice");
+  if (c->W <= LM_WIN || c->H <= LM_WIN) return fe_fail(c, VPL_E_INVALID, "image smaller than the KLT window");
+  FECHK(c, hipSetDevice(c->device));
+  LmBatch& M = c->M;
+  std::memset(&M, 0, sizeof(M));
+  M.W = c->W; M.H = c->H; M.img = c->B.img;
+  // buildOpticalFlowPyramid: halve until maxLevel or until the next level would not exceed the window
+  int w = c->W, h = c->H, l = 0;
+  size_t off = 0;
+  for (;;) {
+    M.lw[l] = w; M.lh[l] = h; M.ls[l] = w + 2 * LM_WIN; M.loff[l] = off;
+    off += (size_t)(w + 2 * LM_WIN) * (h + 2 * LM_WIN);
+    off = (off + 63) & ~(size_t)63;
+    if (l == LM_LEVELS - 1) break;
+    const int nw = (w + 1) / 2, nh = (h + 1) / 2;
+    if (nw <= LM_WIN || nh <= LM_WIN) break;
+    w = nw; h = nh; ++l;
+  }
+  M.nLevels = l + 1;
+  M.pyrSize = off;
+  M.maxLines = c->maxLines; M.maxK = max_kps;
+  c->maxPairs = max_pairs;
+  const size_t N = c->maxN, P = max_pairs, ML = c->maxLines, MK = max_kps;
+  hipError_t e = hipSuccess;
+#define AL(ptr, n) if (e == hipSuccess) e = fe_alloc(c, &ptr, (size_t)(n))
+  AL(M.pyr, N * M.pyrSize); AL(M.der, N * M.pyrSize * 2);
+  AL(c->d_refImg, P); AL(c->d_curImg, P); AL(c->d_nRef, P); AL(c->d_nCur, P);
+  AL(c->d_linesRef, P * ML); AL(c->d_linesCur, P * ML);
+  AL(M.kpsRef, P * MK); AL(M.kpsCur, P * MK); AL(M.status, P * MK); AL(M.err, P * MK); AL(M.kp2lineCur, P * MK);
+  AL(M.kpOff, P * ML); AL(M.kpNum, P * ML); AL(M.nK, P); AL(M.r2c, P * ML); AL(M.valid, P);
+#undef AL
+  if (e != hipSuccess) return fe_fail(c, VPL_E_HIP, std::string("vpl_match_reserve: ") + hipGetErrorString(e));
+  M.refImg = c->d_refImg; M.curImg = c->d_curImg; M.nRef = c->d_nRef; M.nCur = c->d_nCur;
+  M.linesRef = c->d_linesRef; M.linesCur = c->d_linesCur;
+  if (!c->lmAttr) {
+    FECHK(c, hipFuncSetAttribute((const void*)k_lm_klt, hipFuncAttributeMaxDynamicSharedMemorySize, LM_KLT_SMEM));
+    c->lmAttr = true;
+  }
+  c->lmReserved = true;
+  return VPL_OK;
+}
+
+int vpl_match_upload(vpl_fe_ctx* c, int n_pairs, const int* ref_image, const int* cur_image, const vpl_line* lines_ref,
+                     const int* n_ref, const vpl_line* lines_cur, const int* n_cur) {
+  if (!c || !c->lmReserved || n_pairs < 1 || !ref_image || !cur_image || !lines_ref || !n_ref || !lines_cur || !n_cur)
+    return VPL_E_INVALID;
+  if (n_pairs > c->maxPairs) return fe_fail(c, VPL_E_CAPACITY, "more pairs than max_pairs");
+  if (c->n < 1) return fe_fail(c, VPL_E_INVALID, "no images uploaded");
+  for (int i = 0; i < n_pairs; ++i) {
+    if (ref_image[i] < 0 || ref_image[i] >= c->n || cur_image[i] < 0 || cur_image[i] >= c->n)
+      return fe_fail(c, VPL_E_INVALID, "pair names an image that was not uploaded");
+    if (n_ref[i] < 0 || n_ref[i] > c->maxLines || n_cur[i] < 0 || n_cur[i] > c->maxLines)
+      return fe_fail(c, VPL_E_CAPACITY, "more lines than max_lines_per_image");
+  }
+  FECHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t P = n_pairs, ML = c->maxLines;
+  FECHK(c, hipMemcpyAsync(c->d_refImg, ref_image, P * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_curImg, cur_image, P * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_nRef, n_ref, P * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_nCur, n_cur, P * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_linesRef, lines_ref, P * ML * sizeof(vpl_line), hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_linesCur, lines_cur, P * ML * sizeof(vpl_line), hipMemcpyHostToDevice, s));
+  FECHK(c, hipStreamSynchronize(s));   // the caller's buffers may be pageable and short-lived
+  c->nPairs = n_pairs;
+  return VPL_OK;
+}
+
+int vpl_match_run(vpl_fe_ctx* c, const vpl_match_param* p) {
+  if (!c || !p || !c->lmReserved || c->nPairs < 1) return VPL_E_INVALID;
+  if (p->step < 1) return fe_fail(c, VPL_E_INVALID, "bad LineMatching parameters");
+  FECHK(c, hipSetDevice(c->device));
+  LmBatch& M = c->M;
+  M.N = c->n; M.nPairs = c->nPairs; M.prm = *p;
+  double eps = std::min(std::max(0.001, 0.), 10.);   // TermCriteria(COUNT|EPS, 30, 0.001) through KLT::KLT, klt.cpp:28-33
+  M.epsilon = eps * eps;
+  hipStream_t s = c->stream;
+  auto blocks = [&](int l) { return (unsigned)(((size_t)M.ls[l] * (M.lh[l] + 2 * LM_WIN) + 255) / 256); };
+  hipLaunchKernelGGL(k_lm_level0, dim3(blocks(0), c->n), dim3(256), 0, s, M);
+  for (int l = 1; l < M.nLevels; ++l) hipLaunchKernelGGL(k_lm_down, dim3(blocks(l), c->n), dim3(256), 0, s, M, l);
+  hipLaunchKernelGGL(k_lm_scharr, dim3(blocks(0), c->n, M.nLevels), dim3(256), 0, s, M);
+  hipLaunchKernelGGL(k_lm_anchors, dim3(c->nPairs), dim3(256), 0, s, M);
+  hipLaunchKernelGGL(k_lm_klt, dim3((M.maxK + 63) / 64, c->nPairs), dim3(64), LM_KLT_SMEM, s, M);
+  hipLaunchKernelGGL(k_lm_vote, dim3(c->nPairs), dim3(256), (2 * M.maxLines + 1) * sizeof(int), s, M);
+  FECHK(c, hipGetLastError());
+  return VPL_OK;
+}
+
+int vpl_match_download(vpl_fe_ctx* c, int n_pairs, int* r2c, int* matched) {
+  if (!c || !c->lmReserved || n_pairs != c->nPairs || !r2c || !matched) return VPL_E_INVALID;
+  FECHK(c, hipSetDevice(c->device));
+  const size_t ML = c->maxLines;
+  std::vector<int> valid(n_pairs), nref(n_pairs), buf((size_t)n_pairs * ML);
+  FECHK(c, hipMemcpyAsync(valid.data(), c->M.valid, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipMemcpyAsync(nref.data(), c->d_nRef, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipMemcpyAsync(buf.data(), c->M.r2c, buf.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n_pairs; ++i)
+    if (valid[i] < 0) return fe_fail(c, VPL_E_CAPACITY, "pair " + std::to_string(i) + ": more key points than max_kps");
+  for (int i = 0; i < n_pairs; ++i) {
+    matched[i] = valid[i];
+    if (valid[i] == 1) std::memcpy(r2c + (size_t)i * ML, buf.data() + (size_t)i * ML, (size_t)nref[i] * 4);
+  }
+  return VPL_OK;
+}
+
+int vpl_line_match_batch(vpl_fe_ctx* c, int n_images, const uint8_t* images, int n_pairs, const int* ref_image,
+                         const int* cur_image, const vpl_line* lines_ref, const int* n_ref, const vpl_line* lines_cur,
+                         const int* n_cur, const vpl_match_param* param, int* r2c, int* matched) {
+  int rc = vpl_edlines_upload(c, n_images, images);
+  if (rc) return rc;
+  rc = vpl_match_upload(c, n_pairs, ref_image, cur_image, lines_ref, n_ref, lines_cur, n_cur);
+  if (rc) return rc;
+  rc = vpl_match_run(c, param);
+  if (rc) return rc;
+  rc = vpl_fe_synchronize(c);
+  if (rc) return rc;
+  return vpl_match_download(c, n_pairs, r2c, matched);
+}
+
+int vpl_match_debug_kps(vpl_fe_ctx* c, int pair, int cap, float* kps_ref, float* kps_cur, uint8_t* status, float* err,
+                        int* kp2line_cur, int* n_kps) {
+  if (!c || !c->lmReserved || pair < 0 || pair >= c->nPairs) return VPL_E_INVALID;
+  FECHK(c, hipSetDevice(c->device));
+  FECHK(c, hipStreamSynchronize(c->stream));
+  const LmBatch& M = c->M;
+  int nk = 0;
+  FECHK(c, hipMemcpy(&nk, M.nK + pair, 4, hipMemcpyDeviceToHost));
+  if (n_kps) *n_kps = nk;
+  const size_t m = (size_t)std::min(nk, cap), o = (size_t)pair * M.maxK;
+  if (m == 0) return VPL_OK;
+  if (kps_ref) FECHK(c, hipMemcpy(kps_ref, M.kpsRef + o, m * 8, hipMemcpyDeviceToHost));
+  if (kps_cur) FECHK(c, hipMemcpy(kps_cur, M.kpsCur + o, m * 8, hipMemcpyDeviceToHost));
+  if (status) FECHK(c, hipMemcpy(status, M.status + o, m, hipMemcpyDeviceToHost));
+  if (err) FECHK(c, hipMemcpy(err, M.err + o, m * 4, hipMemcpyDeviceToHost));
+  if (kp2line_cur) FECHK(c, hipMemcpy(kp2line_cur, M.kp2lineCur + o, m * 4, hipMemcpyDeviceToHost));
+  return VPL_OK;
+}
+
+int vpl_match_debug_level(vpl_fe_ctx* c, int img, int level, uint8_t* pixels, int16_t* deriv, int* w, int* h) {
+  if (!c || !c->lmReserved || img < 0 || img >= c->n || level < 0 || level >= c->M.nLevels) return VPL_E_INVALID;
+  FECHK(c, hipSetDevice(c->device));
+  FECHK(c, hipStreamSynchronize(c->stream));
+  const LmBatch& M = c->M;
+  const int lw = M.lw[level], lh = M.lh[level], S = M.ls[level];
+  if (w) *w = lw;
+  if (h) *h = lh;
+  const size_t base = (size_t)img * M.pyrSize + M.loff[level] + (size_t)LM_WIN * S + LM_WIN;
+  if (pixels) FECHK(c, hipMemcpy2D(pixels, lw, M.pyr + base, S, lw, lh, hipMemcpyDeviceToHost));
+  if (deriv) FECHK(c, hipMemcpy2D(deriv, (size_t)lw * 4, M.der + base * 2, (size_t)S * 4, (size_t)lw * 4, lh, hipMemcpyDeviceToHost));
   return VPL_OK;
 }
 

@@ -1,4 +1,4 @@
-"""ctypes binding of include/vplines_frontend.h (EDLines extractor on the GPU)."""
+"""ctypes binding of include/vplines_frontend.h (EDLines extractor + KLT line matcher on the GPU)."""
 import ctypes as C
 
 import numpy as np
@@ -15,6 +15,19 @@ class EdlineParam(C.Structure):
 class Line(C.Structure):
     _fields_ = [("line_endpoint", C.c_float * 4), ("line_equation", C.c_double * 3), ("center", C.c_float * 2),
                 ("length", C.c_float)]
+
+
+class MatchParam(C.Structure):
+    _fields_ = [("step", C.c_int), ("closest_line_threshold", C.c_float), ("line_matching_ratio", C.c_float),
+                ("line_distance_error_ratio", C.c_float), ("klt_error_threshold", C.c_float),
+                ("illumination_adapt", C.c_int), ("topological_filter", C.c_int),
+                ("topo_distance_threshold", C.c_float), ("topo_length_tolerate_ratio", C.c_float),
+                ("topo_violation_ratio", C.c_float)]
+
+
+def default_match_param(illumination_adapt=True, topological_filter=True):
+    """LineMatching() defaults (line_matching.h:14-18,45-47) with the tracker's flags (line_feature_tracker.cpp:307-308)"""
+    return MatchParam(10, 0.5, 0.4, 3.0, 40.0, int(illumination_adapt), int(topological_filter), 15.0, 0.2, 0.05)
 
 
 def default_param():
@@ -48,6 +61,16 @@ def _bind(lib):
                                              C.POINTER(C.c_int)]
     lib.vpl_edlines_debug_stage.argtypes = [vp, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_int)] + [C.c_void_p] * 3 + \
                                            [C.POINTER(C.c_int)]
+    ip = C.POINTER(C.c_int)
+    lib.vpl_match_default_param.argtypes = [C.POINTER(MatchParam)]
+    lib.vpl_match_reserve.argtypes = [vp, C.c_int, C.c_int]
+    lib.vpl_match_upload.argtypes = [vp, C.c_int, ip, ip, C.POINTER(Line), ip, C.POINTER(Line), ip]
+    lib.vpl_match_run.argtypes = [vp, C.POINTER(MatchParam)]
+    lib.vpl_match_download.argtypes = [vp, C.c_int, ip, ip]
+    lib.vpl_line_match_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8), C.c_int, ip, ip, C.POINTER(Line), ip,
+                                         C.POINTER(Line), ip, C.POINTER(MatchParam), ip, ip]
+    lib.vpl_match_debug_kps.argtypes = [vp, C.c_int, C.c_int] + [C.c_void_p] * 5 + [ip]
+    lib.vpl_match_debug_level.argtypes = [vp, C.c_int, C.c_int, C.c_void_p, C.c_void_p, ip, ip]
     _bound = True
 
 
@@ -131,3 +154,74 @@ class FrontendContext:
         npx = int(sid[ne])
         return dict(dx=dx.reshape(H, W), dy=dy.reshape(H, W), g=g.reshape(H, W), dir=d.reshape(H, W),
                     anchors=anchors[:nA.value], chain_x=cx[:npx], chain_y=cy[:npx], sid=sid[:ne + 1])
+
+    # ---- KLT line matching ---------------------------------------------------------------------------------
+    def match_reserve(self, max_pairs, max_kps=4096):
+        self.max_pairs, self.max_kps = max_pairs, max_kps
+        self._check(self.lib.vpl_match_reserve(self.h, max_pairs, max_kps), "vpl_match_reserve")
+
+    def _pack_lines(self, per_pair):
+        arr = (Line * (len(per_pair) * self.max_lines))()
+        cnt = (C.c_int * len(per_pair))()
+        for i, L in enumerate(per_pair):
+            cnt[i] = len(L)
+            if len(L) > self.max_lines:
+                continue   # the library reports VPL_E_CAPACITY
+            for k, r in enumerate(L):
+                ln = arr[i * self.max_lines + k]
+                ln.line_endpoint[:] = [float(x) for x in r[0:4]]
+                ln.line_equation[:] = [float(x) for x in r[4:7]]
+                ln.center[:] = [float(x) for x in r[7:9]]
+                ln.length = float(r[9])
+        return arr, cnt
+
+    def match_upload(self, pairs, lines_ref, lines_cur):
+        """pairs: list of (ref image index, cur image index); lines_*: per pair [n,10] arrays"""
+        self.n_pairs = len(pairs)
+        ri = (C.c_int * self.n_pairs)(*[p[0] for p in pairs])
+        ci = (C.c_int * self.n_pairs)(*[p[1] for p in pairs])
+        lr, nr = self._pack_lines(lines_ref)
+        lc, nc = self._pack_lines(lines_cur)
+        self._nref = [len(L) for L in lines_ref]
+        self._check(self.lib.vpl_match_upload(self.h, self.n_pairs, ri, ci, lr, nr, lc, nc), "vpl_match_upload")
+
+    def match_run(self, param=None):
+        self._mparam = param or default_match_param()
+        self._check(self.lib.vpl_match_run(self.h, C.byref(self._mparam)), "vpl_match_run")
+
+    def match_download(self):
+        r2c = (C.c_int * (self.n_pairs * self.max_lines))()
+        for i in range(len(r2c)):
+            r2c[i] = -2
+        ok = (C.c_int * self.n_pairs)()
+        self._check(self.lib.vpl_match_download(self.h, self.n_pairs, r2c, ok), "vpl_match_download")
+        a = np.ctypeslib.as_array(r2c).reshape(self.n_pairs, self.max_lines)
+        return [a[i, :self._nref[i]].copy() for i in range(self.n_pairs)], [int(x) for x in ok]
+
+    def match_batch(self, images, pairs, lines_ref, lines_cur, param=None):
+        self.upload(images)
+        self.match_upload(pairs, lines_ref, lines_cur)
+        self.match_run(param)
+        self.synchronize()
+        return self.match_download()
+
+    def match_debug_kps(self, pair):
+        cap = self.max_kps
+        kr = np.zeros((cap, 2), np.float32); kc = np.zeros((cap, 2), np.float32)
+        st = np.zeros(cap, np.uint8); er = np.zeros(cap, np.float32); k2l = np.zeros(cap, np.int32)
+        nk = C.c_int(0)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        self._check(self.lib.vpl_match_debug_kps(self.h, pair, cap, p(kr), p(kc), p(st), p(er), p(k2l), C.byref(nk)),
+                    "vpl_match_debug_kps")
+        n = nk.value
+        return dict(kps_ref=kr[:n], kps_cur=kc[:n], status=st[:n], err=er[:n], kp2line_cur=k2l[:n])
+
+    def match_debug_level(self, img, level):
+        w, h = C.c_int(0), C.c_int(0)
+        self._check(self.lib.vpl_match_debug_level(self.h, img, level, None, None, C.byref(w), C.byref(h)),
+                    "vpl_match_debug_level")
+        px = np.zeros((h.value, w.value), np.uint8); d = np.zeros((h.value, w.value, 2), np.int16)
+        self._check(self.lib.vpl_match_debug_level(self.h, img, level, C.c_void_p(px.ctypes.data),
+                                                   C.c_void_p(d.ctypes.data), C.byref(w), C.byref(h)),
+                    "vpl_match_debug_level")
+        return px, d
