@@ -3,10 +3,10 @@
 //   k_lm_scharr             : Scharr 3/10/3 derivative planes, zero border (klt.cpp:42-122, :613)
 //   k_lm_anchors            : LineMatching::Anchors (line_matching.cpp:532-602), one lane per reference line
 //   k_lm_klt                : pyramidal LK with per-iteration gain/bias (lk_tracker_invoker_2d.cpp:28-479), ONE LANE PER
-//                             KEY POINT, all four levels inside the lane; the 13x13 I / dI / J windows of the 64 lanes
-//                             of a wave live in LDS as [pixel][lane] int16 columns (no barrier: a lane only touches its
-//                             own column).  The float accumulations run in the reference's pixel order, so the tracked
-//                             positions are bit-identical to the CPU path.
+//                             KEY POINT, all four levels inside the lane; persistent waves pull chunks of 64 points.
+//                             The I/dI window of a lane is a coalesced [pixel][lane] column in global scratch, the J
+//                             window an LDS column.  The float accumulations run in the reference's pixel order, so
+//                             the tracked positions are bit-identical to the CPU path.
 //   k_lm_vote               : ClosestLine / Point2Line / TopologicalFilter (:48-133, :266-436), one workgroup per pair
 // Streaming kernels are HBM-bound; k_lm_klt is latency bound (byte gathers from L2-resident pyramids).
 #pragma once
@@ -21,7 +21,8 @@ constexpr int LM_WIN = 13;
 constexpr int LM_NPX = LM_WIN * LM_WIN;
 constexpr int LM_LEVELS = 4;      // maxLevel 3 (line_matching.cpp:14)
 constexpr int LM_MAXCOUNT = 30;
-constexpr int LM_KLT_SMEM = 4 * LM_NPX * 64 * 2;   // I, dIx, dIy, J windows of 64 lanes
+constexpr int LM_KLT_SMEM = LM_NPX * 64 * 2;       // J windows of the 64 lanes of a wave
+constexpr int LM_KLT_GRID = 256 * 7;              // persistent waves: 7 per CU fit the LDS
 
 struct LmBatch {
   int N, W, H;                 // images (shared with the EDLines batch)
@@ -44,6 +45,9 @@ struct LmBatch {
   int *kpOff, *kpNum;          // [P][maxLines]
   int* nK;                     // [P]
   int* r2c;                    // [P][maxLines]
+  int* chunkOff;               // [P+1] prefix of ceil(nK/64)
+  int* workCounter;            // [1]
+  uint2* winScratch;           // [LM_KLT_GRID][169][64]  I | dIx<<16 , dIy  per lane column
   int* valid;                  // [P]  1 matched, 0 Matching() returned false, -1 key-point capacity exceeded
   vpl_match_param prm;
   double epsilon;              // criteria_.epsilon^2 (klt.cpp:28-33)
@@ -160,23 +164,47 @@ __device__ __forceinline__ LmWeights lm_weights(float a, float b) {
   return w;
 }
 
-// bilinear J window (scaled x32) into the lane's LDS column; returns sum and sum of squares (exact integers)
+// 14 consecutive bytes of one window row from an arbitrarily aligned address: five aligned dword loads + v_alignbyte
+// (a byte gather per pixel costs one cache-line lookup per lane per byte; this is 5 lookups per 14 pixels)
+__device__ __forceinline__ void lm_load_row(const uint8_t* p, int (&v)[LM_WIN + 1]) {
+  const uintptr_t a = (uintptr_t)p;
+  const unsigned* q = (const unsigned*)(a & ~(uintptr_t)3);
+  const unsigned sh = (unsigned)(a & 3);
+  const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+  unsigned w[4];
+  w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+  w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+  w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+  w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+#pragma unroll
+  for (int x = 0; x <= LM_WIN; ++x) v[x] = (int)((w[x >> 2] >> ((x & 3) * 8)) & 255u);
+}
+
+// bilinear J window (scaled x32) into the lane's LDS column; returns sum and sum of squares (exact integers).
+// Row r contributes to window row r-1 as its lower neighbour and to row r as its upper one: one load per row.
 __device__ __forceinline__ void lm_sample_J(const uint8_t* Jp, int S, int ix, int iy, LmWeights w, short* Jw, int& sJ,
                                             long long& qJ) {
-  sJ = 0; qJ = 0;
+  sJ = 0;
+  unsigned long long q = 0;
+  const uint8_t* r = Jp + (size_t)(iy + LM_WIN) * S + (ix + LM_WIN);
+  int v[LM_WIN + 1], up[LM_WIN];
+  lm_load_row(r, v);
+#pragma unroll
+  for (int x = 0; x < LM_WIN; ++x) up[x] = v[x] * w.w00 + v[x + 1] * w.w01 + (1 << 8);
+#pragma unroll 1
   for (int y = 0; y < LM_WIN; ++y) {
-    const uint8_t* r = Jp + (size_t)(iy + y + LM_WIN) * S + (ix + LM_WIN);
-    int v00 = r[0], v10 = r[S];
+    r += S;
+    lm_load_row(r, v);
 #pragma unroll
     for (int x = 0; x < LM_WIN; ++x) {
-      const int v01 = r[x + 1], v11 = r[x + 1 + S];
-      const int v = (v00 * w.w00 + v01 * w.w01 + v10 * w.w10 + v11 * w.w11 + (1 << 8)) >> 9;
-      Jw[(y * LM_WIN + x) * 64] = (short)v;
-      sJ += v;
-      qJ += v * v;
-      v00 = v01; v10 = v11;
+      const int val = (up[x] + v[x] * w.w10 + v[x + 1] * w.w11) >> 9;
+      Jw[(y * LM_WIN + x) * 64] = (short)val;
+      sJ += val;
+      q += (unsigned)(val * val);
+      up[x] = v[x] * w.w00 + v[x + 1] * w.w01 + (1 << 8);
     }
   }
+  qJ = (long long)q;
 }
 
 // getImageNormParams (klt.cpp:4-10) from the integer moments of the two windows
@@ -189,128 +217,177 @@ __device__ __forceinline__ void lm_norm_params(int sI, long long qI, int sJ, lon
   beta = float(mI - alpha * mJ);
 }
 
+// chunk plan: 64 key points per wave, chunks of all pairs in one list (prefix over the pairs), work counter reset
+__global__ __launch_bounds__(64) void k_lm_plan(LmBatch B) {
+  if (threadIdx.x != 0) return;
+  int s = 0;
+  for (int p = 0; p < B.nPairs; ++p) {
+    B.chunkOff[p] = s;
+    s += (B.nK[p] + 63) >> 6;
+  }
+  B.chunkOff[B.nPairs] = s;
+  *B.workCounter = 0;
+}
+
+// Persistent waves: each takes chunks of 64 key points from the work counter.  Per lane: the I / dIx / dIy window of
+// the current level lives in a global scratch column (uint2 per pixel, [pixel][lane] => one coalesced 512-B access per
+// wave per pixel), the J window of the current iteration in LDS.
 __global__ __launch_bounds__(64) void k_lm_klt(LmBatch B) {
   extern __shared__ short lm_sm[];
-  const int p = blockIdx.y, lane = threadIdx.x;
-  const int idx = blockIdx.x * 64 + lane;
-  if (idx >= B.nK[p]) return;   // no barrier below: lanes are independent
-  short* Iw = lm_sm + lane;
-  short* dX = Iw + LM_NPX * 64;
-  short* dY = dX + LM_NPX * 64;
-  short* Jw = dY + LM_NPX * 64;
-  const uint8_t* pyrI = B.pyr + (size_t)B.refImg[p] * B.pyrSize;
-  const uint8_t* pyrJ = B.pyr + (size_t)B.curImg[p] * B.pyrSize;
-  const int16_t* derI = B.der + (size_t)B.refImg[p] * B.pyrSize * 2;
-  const float2 prev0 = B.kpsRef[(size_t)p * B.maxK + idx];
+  __shared__ int chunkS;
+  const int lane = threadIdx.x;
+  short* Jw = lm_sm + lane;
+  uint2* win = B.winScratch + (size_t)blockIdx.x * LM_NPX * 64 + lane;
   const bool illum = B.prm.illumination_adapt != 0;
   const float halfWin = (LM_WIN - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (1 << 20);
   const int maxLevel = B.nLevels - 1;
-  float outx = 0.f, outy = 0.f, errv = 0.f;
-  bool st = true;
+  const int totalChunks = B.chunkOff[B.nPairs];
 
-  for (int level = maxLevel; level >= 0; --level) {
-    const int S = B.ls[level], w = B.lw[level], h = B.lh[level];
-    const uint8_t* Ip = pyrI + B.loff[level];
-    const uint8_t* Jp = pyrJ + B.loff[level];
-    const int16_t* Dp = derI + B.loff[level] * 2;
-    const float lscale = (float)(1. / (1 << level));
-    float prevx = prev0.x * lscale, prevy = prev0.y * lscale;
-    float nx, ny;
-    if (level == maxLevel) { nx = prevx; ny = prevy; }
-    else { nx = outx * 2.f; ny = outy * 2.f; }
-    outx = nx; outy = ny;
-
-    prevx -= halfWin; prevy -= halfWin;
-    const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
-    if (ipx < -LM_WIN || ipx >= w || ipy < -LM_WIN || ipy >= h) {
-      if (level == 0) { st = false; errv = 0.f; }
-      continue;
+  for (;;) {
+    __syncthreads();
+    if (lane == 0) chunkS = atomicAdd(B.workCounter, 1);
+    __syncthreads();
+    const int chunk = chunkS;
+    if (chunk >= totalChunks) return;
+    int lo = 0, hi = B.nPairs - 1;          // last pair whose first chunk is <= chunk
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (B.chunkOff[mid] <= chunk) lo = mid; else hi = mid - 1;
     }
-    LmWeights wt = lm_weights(prevx - ipx, prevy - ipy);
-    float iA11 = 0, iA12 = 0, iA22 = 0;
-    int sI = 0;
-    long long qI = 0;
-    for (int y = 0; y < LM_WIN; ++y) {
-      const size_t o = (size_t)(ipy + y + LM_WIN) * S + (ipx + LM_WIN);
-      const uint8_t* r = Ip + o;
-      const int* d = (const int*)(Dp + o * 2);   // (dx, dy) pairs, 4-byte aligned
-      int v00 = r[0], v10 = r[S];
-      int e00 = d[0], e10 = d[S];
-      for (int x = 0; x < LM_WIN; ++x) {
-        const int v01 = r[x + 1], v11 = r[x + 1 + S];
-        const int e01 = d[x + 1], e11 = d[x + 1 + S];
-        const int ival = (v00 * wt.w00 + v01 * wt.w01 + v10 * wt.w10 + v11 * wt.w11 + (1 << 8)) >> 9;
-        const int ixval = ((short)e00 * wt.w00 + (short)e01 * wt.w01 + (short)e10 * wt.w10 + (short)e11 * wt.w11 + (1 << 13)) >> 14;
-        const int iyval = ((e00 >> 16) * wt.w00 + (e01 >> 16) * wt.w01 + (e10 >> 16) * wt.w10 + (e11 >> 16) * wt.w11 + (1 << 13)) >> 14;
-        const int k = (y * LM_WIN + x) * 64;
-        Iw[k] = (short)ival;
-        dX[k] = (short)ixval;
-        dY[k] = (short)iyval;
-        sI += ival;
-        qI += ival * ival;
-        iA11 += (float)(ixval * ixval);
-        iA12 += (float)(ixval * iyval);
-        iA22 += (float)(iyval * iyval);
-        v00 = v01; v10 = v11; e00 = e01; e10 = e11;
+    const int p = lo;
+    const int idx = (chunk - B.chunkOff[p]) * 64 + lane;
+    if (idx < B.nK[p]) {                    // (lanes past the end of a ragged chunk idle until the next chunk)
+
+    const uint8_t* pyrI = B.pyr + (size_t)B.refImg[p] * B.pyrSize;
+    const uint8_t* pyrJ = B.pyr + (size_t)B.curImg[p] * B.pyrSize;
+    const int16_t* derI = B.der + (size_t)B.refImg[p] * B.pyrSize * 2;
+    const float2 prev0 = B.kpsRef[(size_t)p * B.maxK + idx];
+    float outx = 0.f, outy = 0.f, errv = 0.f;
+    bool st = true;
+
+    for (int level = maxLevel; level >= 0; --level) {
+      const int S = B.ls[level], w = B.lw[level], h = B.lh[level];
+      const uint8_t* Ip = pyrI + B.loff[level];
+      const uint8_t* Jp = pyrJ + B.loff[level];
+      const int16_t* Dp = derI + B.loff[level] * 2;
+      const float lscale = (float)(1. / (1 << level));
+      float prevx = prev0.x * lscale, prevy = prev0.y * lscale;
+      float nx, ny;
+      if (level == maxLevel) { nx = prevx; ny = prevy; }
+      else { nx = outx * 2.f; ny = outy * 2.f; }
+      outx = nx; outy = ny;
+
+      prevx -= halfWin; prevy -= halfWin;
+      const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
+      if (ipx < -LM_WIN || ipx >= w || ipy < -LM_WIN || ipy >= h) {
+        if (level == 0) { st = false; errv = 0.f; }
+        continue;
       }
-    }
-    const float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
-    float D = A11 * A22 - A12 * A12;
-    const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * LM_WIN * LM_WIN);
-    if (minEig < 1e-4f || D < 1.1920928955078125e-07f) {
-      if (level == 0) st = false;
-      continue;
-    }
-    D = 1.f / D;
-    nx -= halfWin; ny -= halfWin;
-    float pdx = 0, pdy = 0;
-    int j;
-    for (j = 0; j < LM_MAXCOUNT; ++j) {
-      const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-      if (inx < -halfWin || inx >= w || iny < -halfWin || iny >= h) {
+      const LmWeights wt = lm_weights(prevx - ipx, prevy - ipy);
+      float iA11 = 0, iA12 = 0, iA22 = 0;
+      int sI = 0;
+      unsigned long long qIu = 0;
+      {
+        const size_t o = (size_t)(ipy + LM_WIN) * S + (ipx + LM_WIN);
+        const uint8_t* r = Ip + o;
+        const int* d = (const int*)(Dp + o * 2);   // (dx, dy) pairs, 4-byte aligned
+        int v[LM_WIN + 1], up[LM_WIN], e[LM_WIN + 1], upx[LM_WIN], upy[LM_WIN];
+        lm_load_row(r, v);
+#pragma unroll
+        for (int x = 0; x <= LM_WIN; ++x) e[x] = d[x];
+#pragma unroll
+        for (int x = 0; x < LM_WIN; ++x) {
+          up[x] = v[x] * wt.w00 + v[x + 1] * wt.w01 + (1 << 8);
+          upx[x] = (short)e[x] * wt.w00 + (short)e[x + 1] * wt.w01 + (1 << 13);
+          upy[x] = (e[x] >> 16) * wt.w00 + (e[x + 1] >> 16) * wt.w01 + (1 << 13);
+        }
+#pragma unroll 1
+        for (int y = 0; y < LM_WIN; ++y) {
+          r += S; d += S;
+          lm_load_row(r, v);
+#pragma unroll
+          for (int x = 0; x <= LM_WIN; ++x) e[x] = d[x];
+#pragma unroll
+          for (int x = 0; x < LM_WIN; ++x) {
+            const int ival = (up[x] + v[x] * wt.w10 + v[x + 1] * wt.w11) >> 9;
+            const int ixval = (upx[x] + (short)e[x] * wt.w10 + (short)e[x + 1] * wt.w11) >> 14;
+            const int iyval = (upy[x] + (e[x] >> 16) * wt.w10 + (e[x + 1] >> 16) * wt.w11) >> 14;
+            win[(size_t)(y * LM_WIN + x) * 64] = make_uint2((unsigned)(ival & 0xffff) | ((unsigned)ixval << 16), (unsigned)iyval);
+            sI += ival;
+            qIu += (unsigned)(ival * ival);
+            iA11 += (float)(ixval * ixval);
+            iA12 += (float)(ixval * iyval);
+            iA22 += (float)(iyval * iyval);
+            up[x] = v[x] * wt.w00 + v[x + 1] * wt.w01 + (1 << 8);
+            upx[x] = (short)e[x] * wt.w00 + (short)e[x + 1] * wt.w01 + (1 << 13);
+            upy[x] = (e[x] >> 16) * wt.w00 + (e[x + 1] >> 16) * wt.w01 + (1 << 13);
+          }
+        }
+      }
+      const long long qI = (long long)qIu;
+      const float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
+      float D = A11 * A22 - A12 * A12;
+      const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * LM_WIN * LM_WIN);
+      if (minEig < 1e-4f || D < 1.1920928955078125e-07f) {
         if (level == 0) st = false;
-        break;
+        continue;
       }
-      int sJ; long long qJ;
-      lm_sample_J(Jp, S, inx, iny, lm_weights(nx - inx, ny - iny), Jw, sJ, qJ);
-      float alpha = 1.0f, beta = 0.0f;
-      if (illum) lm_norm_params(sI, qI, sJ, qJ, alpha, beta);
-      float ib1 = 0, ib2 = 0;
-      for (int k = 0; k < LM_NPX * 64; k += 64) {
-        const float diff = alpha * (float)Jw[k] + beta - (float)Iw[k];
-        ib1 += diff * (float)dX[k];
-        ib2 += diff * (float)dY[k];
+      D = 1.f / D;
+      nx -= halfWin; ny -= halfWin;
+      float pdx = 0, pdy = 0;
+      int j;
+      for (j = 0; j < LM_MAXCOUNT; ++j) {
+        const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+        if (inx < -halfWin || inx >= w || iny < -halfWin || iny >= h) {
+          if (level == 0) st = false;
+          break;
+        }
+        int sJ; long long qJ;
+        lm_sample_J(Jp, S, inx, iny, lm_weights(nx - inx, ny - iny), Jw, sJ, qJ);
+        float alpha = 1.0f, beta = 0.0f;
+        if (illum) lm_norm_params(sI, qI, sJ, qJ, alpha, beta);
+        float ib1 = 0, ib2 = 0;
+#pragma unroll 13
+        for (int k = 0; k < LM_NPX; ++k) {
+          const uint2 t = win[(size_t)k * 64];
+          const float diff = alpha * (float)Jw[k * 64] + beta - (float)(int)(t.x & 0xffff);
+          ib1 += diff * (float)((int)t.x >> 16);
+          ib2 += diff * (float)(int)t.y;
+        }
+        const float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
+        const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+        nx += dx; ny += dy;
+        outx = nx + halfWin; outy = ny + halfWin;
+        if ((double)dx * dx + (double)dy * dy <= B.epsilon) break;
+        if (j > 0 && fabsf(dx + pdx) < 0.01 && fabsf(dy + pdy) < 0.01) {
+          outx -= dx * 0.5f; outy -= dy * 0.5f;
+          break;
+        }
+        pdx = dx; pdy = dy;
       }
-      const float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
-      const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
-      nx += dx; ny += dy;
-      outx = nx + halfWin; outy = ny + halfWin;
-      if ((double)dx * dx + (double)dy * dy <= B.epsilon) break;
-      if (j > 0 && fabsf(dx + pdx) < 0.01 && fabsf(dy + pdy) < 0.01) {
-        outx -= dx * 0.5f; outy -= dy * 0.5f;
-        break;
+      if (j == LM_MAXCOUNT && level == 0) st = false;
+      if (level == 0 && st) {
+        const float fx = outx - halfWin, fy = outy - halfWin;
+        const int ix = (int)floorf(fx), iy = (int)floorf(fy);
+        if (ix < -LM_WIN || ix >= w || iy < -LM_WIN || iy >= h) { st = false; continue; }
+        int sJ; long long qJ;
+        lm_sample_J(Jp, S, ix, iy, lm_weights(fx - ix, fy - iy), Jw, sJ, qJ);
+        float alpha = 1.0f, beta = 0.0f;
+        if (illum) lm_norm_params(sI, qI, sJ, qJ, alpha, beta);
+        float e = 0.f;
+#pragma unroll 13
+        for (int k = 0; k < LM_NPX; ++k)
+          e += fabsf(alpha * (float)Jw[k * 64] + beta - (float)(int)(win[(size_t)k * 64].x & 0xffff));
+        errv = e * 1.f / (32 * LM_WIN * LM_WIN);
       }
-      pdx = dx; pdy = dy;
     }
-    if (j == LM_MAXCOUNT && level == 0) st = false;
-    if (level == 0 && st) {
-      const float fx = outx - halfWin, fy = outy - halfWin;
-      const int ix = (int)floorf(fx), iy = (int)floorf(fy);
-      if (ix < -LM_WIN || ix >= w || iy < -LM_WIN || iy >= h) { st = false; continue; }
-      int sJ; long long qJ;
-      lm_sample_J(Jp, S, ix, iy, lm_weights(fx - ix, fy - iy), Jw, sJ, qJ);
-      float alpha = 1.0f, beta = 0.0f;
-      if (illum) lm_norm_params(sI, qI, sJ, qJ, alpha, beta);
-      float e = 0.f;
-      for (int k = 0; k < LM_NPX * 64; k += 64) e += fabsf(alpha * (float)Jw[k] + beta - (float)Iw[k]);
-      errv = e * 1.f / (32 * LM_WIN * LM_WIN);
+    const size_t o = (size_t)p * B.maxK + idx;
+    B.kpsCur[o] = make_float2(outx, outy);
+    B.status[o] = st ? 1 : 0;
+    B.err[o] = errv;
     }
   }
-  const size_t o = (size_t)p * B.maxK + idx;
-  B.kpsCur[o] = make_float2(outx, outy);
-  B.status[o] = st ? 1 : 0;
-  B.err[o] = errv;
 }
 
 // LineMatching::PointLineDistance :21-41

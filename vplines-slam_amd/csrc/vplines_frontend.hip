@@ -22,7 +22,7 @@ struct vpl_fe_ctx {
   EdBatch B;
   LmBatch M;
   int maxPairs = 0, nPairs = 0;
-  bool lmReserved = false, lmAttr = false;
+  bool lmReserved = false;
   int *d_refImg = nullptr, *d_curImg = nullptr, *d_nRef = nullptr, *d_nCur = nullptr;
   vpl_line *d_linesRef = nullptr, *d_linesCur = nullptr;
   std::vector<void*> allocs;
@@ -247,14 +247,11 @@ int vpl_match_reserve(vpl_fe_ctx* c, int max_pairs, int max_kps) {
   AL(c->d_linesRef, P * ML); AL(c->d_linesCur, P * ML);
   AL(M.kpsRef, P * MK); AL(M.kpsCur, P * MK); AL(M.status, P * MK); AL(M.err, P * MK); AL(M.kp2lineCur, P * MK);
   AL(M.kpOff, P * ML); AL(M.kpNum, P * ML); AL(M.nK, P); AL(M.r2c, P * ML); AL(M.valid, P);
+  AL(M.chunkOff, P + 1); AL(M.workCounter, 1); AL(M.winScratch, (size_t)LM_KLT_GRID * LM_NPX * 64);
 #undef AL
   if (e != hipSuccess) return fe_fail(c, VPL_E_HIP, std::string("vpl_match_reserve: ") + hipGetErrorString(e));
   M.refImg = c->d_refImg; M.curImg = c->d_curImg; M.nRef = c->d_nRef; M.nCur = c->d_nCur;
   M.linesRef = c->d_linesRef; M.linesCur = c->d_linesCur;
-  if (!c->lmAttr) {
-    FECHK(c, hipFuncSetAttribute((const void*)k_lm_klt, hipFuncAttributeMaxDynamicSharedMemorySize, LM_KLT_SMEM));
-    c->lmAttr = true;
-  }
   c->lmReserved = true;
   return VPL_OK;
 }
@@ -299,7 +296,8 @@ int vpl_match_run(vpl_fe_ctx* c, const vpl_match_param* p) {
   for (int l = 1; l < M.nLevels; ++l) hipLaunchKernelGGL(k_lm_down, dim3(blocks(l), c->n), dim3(256), 0, s, M, l);
   hipLaunchKernelGGL(k_lm_scharr, dim3(blocks(0), c->n, M.nLevels), dim3(256), 0, s, M);
   hipLaunchKernelGGL(k_lm_anchors, dim3(c->nPairs), dim3(256), 0, s, M);
-  hipLaunchKernelGGL(k_lm_klt, dim3((M.maxK + 63) / 64, c->nPairs), dim3(64), LM_KLT_SMEM, s, M);
+  hipLaunchKernelGGL(k_lm_plan, dim3(1), dim3(64), 0, s, M);
+  hipLaunchKernelGGL(k_lm_klt, dim3(LM_KLT_GRID), dim3(64), LM_KLT_SMEM, s, M);
   hipLaunchKernelGGL(k_lm_vote, dim3(c->nPairs), dim3(256), (2 * M.maxLines + 1) * sizeof(int), s, M);
   FECHK(c, hipGetLastError());
   return VPL_OK;
