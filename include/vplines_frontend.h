@@ -67,6 +67,8 @@ int vpl_edlines_detect_batch(vpl_fe_ctx* ctx, int n_images, const uint8_t* image
 int vpl_edlines_debug_stage(vpl_fe_ctx* ctx, int img, int16_t* dx, int16_t* dy, int16_t* gImg, uint8_t* dirImg,
                             uint32_t* anchors, int* n_anchors, uint32_t* chain_x, uint32_t* chain_y, uint32_t* sId,
                             int* n_edges);
+/* routing counters of image `img` of the last detect: steps walked, LDS tile loads, walks started, shader cycles */
+int vpl_edlines_debug_route_stats(vpl_fe_ctx* ctx, int img, unsigned long long* out4);
 
 /* ------------------------------------------------------------------------------------------------------------
  * KLT line matching.  Drop-in boundary:

@@ -36,6 +36,8 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     lines = fe.download()
+    rs = fe.route_stats(0)
+    na = len(fe.debug_stage(0)["anchors"])
     import oracle_api as o
     tc = time.perf_counter()
     ref = [o.edlines(imgs[i]) for i in range(16)]
@@ -45,7 +47,7 @@ def main():
     print(json.dumps({"metric": "EDLines frames/s (752x480, batch 64)", "value": n * steps / dt, "unit": "frames/s",
                       "ms_per_batch": 1e3 * dt / steps, "mean_lines_per_frame": float(np.mean([len(l) for l in lines])),
                       "gradient_stage_algorithmic_bytes_per_frame": px * 8,
-                      "cpu_oracle_frames_per_s_1thread": 16 / tc, "line_count_match_on_16_frames": same}))
+                      "cpu_oracle_frames_per_s_1thread": 16 / tc, "line_count_match_on_16_frames": same, "route_stats_frame0": rs, "anchors_frame0": na}))
     fe.close()
 
 if __name__ == "__main__":

@@ -2,8 +2,9 @@
 //   k_ed_grad   : Sobel 3x3 (BORDER_REFLECT_101) -> |dx|+|dy| -> threshold -> /4 (half-to-even) -> direction
 //                 (edline_detector.cpp:125-136); streaming, HBM-bound: 1 byte read, 7 bytes written per pixel
 //   k_ed_anchor : anchor test on the scan lattice + ORDERED compaction (w outer, h inner, :148-164)
+//   k_ed_code   : per-pixel routing byte (walkable, direction, arg-max forward neighbour for both senses of travel)
 //   k_ed_route  : smart routing (:166-707): inherently serial and order dependent per frame -> one wave per
-//                 frame, lane 0 walks, the wave copies accepted chains; throughput comes from the batch
+//                 frame; edge bitmap + a 128x128 tile of routing words in LDS; throughput comes from the batch
 //   k_ed_fit    : per edge chain least-squares fit / extension / Helmholtz validation (:729-1174), one lane per chain
 #pragma once
 #include <hip/hip_runtime.h>
@@ -20,7 +21,10 @@ struct EdBatch {
   double fitErr;
   const uint8_t* img;      // [N][H][W]
   int16_t *dx, *dy, *g;    // [N][H][W]
-  uint8_t *dir, *edge;     // [N][H][W]
+  uint8_t* dir;            // [N][H][W]
+  uint16_t* code;          // [N][H][Wc] routing words (k_ed_code)
+  int Wc;                  // W rounded up to the routing tile width (128)
+  unsigned long long* rstats; // [N][4] routing counters: steps, tile loads, walks, cycles (diagnostic)
   uint32_t *anchX, *anchY; // [N][cap]
   int* nAnch;              // [N]
   uint32_t *fX, *fY;       // [N][cap]  scratch: first part of the chain under construction
@@ -59,7 +63,6 @@ __global__ __launch_bounds__(256) void k_ed_grad(EdBatch B) {
   B.dy[o] = (int16_t)gy;
   B.g[o] = (int16_t)gq;
   B.dir[o] = ax < ay ? 255 : 0;
-  B.edge[o] = 0;
 }
 
 // one workgroup of 1024 per frame; thread t owns a contiguous slice of the scan order
@@ -103,65 +106,177 @@ __global__ __launch_bounds__(1024) void k_ed_anchor(EdBatch B) {
   if (tid == 1023) B.nAnch[n] = min(sc[1023], B.cap);
 }
 
-enum { ED_UP = 1, ED_RIGHT = 2, ED_DOWN = 3, ED_LEFT = 4 };
+// ---- smart routing ---------------------------------------------------------------------------------------
+// Everything the walk needs to know about a pixel is static once gImg/dirImg exist: whether it is walkable (g > 0), its
+// direction, and -- for each of the two senses of travel -- the move to the forward neighbour with the largest gradient
+// (compared as unsigned char, edline_detector.cpp:231-233) or that the image border stops the walk.  k_ed_code computes
+// that in parallel into one 16-bit word per pixel (row stride Wc = W rounded up to the tile width):
+//   bits 0-3 move when travelling forward (RIGHT on a horizontal pixel, DOWN on a vertical one): (dx+1) | (dy+1) << 2,
+//   bits 4-7 move when travelling backward (LEFT / UP); the "move" (0,0) = 5 means the border breaks the walk,
+//   bit 8 horizontal pixel, bit 9 walkable (g > 0)
+constexpr int ED_TILE = 128;
+constexpr int ED_STOP = 5;
+constexpr int ED_HORIZ = 1 << 8, ED_LIVE = 1 << 9;
 
-// one walk (the loop body that the reference repeats four times); lane 0 only
-__device__ int ed_walk(const int16_t* g, const uint8_t* dir, uint8_t* edge, int W, int H, unsigned x, unsigned y,
-                       int lastDirection, unsigned& lastX, unsigned& lastY, uint32_t* px, uint32_t* py, int n, int cap) {
-  int idx = y * W + x;
-  while (g[idx] > 0 && !edge[idx]) {
-    edge[idx] = 1;
-    if (n < cap) { px[n] = x; py[n] = y; }
-    ++n;
-    int shouldGo = 0;
-    if (dir[idx] == 255) {
-      if (lastDirection == ED_UP || lastDirection == ED_DOWN) shouldGo = x > lastX ? ED_RIGHT : ED_LEFT;
-      lastX = x; lastY = y;
-      if (lastDirection == ED_RIGHT || shouldGo == ED_RIGHT) {
-        if (x == (unsigned)W - 1 || y == 0 || y == (unsigned)H - 1) break;
-        const unsigned char g1 = (unsigned char)g[idx - W + 1], g2 = (unsigned char)g[idx + 1], g3 = (unsigned char)g[idx + W + 1];
-        if (g1 >= g2 && g1 >= g3) { x = x + 1; y = y - 1; }
-        else if (g3 >= g2 && g3 >= g1) { x = x + 1; y = y + 1; }
-        else x = x + 1;
-        lastDirection = ED_RIGHT;
-      } else if (lastDirection == ED_LEFT || shouldGo == ED_LEFT) {
-        if (x == 0 || y == 0 || y == (unsigned)H - 1) break;
-        const unsigned char g1 = (unsigned char)g[idx - W - 1], g2 = (unsigned char)g[idx - 1], g3 = (unsigned char)g[idx + W - 1];
-        if (g1 >= g2 && g1 >= g3) { x = x - 1; y = y - 1; }
-        else if (g3 >= g2 && g3 >= g1) { x = x - 1; y = y + 1; }
-        else x = x - 1;
-        lastDirection = ED_LEFT;
+__device__ __forceinline__ int ed_pick(int g1, int g2, int g3) {   // g1, g3 diagonals, g2 straight
+  g1 &= 255; g2 &= 255; g3 &= 255;
+  if (g1 >= g2 && g1 >= g3) return 0;
+  if (g3 >= g2 && g3 >= g1) return 1;
+  return 2;
+}
+__device__ __forceinline__ int ed_move(int dx, int dy) { return (dx + 1) | ((dy + 1) << 2); }
+
+__global__ __launch_bounds__(256) void k_ed_code(EdBatch B) {
+  const int n = blockIdx.y;
+  const int W = B.W, H = B.H;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W * H) return;
+  const int y = i / W, x = i - y * W;
+  const int16_t* g = B.g + (size_t)n * W * H;
+  const int gv = g[i];
+  int code = 0;
+  if (gv > 0) {
+    const bool horiz = B.dir[(size_t)n * W * H + i] == 255;
+    int f = ED_STOP, b = ED_STOP;
+    if (horiz) {
+      if (!(x == W - 1 || y == 0 || y == H - 1)) {   // RIGHT: (x+1,y-1) | (x+1,y+1) | (x+1,y)
+        const int c = ed_pick(g[i - W + 1], g[i + 1], g[i + W + 1]);
+        f = ed_move(1, c == 0 ? -1 : (c == 1 ? 1 : 0));
+      }
+      if (!(x == 0 || y == 0 || y == H - 1)) {       // LEFT: (x-1,y-1) | (x-1,y+1) | (x-1,y)
+        const int c = ed_pick(g[i - W - 1], g[i - 1], g[i + W - 1]);
+        b = ed_move(-1, c == 0 ? -1 : (c == 1 ? 1 : 0));
       }
     } else {
-      if (lastDirection == ED_RIGHT || lastDirection == ED_LEFT) shouldGo = y > lastY ? ED_DOWN : ED_UP;
-      lastX = x; lastY = y;
-      if (lastDirection == ED_DOWN || shouldGo == ED_DOWN) {
-        if (x == 0 || x == (unsigned)W - 1 || y == (unsigned)H - 1) break;
-        const unsigned char g1 = (unsigned char)g[idx + W + 1], g2 = (unsigned char)g[idx + W], g3 = (unsigned char)g[idx + W - 1];
-        if (g1 >= g2 && g1 >= g3) { x = x + 1; y = y + 1; }
-        else if (g3 >= g2 && g3 >= g1) { x = x - 1; y = y + 1; }
-        else y = y + 1;
-        lastDirection = ED_DOWN;
-      } else if (lastDirection == ED_UP || shouldGo == ED_UP) {
-        if (x == 0 || x == (unsigned)W - 1 || y == 0) break;
-        const unsigned char g1 = (unsigned char)g[idx - W + 1], g2 = (unsigned char)g[idx - W], g3 = (unsigned char)g[idx - W - 1];
-        if (g1 >= g2 && g1 >= g3) { x = x + 1; y = y - 1; }
-        else if (g3 >= g2 && g3 >= g1) { x = x - 1; y = y - 1; }
-        else y = y - 1;
-        lastDirection = ED_UP;
+      if (!(x == 0 || x == W - 1 || y == H - 1)) {   // DOWN: (x+1,y+1) | (x-1,y+1) | (x,y+1)
+        const int c = ed_pick(g[i + W + 1], g[i + W], g[i + W - 1]);
+        f = ed_move(c == 0 ? 1 : (c == 1 ? -1 : 0), 1);
+      }
+      if (!(x == 0 || x == W - 1 || y == 0)) {       // UP: (x+1,y-1) | (x-1,y-1) | (x,y-1)
+        const int c = ed_pick(g[i - W + 1], g[i - W], g[i - W - 1]);
+        b = ed_move(c == 0 ? 1 : (c == 1 ? -1 : 0), -1);
       }
     }
-    idx = y * W + x;
+    code = ED_LIVE | (horiz ? ED_HORIZ : 0) | f | (b << 4);
   }
+  B.code[((size_t)n * H + y) * B.Wc + x] = (uint16_t)code;
+}
+
+// Walk state shared by the whole wave: every lane computes the same (uniform) walk.
+// LDS: edge bitmap of the frame (1 bit / pixel) + a 128 x 128 tile of routing words around the walker, reloaded
+// cooperatively when the walker leaves it -- one global latency per ~80 steps instead of two per step.
+// The travel state is four bits S = lastWasHorizontal | lastWasForward << 1 | (x > lastX) << 2 | (y > lastY) << 3
+// (lastDirection / lastX / lastY of edline_detector.cpp:196-215 only ever enter through these predicates); whether the
+// walk goes forward on the current pixel is a 16-entry truth table per pixel type.
+struct EdWalker {
+  const uint16_t* code;  // frame's routing words
+  unsigned* bits;        // LDS edge bitmap
+  uint16_t* tile;        // LDS tile
+  unsigned* ring;        // LDS: the last <= 64 pixels of the current part (x | y << 16)
+  int W, H, Wc;
+  int tx0, ty0;          // tile origin; tx0 < 0 = nothing loaded
+  unsigned nSteps, nLoads, nWalks;
+};
+
+constexpr unsigned ed_truth(bool horizPixel) {
+  unsigned t = 0;
+  for (unsigned S = 0; S < 16; ++S) {
+    const bool ldH = S & 1, ldF = S & 2, gx = S & 4, gy = S & 8;
+    const bool F = horizPixel ? (ldH ? ldF : gx) : (ldH ? gy : ldF);
+    t |= (F ? 1u : 0u) << S;
+  }
+  return t;
+}
+constexpr unsigned ED_TRUTH = ed_truth(false) | (ed_truth(true) << 16);
+
+__device__ __forceinline__ void ed_tile_load(EdWalker& wk, int x, int y, unsigned S) {
+  int tx = x - ED_TILE / 2, ty = y - ED_TILE / 2;
+  if (S & 1) tx = (S & 2) ? x - 16 : x - (ED_TILE - 24);    // travelling RIGHT / LEFT (x stays inside after the rounding below)
+  else ty = (S & 2) ? y - 16 : y - (ED_TILE - 17);          // DOWN / UP
+  tx &= ~7;
+  tx = max(0, min(tx, wk.Wc - ED_TILE));
+  ty = max(0, min(ty, wk.H - ED_TILE));
+  // a tile row is 256 B = 16 lanes x 16 B: one instruction moves four rows; eight loads in flight per batch
+  const int lane = threadIdx.x, sub = lane >> 4, col = (lane & 15) * 8;
+  const uint16_t* src = wk.code + (size_t)(ty + sub) * wk.Wc + tx + col;
+  uint16_t* dst = wk.tile + sub * ED_TILE + col;
+#pragma unroll 1
+  for (int b = 0; b < ED_TILE / 32; ++b) {
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = ty + sub + 4 * (8 * b + k);
+      v[k] = row < wk.H ? *(const uint4*)(src + (size_t)4 * (8 * b + k) * wk.Wc) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *(uint4*)(dst + 4 * (8 * b + k) * ED_TILE) = v[k];
+  }
+  wk.tx0 = tx; wk.ty0 = ty;
+  ++wk.nLoads;
+  __syncthreads();
+}
+
+// EdgeDrawing's routing loops (edline_detector.cpp:191-647); returns the number of pixels of this part.
+// The pixels of the part go through a 64-entry LDS ring and are written 64 at a time; the tile bounds are only
+// re-examined when the walker may have reached the tile border (it moves one pixel per step).
+__device__ int ed_walk(EdWalker& wk, int x, int y, unsigned S, uint32_t* px, uint32_t* py, int cap) {
+  const int W = wk.W, lane = threadIdx.x;
+  int n = 0, safe = 0;
+  for (;;) {
+    if (safe == 0) {
+      if ((unsigned)(x - wk.tx0) >= (unsigned)ED_TILE || (unsigned)(y - wk.ty0) >= (unsigned)ED_TILE || wk.tx0 < 0)
+        ed_tile_load(wk, x, y, S);
+      const int rx = x - wk.tx0, ry = y - wk.ty0;
+      safe = min(min(rx, ED_TILE - 1 - rx), min(ry, ED_TILE - 1 - ry));   // steps that cannot leave the tile
+    } else {
+      --safe;
+    }
+    const int idx = __mul24(y, W) + x;
+    const unsigned w = wk.tile[(y - wk.ty0) * ED_TILE + (x - wk.tx0)];
+    const unsigned word = wk.bits[idx >> 5], bit = 1u << (idx & 31);
+    if (!(w & ED_LIVE) || (word & bit)) break;       // while (g > 0 && !edge)
+    if (lane == 0) {
+      wk.bits[idx >> 5] = word | bit;
+      wk.ring[n & 63] = (unsigned)x | ((unsigned)y << 16);
+    }
+    ++n;
+    if ((n & 63) == 0) {
+      const int o = n - 64 + lane;
+      const unsigned pxy = wk.ring[lane];
+      if (o < cap) { px[o] = pxy & 0xffff; py[o] = pxy >> 16; }
+    }
+    const unsigned h = (w >> 8) & 1;
+    const unsigned F = (ED_TRUTH >> (h * 16 + S)) & 1;
+    const unsigned mv = (w >> (F ? 0 : 4)) & 15;
+    if (mv == ED_STOP) break;
+    x += (int)(mv & 3) - 1;
+    y += (int)(mv >> 2) - 1;
+    S = h | (F << 1) | ((mv & 2) << 1) | (mv & 8);   // dx > 0 <=> (mv & 3) == 2, dy > 0 <=> (mv >> 2) == 2
+  }
+  if (n & 63) {
+    const int o = (n & ~63) + lane;
+    const unsigned pxy = wk.ring[lane];
+    if (lane < (n & 63) && o < cap) { px[o] = pxy & 0xffff; py[o] = pxy >> 16; }
+  }
+  wk.nSteps += n;
   return n;
 }
 
 __global__ __launch_bounds__(64) void k_ed_route(EdBatch B) {
+  extern __shared__ unsigned ed_sm[];
   const int n = blockIdx.x, lane = threadIdx.x;
   const int W = B.W, H = B.H;
-  const int16_t* g = B.g + (size_t)n * W * H;
-  const uint8_t* dir = B.dir + (size_t)n * W * H;
-  uint8_t* edge = B.edge + (size_t)n * W * H;
+  const int nWords = (W * H + 31) >> 5;
+  EdWalker wk;
+  wk.code = B.code + (size_t)n * H * B.Wc;
+  wk.bits = ed_sm;
+  wk.tile = (uint16_t*)(ed_sm + ((nWords + 3) & ~3));
+  wk.ring = (unsigned*)(wk.tile + ED_TILE * ED_TILE);
+  wk.W = W; wk.H = H; wk.Wc = B.Wc;
+  wk.tx0 = -1; wk.ty0 = 0;
+  wk.nSteps = wk.nLoads = wk.nWalks = 0;
+  const long long t0 = __builtin_readcyclecounter();
+  for (int k = lane; k < nWords; k += 64) wk.bits[k] = 0;
   const uint32_t* ax = B.anchX + (size_t)n * B.cap;
   const uint32_t* ay = B.anchY + (size_t)n * B.cap;
   uint32_t* fX = B.fX + (size_t)n * B.cap;
@@ -170,42 +285,47 @@ __global__ __launch_bounds__(64) void k_ed_route(EdBatch B) {
   uint32_t* cY = B.cY + (size_t)n * 2 * B.cap;
   uint32_t* sId = B.sId + (size_t)n * (B.capEdges + 2);
   const int nA = B.nAnch[n];
-  __shared__ int s_nf, s_ns, s_go;
-  unsigned lastX = 0, lastY = 0;
   int nC = 0, nE = 0;   // chain pixels written, edges accepted (uniform across the wave)
-  for (int i = 0; i < nA; ++i) {
-    if (lane == 0) {
-      const unsigned x = ax[i], y = ay[i];
+  __syncthreads();
+  for (int i0 = 0; i0 < nA; i0 += 64) {
+    // 64 anchors per trip: coordinates and routing word of the anchor pixel (its direction) in one latency
+    unsigned mx = 0, my = 0;
+    int mcode = 0;
+    if (i0 + lane < nA) {
+      mx = ax[i0 + lane]; my = ay[i0 + lane];
+      mcode = wk.code[(size_t)my * B.Wc + mx];
+    }
+    const int cnt = min(64, nA - i0);
+    for (int k = 0; k < cnt; ++k) {
+      const int x = __shfl((int)mx, k, 64), y = __shfl((int)my, k, 64);
+      const int code = __shfl(mcode, k, 64);
       const int idx = y * W + x;
-      int nf = 0, ns = 0, go = 0;
-      if (!edge[idx]) {
-        const bool horiz = dir[idx] == 255;
-        // first part into the scratch arrays, second part directly behind the slot of the (reversed) first part
-        nf = ed_walk(g, dir, edge, W, H, x, y, horiz ? ED_RIGHT : ED_DOWN, lastX, lastY, fX, fY, 0, B.cap);
-        edge[idx] = 0;
-        const int room = 2 * B.cap - nC - nf;
-        // second part: element 0 is the anchor again; it is written at slot nC + nf - 1 and overwritten... see copy below
-        ns = ed_walk(g, dir, edge, W, H, x, y, horiz ? ED_LEFT : ED_UP, lastX, lastY, cX + nC + nf - 1, cY + nC + nf - 1, 0,
-                     room > 0 ? room : 0);
-        go = (nf + ns >= B.minLineLen + 1 && nE < B.capEdges && nC + nf + ns - 1 <= 2 * B.cap && nf <= B.cap) ? 1 : 0;
+      if ((wk.bits[idx >> 5] >> (idx & 31)) & 1) continue;
+      const unsigned h = (code >> 8) & 1;
+      wk.nWalks += 2;
+      // first part (RIGHT / DOWN) into the scratch arrays, second part (LEFT / UP) directly behind the slot of the
+      // (reversed) first part: its element 0 is the anchor again
+      const int nf = ed_walk(wk, x, y, h | 2u, fX, fY, B.cap);
+      if (lane == 0) wk.bits[idx >> 5] &= ~(1u << (idx & 31));
+      const int room = 2 * B.cap - nC - nf;
+      const int ns = ed_walk(wk, x, y, h, cX + nC + nf - 1, cY + nC + nf - 1, room > 0 ? room : 0);
+      const bool go = nf + ns >= B.minLineLen + 1 && nE < B.capEdges && nC + nf + ns - 1 <= 2 * B.cap && nf <= B.cap;
+      if (go) {
+        // chain = reverse(first part) ++ second part without the anchor
+        __syncthreads();
+        for (int q = lane; q < nf; q += 64) { cX[nC + nf - 1 - q] = fX[q]; cY[nC + nf - 1 - q] = fY[q]; }
+        if (lane == 0) sId[nE] = nC;
+        nC += nf + ns - 1;
+        nE += 1;
+        __syncthreads();
       }
-      s_nf = nf; s_ns = ns; s_go = go;
     }
-    __syncthreads();
-    const int nf = s_nf, ns = s_ns, go = s_go;
-    if (go) {
-      // chain = reverse(first part) ++ second part without the anchor.  The second part already sits at
-      // [nC + nf - 1, ...) with its element 0 (the anchor) in the slot of the first part's element 0.
-      for (int k = lane; k < nf; k += 64) { cX[nC + nf - 1 - k] = fX[k]; cY[nC + nf - 1 - k] = fY[k]; }
-      if (lane == 0) sId[nE] = nC;
-      nC += nf + ns - 1;
-      nE += 1;
-    }
-    __syncthreads();
   }
   if (lane == 0) {
     sId[nE] = nC;
     B.nEdges[n] = nE;
+    unsigned long long* rs = B.rstats + (size_t)n * 4;
+    rs[0] = wk.nSteps; rs[1] = wk.nLoads; rs[2] = wk.nWalks; rs[3] = (unsigned long long)(__builtin_readcyclecounter() - t0);
   }
 }
 

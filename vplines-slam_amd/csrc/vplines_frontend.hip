@@ -19,6 +19,7 @@ struct vpl_fe_ctx {
   hipStream_t stream = nullptr;
   int maxN = 0, W = 0, H = 0, maxLines = 0;
   int n = 0;
+  size_t routeSmem = 0;
   EdBatch B;
   LmBatch M;
   int maxPairs = 0, nPairs = 0;
@@ -74,16 +75,23 @@ int vpl_fe_create(vpl_fe_ctx** out, int device, int max_images, int width, int h
   uint8_t* img = nullptr;
 #define AL(ptr, n) if (e == hipSuccess) e = fe_alloc(c, &ptr, (size_t)(n))
   AL(img, N * PX); B.img = img;
-  AL(B.dx, N * PX); AL(B.dy, N * PX); AL(B.g, N * PX); AL(B.dir, N * PX); AL(B.edge, N * PX);
+  AL(B.dx, N * PX); AL(B.dy, N * PX); AL(B.g, N * PX); AL(B.dir, N * PX);
+  B.Wc = (width + ED_TILE - 1) / ED_TILE * ED_TILE;
+  AL(B.code, N * (size_t)height * B.Wc); AL(B.rstats, N * 4);
   AL(B.anchX, N * B.cap); AL(B.anchY, N * B.cap); AL(B.nAnch, N);
   AL(B.fX, N * B.cap); AL(B.fY, N * B.cap); AL(B.cX, N * 2 * B.cap); AL(B.cY, N * 2 * B.cap);
   AL(B.sId, N * (B.capEdges + 2)); AL(B.nEdges, N);
   AL(B.lines, N * B.maxLines * 10); AL(B.lkey, N * B.maxLines); AL(B.nLines, N);
 #undef AL
+  // k_ed_route keeps the frame's edge bitmap and one tile of routing codes in LDS
+  c->routeSmem = (size_t)(((((size_t)width * height + 31) >> 5) + 3) & ~(size_t)3) * 4 + ED_TILE * ED_TILE * 2 + 64 * 4;
+  if (e == hipSuccess && c->routeSmem > 159 * 1024) e = hipErrorInvalidValue;   // frames above ~1.2 Mpixel
+  if (e == hipSuccess && c->routeSmem > 48 * 1024)
+    e = hipFuncSetAttribute((const void*)k_ed_route, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->routeSmem);
   if (e != hipSuccess) {
     for (void* p : c->allocs) hipFree(p);
     delete c;
-    return VPL_E_HIP;
+    return e == hipErrorInvalidValue ? VPL_E_CAPACITY : VPL_E_HIP;
   }
   *out = c;
   return VPL_OK;
@@ -126,7 +134,8 @@ int vpl_edlines_detect(vpl_fe_ctx* c, const vpl_edline_param* p) {
   FECHK(c, hipMemsetAsync(B.nLines, 0, c->n * sizeof(int), s));
   hipLaunchKernelGGL(k_ed_grad, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B);
   hipLaunchKernelGGL(k_ed_anchor, dim3(c->n), dim3(1024), 0, s, B);
-  hipLaunchKernelGGL(k_ed_route, dim3(c->n), dim3(64), 0, s, B);
+  hipLaunchKernelGGL(k_ed_code, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B);
+  hipLaunchKernelGGL(k_ed_route, dim3(c->n), dim3(64), c->routeSmem, s, B);
   hipLaunchKernelGGL(k_ed_fit, dim3((B.capEdges + 63) / 64, c->n), dim3(64), 0, s, B);
   FECHK(c, hipGetLastError());
   return VPL_OK;
@@ -205,6 +214,14 @@ int vpl_edlines_debug_stage(vpl_fe_ctx* c, int img, int16_t* dx, int16_t* dy, in
   return VPL_OK;
 }
 
+
+int vpl_edlines_debug_route_stats(vpl_fe_ctx* c, int img, unsigned long long* out4) {
+  if (!c || img < 0 || img >= c->n || !out4) return VPL_E_INVALID;
+  FECHK(c, hipSetDevice(c->device));
+  FECHK(c, hipStreamSynchronize(c->stream));
+  FECHK(c, hipMemcpy(out4, c->B.rstats + (size_t)img * 4, 32, hipMemcpyDeviceToHost));
+  return VPL_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // KLT line matching

@@ -62,6 +62,7 @@ def _bind(lib):
     lib.vpl_edlines_debug_stage.argtypes = [vp, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_int)] + [C.c_void_p] * 3 + \
                                            [C.POINTER(C.c_int)]
     ip = C.POINTER(C.c_int)
+    lib.vpl_edlines_debug_route_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong)]
     lib.vpl_match_default_param.argtypes = [C.POINTER(MatchParam)]
     lib.vpl_match_reserve.argtypes = [vp, C.c_int, C.c_int]
     lib.vpl_match_upload.argtypes = [vp, C.c_int, ip, ip, C.POINTER(Line), ip, C.POINTER(Line), ip]
@@ -154,6 +155,11 @@ class FrontendContext:
         npx = int(sid[ne])
         return dict(dx=dx.reshape(H, W), dy=dy.reshape(H, W), g=g.reshape(H, W), dir=d.reshape(H, W),
                     anchors=anchors[:nA.value], chain_x=cx[:npx], chain_y=cy[:npx], sid=sid[:ne + 1])
+
+    def route_stats(self, img):
+        out = (C.c_ulonglong * 4)()
+        self._check(self.lib.vpl_edlines_debug_route_stats(self.h, img, out), "vpl_edlines_debug_route_stats")
+        return dict(steps=out[0], tile_loads=out[1], walks=out[2], cycles=out[3])
 
     # ---- KLT line matching ---------------------------------------------------------------------------------
     def match_reserve(self, max_pairs, max_kps=4096):
