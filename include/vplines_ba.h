@@ -121,6 +121,7 @@ typedef struct vpl_window {
   const int* line_nobs;     /* [n_lines] */
   const double* line_obs;   /* [sum nobs][8] x1,y1,x2,y2, vp_x,vp_y,vp_z, vp_flag (estimator_node.cpp:375-407) */
   double* line_plk;         /* [n_lines][6] lineFeaturePerId::line_plucker, start-CAMERA frame (in/out) */
+  int* line_removed;        /* [n_lines] out, may be NULL: 1 = erased by removeLineOutlier (options.remove_line_outliers) */
 
   /* pre_integrations[1..10]; entry 0 unused (estimator.cpp:1085-1093) */
   vpl_preintegration preint[VPL_NFRAMES];

@@ -361,7 +361,16 @@ int solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_out,
   }
 
   e.double2vector2();
-  if (opt->remove_line_outliers) report.n_lines_removed = e.removeLineOutlier(nullptr);
+  if (opt->remove_line_outliers) {
+    std::vector<int> removed_index;
+    report.n_lines_removed = e.removeLineOutlier(&removed_index);
+    if (w->line_removed) {
+      for (int i = 0; i < w->n_lines; ++i) w->line_removed[i] = 0;
+      for (int i : removed_index) w->line_removed[i] = 1;
+    }
+  } else if (w->line_removed) {
+    for (int i = 0; i < w->n_lines; ++i) w->line_removed[i] = 0;
+  }
 
   if (opt->marginalization_flag == VPL_MARGIN_OLD) {
     MarginalizationInfo* marginalization_info = new MarginalizationInfo();
@@ -481,7 +490,9 @@ int solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_out,
       report.prior_n = marginalization_info->n;
       if (prior_out) export_prior(e, parameter_blocks, prior_out);
     } else if (prior_out) {
-      std::memset(prior_out, 0, sizeof(*prior_out));
+      // the reference keeps last_marginalization_info / _parameter_blocks as they are (estimator.cpp:1385)
+      if (w->has_prior && w->prior) { *prior_out = *w->prior; report.prior_n = w->prior->n; }
+      else std::memset(prior_out, 0, sizeof(*prior_out));
     }
   }
   delete loss_function;

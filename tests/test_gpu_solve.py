@@ -162,3 +162,130 @@ def test_marginalization_flag_none_and_reset(gpu_ctx):
     gpu_ctx.download()
     for a, w in zip(first, wg):
         assert np.abs(a - w.pose).max() < 1e-9   # re-solving from the uploaded state reproduces the result
+
+
+def _compare_prior(pg, pc):
+    assert pg.n == pc.n and pg.n_blocks == pc.n_blocks
+    nb = pc.n_blocks
+    assert list(pg.block_kind[:nb]) == list(pc.block_kind[:nb])
+    assert list(pg.block_frame[:nb]) == list(pc.block_frame[:nb])
+    assert list(pg.block_idx[:nb]) == list(pc.block_idx[:nb])
+    for b in range(nb):
+        assert np.abs(np.array(pg.x0[b][:]) - np.array(pc.x0[b][:])).max() < 1e-4
+    Jg, Jc = pg.J(), pc.J()
+    Ag, Ac = Jg.T @ Jg, Jc.T @ Jc
+    assert np.abs(Ag - Ac).max() <= 1e-5 * np.abs(Ac).max()
+    bg, bc = Jg.T @ pg.r(), Jc.T @ pc.r()
+    lam, V = np.linalg.eigh(0.5 * (Ac + Ac.T))
+    sig = V[:, lam > 1e-6 * lam[-1]]
+    assert np.abs(sig.T @ (bg - bc)).max() <= 1e-5 * max(1.0, np.abs(bc).max())
+
+
+def test_remove_line_outliers(gpu_ctx):
+    """FeatureManager::removeLineOutlier between the solve and the marginalisation: same lines erased, and the prior
+    is built without them.  Outliers are provoked by corrupting the observations of some tracks."""
+    ws, opt = make_windows(4, 150, 60, True, seed0=500)
+    rng = np.random.default_rng(7)
+    for w in ws:
+        nl = len(w.line_start)
+        off = np.concatenate([[0], np.cumsum(w.line_nobs)])
+        for l in rng.choice(nl, 8, replace=False):
+            k = off[l] + rng.integers(0, w.line_nobs[l])
+            w.line_obs[k, 0:4] += rng.normal(0, 0.05, 4)          # reprojection error far above 3/500
+        for l in rng.choice(nl, 3, replace=False):
+            w.line_plk[l, 3:6] *= -1.0                             # direction flipped: end points behind the camera
+    opt.remove_line_outliers = 1
+    wg = [w.copy() for w in ws]
+    wc = [w.copy() for w in ws]
+    pri_g, rep_g = gpu_ctx.solve_windows(wg, opt)
+    total = 0
+    for i in range(len(ws)):
+        pri_c, rep_c = o.solve_window(wc[i], opt)
+        assert rep_c.n_lines_removed == int(wc[i].line_removed.sum())
+        assert np.array_equal(wg[i].line_removed, wc[i].line_removed)
+        assert rep_g[i].n_lines_removed == rep_c.n_lines_removed
+        total += rep_c.n_lines_removed
+        dp, dr = pose_err(wg[i], wc[i])
+        assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)
+        assert rep_g[i].prior_m == rep_c.prior_m
+        _compare_prior(pri_g[i], pri_c)
+    assert total >= 8                                              # the test exercised the erase path
+    # erased lines change the kept-block table: the point tracks that start in frame 0 are cut to 3 observations (poses
+    # 1, 2), so the frame-0 lines are the only factors that bring poses 3..5 into the prior; all lines become outliers
+    ws2, opt2 = make_windows(2, 120, 6, False, seed0=520)
+    opt2.remove_line_outliers = 1
+    g, c = [], []
+    for w in ws2:
+        off = np.concatenate([[0], np.cumsum(w.point_nobs)])
+        nobs = np.where(w.point_start == 0, 3, w.point_nobs).astype(np.int32)
+        obs = np.concatenate([w.point_obs[off[i]:off[i] + nobs[i]] for i in range(len(nobs))])
+        w2 = v.capi.Window(w.pose, w.speed_bias, w.ex_pose, w.point_start, nobs, obs, w.inv_depth,
+                           w.line_start, w.line_nobs, w.line_obs, w.line_plk, w.preint, None)
+        w2.line_obs[:, 0:4] += 0.5
+        g.append(w2.copy())
+        c.append(w2.copy())
+    pg, rg = gpu_ctx.solve_windows(g, opt2)
+    for i in range(2):
+        pc, rc = o.solve_window(c[i], opt2)
+        assert rc.n_lines_removed == 6 and rg[i].n_lines_removed == 6
+        dp, dr = pose_err(g[i], c[i])
+        assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)
+        assert rc.prior_n == 27 and rg[i].prior_n == 27 and rg[i].prior_m == rc.prior_m
+        _compare_prior(pg[i], pc)
+    # the same windows without the erase step keep poses 0..4 (45 dims): the table really depends on the flags
+    opt2.remove_line_outliers = 0
+    pg, rg = gpu_ctx.solve_windows([w.copy() for w in g], opt2)
+    assert rg[0].prior_n == 45 and rg[0].n_lines_removed == 0
+
+
+def test_margin_second_new(gpu_ctx):
+    """MARGIN_SECOND_NEW (estimator.cpp:1380-1447): A (MARGIN_OLD) -> prior P1 -> B (SECOND_NEW) -> P2 without pose 9
+    -> C (SECOND_NEW again: P2 holds no pose[9], the prior passes through untouched)."""
+    opt = v.default_options()
+    cfg = v.workload.config(150, 40, True)
+    cfgA = v.workload.config(150, 40, True)
+    cfgA.track_len = 11                                            # tracks over the whole window: P1 holds poses 0..9
+    n = 3
+    A = [v.workload.generate(v.workload.seed_for(3, 600 + i), cfgA, 0.4 * i) for i in range(n)]
+    Bw = [v.workload.generate(v.workload.seed_for(3, 700 + i), cfg, 0.4 * i + cfg.kf_dt) for i in range(n)]
+    Cw = [v.workload.generate(v.workload.seed_for(3, 800 + i), cfg, 0.4 * i + 2 * cfg.kf_dt) for i in range(n)]
+    o.preintegrate_windows(A + Bw + Cw, opt)
+    P1 = [o.solve_window(a.copy(), opt)[0] for a in A]
+    opt.marginalization_flag = v.capi.MARGIN_SECOND_NEW
+    wg, wc = [], []
+    for i in range(n):
+        for lst in (wg, wc):
+            b = Bw[i].copy()
+            b.prior = P1[i]
+            lst.append(b)
+    pri_g, rep_g = gpu_ctx.solve_windows(wg, opt)
+    P2 = []
+    for i in range(n):
+        pri_c, rep_c = o.solve_window(wc[i], opt)
+        assert rep_g[i].iterations == rep_c.iterations
+        dp, dr = pose_err(wg[i], wc[i])
+        assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)
+        assert rep_c.prior_m == 6 and rep_g[i].prior_m == 6 and rep_g[i].prior_n == rep_c.prior_n == P1[i].n - 6
+        poses = [pri_c.block_frame[b] for b in range(pri_c.n_blocks) if pri_c.block_kind[b] == 0]
+        assert poses == list(range(9))                             # frame 9 marginalised, nothing shifted below it
+        _compare_prior(pri_g[i], pri_c)
+        P2.append(pri_c)
+    # second SECOND_NEW in a row: no pose[9] in the prior -> the prior is handed back unchanged
+    wg, wc = [], []
+    for i in range(n):
+        for lst in (wg, wc):
+            cwin = Cw[i].copy()
+            cwin.prior = P2[i]
+            lst.append(cwin)
+    pri_g, rep_g = gpu_ctx.solve_windows(wg, opt)
+    for i in range(n):
+        pri_c, rep_c = o.solve_window(wc[i], opt)
+        dp, dr = pose_err(wg[i], wc[i])
+        assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)
+        assert pri_c.n == P2[i].n and pri_g[i].n == P2[i].n
+        assert np.array_equal(pri_g[i].J(), P2[i].J()) and np.array_equal(pri_c.J(), P2[i].J())
+        assert np.array_equal(pri_g[i].r(), P2[i].r())
+    # without any prior SECOND_NEW produces none
+    wg = [Bw[0].copy()]
+    pri_g, rep_g = gpu_ctx.solve_windows(wg, opt)
+    assert pri_g[0].n == 0 and rep_g[0].prior_n == 0

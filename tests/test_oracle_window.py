@@ -73,3 +73,109 @@ def test_margin_second_new_drops_pose_nine():
     assert rep.prior_m == 6 and prior_b.n == prior_a.n - 6
     frames = [prior_b.block_frame[b] for b in range(prior_b.n_blocks) if prior_b.block_kind[b] == v.capi.BLOCK_POSE]
     assert 9 not in frames
+
+
+def test_margin_second_new_is_the_schur_complement_of_the_prior():
+    """estimator.cpp:1387-1405: the only factor is the old prior, whose Jacobian is the constant J0 -- the new
+    J0'^T J0' must be the Schur complement of J0^T J0 on the six dims of pose[WINDOW_SIZE-1]."""
+    opt = v.default_options()
+    cfgA = v.workload.config(100, 20, True)
+    cfgA.track_len = 11                        # tracks over the whole window: the prior holds poses 0..9
+    A = v.workload.generate(21, cfgA, 0.3)
+    cfg = v.workload.config(100, 20, True)
+    Bw = v.workload.generate(22, cfg, 0.3 + cfg.kf_dt)
+    Cw = v.workload.generate(23, cfg, 0.3 + 2 * cfg.kf_dt)
+    o.preintegrate_windows([A, Bw, Cw], opt)
+    P1, _ = o.solve_window(A, opt)
+    assert P1.n == 75
+    opt.marginalization_flag = v.capi.MARGIN_SECOND_NEW
+    Bw.prior = P1
+    P2, rep = o.solve_window(Bw, opt)
+    assert rep.prior_m == 6 and P2.n == 69
+    J1 = P1.J()
+    H = J1.T @ J1
+    i9 = [P1.block_idx[b] for b in range(P1.n_blocks) if P1.block_kind[b] == 0 and P1.block_frame[b] == 9][0]
+    m = np.arange(i9, i9 + 6)
+    r = np.array([k for k in range(P1.n) if k < i9 or k >= i9 + 6])
+    S = H[np.ix_(r, r)] - H[np.ix_(r, m)] @ np.linalg.pinv(H[np.ix_(m, m)]) @ H[np.ix_(m, r)]
+    J2 = P2.J()
+    lam = np.linalg.eigvalsh(0.5 * (S + S.T))
+    assert lam[0] > -1e-6 * lam[-1]
+    assert np.abs(J2.T @ J2 - S).max() <= 1e-6 * np.abs(S).max()
+    # kept blocks keep their frame index below 9 (estimator.cpp:1421-1437) and their linearisation point is the
+    # current state of window B
+    for b in range(P2.n_blocks):
+        if P2.block_kind[b] == 0:
+            assert np.abs(np.array(P2.x0[b][:7]) - Bw.pose[P2.block_frame[b]]).max() < 1e-12
+    # the next SECOND_NEW finds no pose[9] in the prior and hands it back untouched (estimator.cpp:1385)
+    Cw.prior = P2
+    P3, rep3 = o.solve_window(Cw, opt)
+    assert P3.n == P2.n and np.array_equal(P3.J(), P2.J()) and np.array_equal(P3.r(), P2.r())
+
+
+def _numpy_line_outlier(w, l):
+    """independent restatement of FeatureManager::removeLineOutlier for line l at the state held by Window w"""
+    def quat_R(p):
+        x, y, z, ww = p[3:7] / np.linalg.norm(p[3:7])
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * ww), 2 * (x * z + y * ww)],
+                         [2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww)],
+                         [2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)]])
+    ric, tic = quat_R(w.ex_pose), w.ex_pose[:3]
+    off = int(np.sum(w.line_nobs[:l]))
+    s, no = int(w.line_start[l]), int(w.line_nobs[l])
+    nc, vc = w.line_plk[l, :3], w.line_plk[l, 3:]
+    ob = w.line_obs[off]
+    p11, p21 = np.array([ob[0], ob[1], 1.0]), np.array([ob[2], ob[3], 1.0])
+    ln = np.cross(p11, p21)[:2]
+    ln = ln / np.linalg.norm(ln)
+    p12, p22 = p11 + [ln[0], ln[1], 0], p21 + [ln[0], ln[1], 0]
+    ends = []
+    for pa, pb in ((p11, p12), (p21, p22)):
+        n = np.cross(-pb, pa - pb)                      # plane through the camera centre and the two image points
+        e = np.cross(nc, n) + vc * 0.0, -vc @ n         # Lc * pi with pi = (n, 0)
+        ends.append(e[0] / e[1])
+    if ends[0][2] < 0 or ends[1][2] < 0 or np.linalg.norm(ends[0] - ends[1]) > 10:
+        return True
+    Rs, Ps = quat_R(w.pose[s]), w.pose[s, :3]
+    Rwc, twc = Rs @ ric, Ps + Rs @ tic
+    vw = Rwc @ vc
+    nw = Rwc @ nc + np.cross(twc, vw)
+    worst = 0.0
+    for k in range(no):
+        Rj, Pj = quat_R(w.pose[s + k]), w.pose[s + k, :3]
+        R1, t1 = Rj @ ric, Pj + Rj @ tic
+        ncj = R1.T @ (nw - np.cross(t1, vw))
+        ncj = ncj / np.hypot(ncj[0], ncj[1])
+        ob = w.line_obs[off + k]
+        worst = max(worst, 0.5 * (abs(ncj @ [ob[0], ob[1], 1.0]) + abs(ncj @ [ob[2], ob[3], 1.0])))
+    return worst > 3.0 / 500.0
+
+
+def test_remove_line_outlier_flags():
+    opt = v.default_options()
+    cfg = v.workload.config(80, 40, True)
+    cfg.pose_sigma_p = cfg.pose_sigma_theta_deg = cfg.vel_sigma = cfg.orth_sigma = 0.0   # start at the true state
+    cfg.pix_sigma = 0.2 / 460.0
+    w = v.workload.generate(31, cfg, 0.4)
+    o.preintegrate_windows([w], opt)
+    opt.num_iterations = 0                       # the state the test recomputes the criterion on is the input state
+    opt.remove_line_outliers = 1
+    rng = np.random.default_rng(3)
+    off = np.concatenate([[0], np.cumsum(w.line_nobs)])
+    for l in rng.choice(40, 6, replace=False):
+        w.line_obs[off[l] + 2, 0:4] += 0.03
+    w.line_plk[5, 3:] *= -1.0
+    w0 = w.copy()
+    prior, rep = o.solve_window(w, opt)
+    want = np.array([_numpy_line_outlier(w0, l) for l in range(40)])
+    assert np.array_equal(w.line_removed.astype(bool), want)
+    assert rep.n_lines_removed == int(want.sum()) and 3 <= want.sum() < 20
+    # the prior is the one of the same window without the erased tracks
+    keep = ~want
+    lo = np.concatenate([w0.line_obs[off[l]:off[l + 1]] for l in range(40) if keep[l]])
+    w1 = v.capi.Window(w0.pose, w0.speed_bias, w0.ex_pose, w0.point_start, w0.point_nobs, w0.point_obs, w0.inv_depth,
+                       w0.line_start[keep], w0.line_nobs[keep], lo, w0.line_plk[keep], w0.preint, None)
+    opt.remove_line_outliers = 0
+    prior1, rep1 = o.solve_window(w1, opt)
+    assert rep1.prior_n == rep.prior_n and rep1.prior_m == rep.prior_m
+    assert np.abs(prior1.J().T @ prior1.J() - prior.J().T @ prior.J()).max() <= 1e-9 * np.abs(prior.J().T @ prior.J()).max()

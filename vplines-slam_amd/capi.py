@@ -64,6 +64,7 @@ class CWindow(C.Structure):
                 ("n_points", C.c_int), ("point_start", _ip), ("point_nobs", _ip), ("point_obs", _dp),
                 ("inv_depth", _dp),
                 ("n_lines", C.c_int), ("line_start", _ip), ("line_nobs", _ip), ("line_obs", _dp), ("line_plk", _dp),
+                ("line_removed", _ip),
                 ("preint", Preintegration * NF), ("has_prior", C.c_int), ("prior", C.POINTER(Prior))]
 
 
@@ -93,6 +94,7 @@ class Window:
         self.line_nobs = _arr(line_nobs, np.int32).copy()
         self.line_obs = _arr(line_obs, np.float64).reshape(-1, 8).copy()
         self.line_plk = _arr(line_plk, np.float64).reshape(-1, 6).copy()
+        self.line_removed = np.zeros(max(len(self.line_start), 1), np.int32)   # out: removeLineOutlier flags
         self.preint = preint if preint is not None else (Preintegration * NF)()
         self.prior = prior
         self.extra = {}
@@ -120,6 +122,7 @@ class Window:
         cw.line_nobs = self.line_nobs.ctypes.data_as(_ip)
         cw.line_obs = self.line_obs.ctypes.data_as(_dp)
         cw.line_plk = self.line_plk.ctypes.data_as(_dp)
+        cw.line_removed = self.line_removed.ctypes.data_as(_ip)
         C.memmove(cw.preint, self.preint, C.sizeof(Preintegration) * NF)
         cw.has_prior = 1 if self.prior is not None else 0
         cw.prior = C.pointer(self.prior) if self.prior is not None else C.POINTER(Prior)()

@@ -156,13 +156,18 @@ __device__ __forceinline__ void acc_g(double* gv, int ba, const double* Ja, cons
   for (int c = 0; c < 6; ++c) lds_add(&gv[6 * ba + c], Ja[c] * r[0] + Ja[6 + c] * r[1]);
 }
 
-template <bool MARG>
+// MODE 0: solve linearisation; 1: MARGIN_OLD assembly (prior + IMU(0,1) + landmarks that start in frame 0);
+// 2: MARGIN_SECOND_NEW assembly (the prior alone, estimator.cpp:1387-1405)
+template <int MODE>
 __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
+  constexpr bool MARG = MODE != 0;
+  constexpr bool PRIOR_ONLY = MODE == 2;
   const int w = blockIdx.x, tid = threadIdx.x, T = LIN_THREADS;
   TrState* tr = &B.tr[w];
   if (!MARG) {
     if (tr->status != 0 || tr->fresh_lin) return;
   }
+  if (PRIOR_ONLY && B.mg_n[w] == 0) return;
   extern __shared__ double sm[];
   double* Hv = sm;                 // NV*NV, lower triangle used
   double* gv = Hv + NV * NV;       // NV
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     const int m16 = lane & 15, kk = lane >> 4;
     for (int s = wvi; s < NF; s += nwv) {
       const int b0 = pcnt[s], b1 = pcnt[s + 1];
-      if (MARG && s != 0) continue;
+      if ((MARG && s != 0) || PRIOR_ONLY) continue;
       for (int q0 = b0; q0 < b1; q0 += 64) {
         const int qi = q0 + lane;
         const bool live = qi < b1;
@@ -371,6 +376,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     const int j = tid + 1;
     const DevPreint& dp = B.pre[(size_t)w * NF + j];
     bool act = MARG ? (j == 1 && dp.sum_dt < 10.0) : !(dp.sum_dt > 10.0);   // estimator.cpp:1088, :1261
+    if (PRIOR_ONLY) act = false;
     imuact[tid] = act ? 1 : 0;
     double* J = imuJ + 450 * tid;
     for (int k = 0; k < 450; ++k) J[k] = 0.0;
@@ -427,7 +433,8 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
       const size_t li = (size_t)w * B.maxL + l;
       const int s = B.ln_start[li], off = B.ln_off[li];
       const int k = o - off, j = s + k;
-      const bool act = inb && (!MARG || (s == 0 && k >= 1));   // MARG: start-frame obs skipped (estimator.cpp:1322-1326)
+      // MARG: start-frame obs skipped (estimator.cpp:1322-1326), erased lines are no longer in f_manager.linefeature
+      const bool act = inb && !PRIOR_ONLY && (!MARG || (s == 0 && k >= 1 && !B.ln_removed[li]));
       const double* ob = B.ln_obs + ((size_t)w * B.maxLO + (inb ? o : 0)) * 8;
       LineCtx c;
       if (act) c = line_ctx(xp + 7 * j, xe, B.orth + li * 4);

@@ -70,10 +70,62 @@ __global__ __launch_bounds__(128) void k_gauge(DevBatch B) {
     // vector2double() before the marginalisation: getLineOrthVector on the updated state
     Plk Lw2 = plk_to_pose(Lc, Rwc, twc);
     plk_to_orth(Lw2, B.orth + li * 4);
+
+    // FeatureManager::removeLineOutlier (feature_manager.cpp:702-798) on the gauge-fixed state
+    int erase = 0;
+    if (B.opt.remove_line_outliers) {
+      const double* ob0 = B.ln_obs + ((size_t)w * B.maxLO + B.ln_off[li]) * 8;
+      const V3 p11{ob0[0], ob0[1], 1.0}, p21{ob0[2], ob0[3], 1.0};
+      const V3 cr = cross(p11, p21);
+      const double lnn = sqrt(cr.x * cr.x + cr.y * cr.y);
+      const double lx = cr.x / lnn, ly = cr.y / lnn;
+      const V3 p12{p11.x + lx, p11.y + ly, 1.0}, p22{p21.x + lx, p21.y + ly, 1.0};
+      const V3 cam{0, 0, 0};
+      // pi_from_ppp (line_geometry.cpp:134-139) ; Lc = [skew(nc) vc; -vc^T 0]
+      const V3 n1 = cross(cam - p12, p11 - p12), n2 = cross(cam - p22, p21 - p22);
+      const double d1 = -dot(p12, cross(cam, p11)), d2 = -dot(p22, cross(cam, p21));
+      const V3 e1x = mul(skew(Lc.n), n1) + Lc.v * d1, e2x = mul(skew(Lc.n), n2) + Lc.v * d2;
+      const double e1w = -dot(Lc.v, n1), e2w = -dot(Lc.v, n2);
+      const V3 e1{e1x.x / e1w, e1x.y / e1w, e1x.z / e1w}, e2{e2x.x / e2w, e2x.y / e2w, e2x.z / e2w};
+      if (e1.z < 0 || e2.z < 0) erase = 1;
+      else if (norm(e1 - e2) > 10) erase = 1;
+      else {
+        const Plk line_w = plk_to_pose(Lc, Rwc, twc);
+        double allerr = 0;
+        const int no = B.ln_nobs[li];
+        for (int k = 0; k < no; ++k) {
+          const int j = s + k;
+          const double* xj = pose + 7 * j;
+          const M3 Rj = mul(rot_diff, qmat(qnormalized(qpose(xj))));
+          const V3 Pj{newpose[7 * j], newpose[7 * j + 1], newpose[7 * j + 2]};
+          const V3 t1 = Pj + mul(Rj, tic);
+          const M3 R1 = mul(Rj, ric);
+          const Plk lc = plk_from_pose(line_w, R1, t1);   // feature_manager.cpp:390-411
+          const double sql = sqrt(lc.n.x * lc.n.x + lc.n.y * lc.n.y);
+          const V3 nn{lc.n.x / sql, lc.n.y / sql, lc.n.z / sql};
+          const double* ob = ob0 + 8 * k;
+          const double err = (fabs(nn.x * ob[0] + nn.y * ob[1] + nn.z) + fabs(nn.x * ob[2] + nn.y * ob[3] + nn.z)) / 2.0;
+          if (allerr < err) allerr = err;
+        }
+        if (allerr > 3.0 / 500.0) erase = 1;
+      }
+    }
+    B.ln_removed[li] = erase;
   }
   __syncthreads();
   for (int i = tid; i < 77; i += blockDim.x) pose[i] = newpose[i];
   for (int i = tid; i < 7; i += blockDim.x) ex[i] = newex[i];
+  // erased lines add no factor to the marginalisation: the kept-block table may shrink
+  if (tid == 0 && B.opt.remove_line_outliers && B.opt.marginalization_flag == 0) {
+    KeepSrc S;
+    S.nP = B.nP[w]; S.pt_start = B.pt_start + (size_t)w * B.maxP; S.pt_nobs = B.pt_nobs + (size_t)w * B.maxP;
+    S.nL = nL; S.ln_start = B.ln_start + (size_t)w * B.maxL; S.ln_nobs = B.ln_nobs + (size_t)w * B.maxL;
+    S.ln_removed = B.ln_removed + (size_t)w * B.maxL;
+    S.pr_nb = B.pr_n[w] > 0 ? B.pr_nb[w] : 0; S.pr_kind = B.pr_kind + (size_t)w * MAXPB; S.pr_frame = B.pr_frame + (size_t)w * MAXPB;
+    S.imu01 = B.pre[(size_t)w * NF + 1].sum_dt < 10.0;
+    keep_tables_old(S, B.mg_kind + (size_t)w * MAXPB, B.mg_frame + (size_t)w * MAXPB, B.mg_idx + (size_t)w * MAXPB,
+                    B.mg_cam + (size_t)w * MAXPB, B.mg_n + w, B.mg_nb + w, B.mg_m + w);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -220,8 +272,11 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   const int nP = B.nP[w], nL = B.nL[w];
   const int nb = B.mg_nb[w];
   const int n = B.mg_n[w];
+  if (n == 0) return;   // MARGIN_SECOND_NEW without pose[WINDOW_SIZE-1] in the prior: nothing to do (estimator.cpp:1385)
+  const bool second_new = B.opt.marginalization_flag == 1;
+  const int md = second_new ? 6 : 15;    // dims marginalised through the pseudo-inverse
   const MargLayout L = marg_layout(n);
-  const int nd = L.nd, ldd = L.ldd, ldm = L.ldm;
+  const int nd = md + n, ldd = L.ldd, ldm = L.ldm;
   double* G = sm;                        // n x ldm : kept block -> spectral factor
   double* Ad = G + L.EB;                 // nd x ldd dense pre-marginalisation matrix
   double* tile = Ad + nd * ldd;          // MTROWS x 74
@@ -238,21 +293,25 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
 
   // dense order: [sb_0 (9), pose_0 (6) | kept blocks in canonical order]  (the reference moves the
   // pose-like marginalised blocks behind the landmarks in descending index order, :291-309)
-  if (tid < 15) dmap[tid] = tid < 9 ? 6 + tid : tid - 9;
+  // MARGIN_SECOND_NEW: [pose_9 (6) | kept blocks], no landmarks (estimator.cpp:1387-1405)
+  if (tid < md) dmap[tid] = second_new ? 15 * (NF - 2) + tid : (tid < 9 ? 6 + tid : tid - 9);
   if (tid < nb) {
     const int kind = B.mg_kind[(size_t)w * MAXPB + tid];
     const int base = B.mg_cam[(size_t)w * MAXPB + tid], idx = B.mg_idx[(size_t)w * MAXPB + tid];
     const int ls = kind == 1 ? 9 : 6;
-    for (int k = 0; k < ls; ++k) dmap[15 + idx + k] = base + k;
+    for (int k = 0; k < ls; ++k) dmap[md + idx + k] = base + k;
   }
   if (tid == 32) {
-    int a = 0;
-    for (int p = 0; p < nP && a < LOFF; ++p)
-      if (B.pt_start[(size_t)w * B.maxP + p] == 0 && B.Hpp[(size_t)w * B.maxP + p] != 0.0) lst[a++] = p;
+    int a = 0, c = 0;
+    if (!second_new) {
+      for (int p = 0; p < nP && a < LOFF; ++p)
+        if (B.pt_start[(size_t)w * B.maxP + p] == 0 && B.Hpp[(size_t)w * B.maxP + p] != 0.0) lst[a++] = p;
+      for (int l = 0; l < nL && c < LOFF; ++l)
+        if (B.ln_start[(size_t)w * B.maxL + l] == 0 && B.ln_nobs[(size_t)w * B.maxL + l] >= 2 &&
+            !B.ln_removed[(size_t)w * B.maxL + l])
+          lst[LOFF + c++] = l;
+    }
     s_np0 = a;
-    int c = 0;
-    for (int l = 0; l < nL && c < LOFF; ++l)
-      if (B.ln_start[(size_t)w * B.maxL + l] == 0 && B.ln_nobs[(size_t)w * B.maxL + l] >= 2) lst[LOFF + c++] = l;
     s_nl0 = c;
   }
   __syncthreads();
@@ -333,27 +392,27 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     __syncthreads();
   }
 
-  // ---- marginalise the 15 dims of frame 0 through the eigen pseudo-inverse (:329-346) ----------
+  // ---- marginalise the md pose-like dims through the eigen pseudo-inverse (:329-346) ----------
   //      Amm^+ = sum_{lambda_k > eps} b_k b_k^T / lambda_k^2   with Amm = B B^T, b_k orthogonal, |b_k|^2 = lambda_k
-  for (int it = tid; it < 225; it += T) {
-    const int i = it / 15, j = it % 15;
+  for (int it = tid; it < md * md; it += T) {
+    const int i = it / md, j = it % md;
     E15[i * 17 + j] = 0.5 * (Ad[i * ldd + j] + Ad[j * ldd + i]);
   }
   __syncthreads();
-  psd_spectral_factor(E15, 15, 17, perm, lam, red, s_flag);
+  psd_spectral_factor(E15, md, 17, perm, lam, red, s_flag);
   // tmp(n x 15) = Arm * Amm^+ :  first Y = Arm * B (n x 15), then tmp = (Y ./ lambda^2) * B^T
   double* Y = tile;   // n x 16 scratch (tile is free now)
-  for (int it = tid; it < n * 15; it += T) {
-    const int i = it / 15, k = it % 15;
+  for (int it = tid; it < n * md; it += T) {
+    const int i = it / md, k = it % md;
     double s = 0;
-    for (int t = 0; t < 15; ++t) s += Ad[(15 + i) * ldd + perm[t]] * E15[t * 17 + k];
+    for (int t = 0; t < md; ++t) s += Ad[(md + i) * ldd + perm[t]] * E15[t * 17 + k];
     Y[i * 16 + k] = lam[k] > kMargEps ? s / (lam[k] * lam[k]) : 0.0;
   }
   __syncthreads();
-  for (int it = tid; it < n * 15; it += T) {
-    const int i = it / 15, t = it % 15;   // column perm[t] of tmp
+  for (int it = tid; it < n * md; it += T) {
+    const int i = it / md, t = it % md;   // column perm[t] of tmp
     double s = 0;
-    for (int k = 0; k < 15; ++k) s += Y[i * 16 + k] * E15[t * 17 + k];
+    for (int k = 0; k < md; ++k) s += Y[i * 16 + k] * E15[t * 17 + k];
     tmp[i * 16 + perm[t]] = s;
   }
   __syncthreads();
@@ -363,15 +422,15 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   for (int it = tid; it < n * n; it += T) {
     const int i = it / n, j = it % n;
     double s = 0;
-    for (int k = 0; k < 15; ++k) s += tmp[i * 16 + k] * Ad[k * ldd + 15 + j];
-    const double v = Ad[(15 + i) * ldd + 15 + j] - s;
+    for (int k = 0; k < md; ++k) s += tmp[i * 16 + k] * Ad[k * ldd + md + j];
+    const double v = Ad[(md + i) * ldd + md + j] - s;
     Aout[i * n + j] = v;
     G[i * ldm + j] = v;
   }
   for (int i = tid; i < n; i += T) {
     double s = 0;
-    for (int k = 0; k < 15; ++k) s += tmp[i * 16 + k] * bv[k];
-    bout[i] = bv[15 + i] - s;
+    for (int k = 0; k < md; ++k) s += tmp[i * 16 + k] * bv[k];
+    bout[i] = bv[md + i] - s;
   }
   __syncthreads();
   for (int i = tid; i < n; i += T) bv[i] = bout[i];

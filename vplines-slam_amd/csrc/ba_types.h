@@ -71,6 +71,7 @@ struct DevBatch {
   int *ln_start, *ln_nobs, *ln_off;              // [W][maxL]
   double *ln_obs;                                // [W][maxLO][8]
   int *nLO, *lo_ln;                              // [W] line observation count ; [W][maxLO] observation -> line
+  int *ln_removed;                               // [W][maxL] 1 = erased by removeLineOutlier (k_gauge)
 
   DevPreint *pre;                                // [W][11]
 
@@ -101,5 +102,72 @@ struct DevBatch {
   int *mg_m;                                     // [W] MarginalizationInfo::m
   long long *dbg;                                // [W][64] phase stamps (diagnostic builds: -DVPL_STAMPS)
 };
+
+
+// ---- kept-block tables of the marginalisation -------------------------------------------------------------
+// The reference orders the kept parameter blocks by address (std::map<long, ...>, marginalization_factor.cpp:133-175),
+// i.e. para_Pose[0..10] < para_SpeedBias[0..10] < para_Ex_Pose (estimator.h member order); the same canonical order is
+// produced here from which blocks the added factors touch.  Shared by the host (upload) and the device (after
+// removeLineOutlier changed the set of line factors).
+struct KeepSrc {
+  int nP; const int *pt_start, *pt_nobs;
+  int nL; const int *ln_start, *ln_nobs, *ln_removed;   // ln_removed may be null
+  int pr_nb; const int *pr_kind, *pr_frame;
+  bool imu01;                                           // pre_integrations[1]->sum_dt < 10 (estimator.cpp:1261)
+};
+
+// MARGIN_OLD (estimator.cpp:1229-1378): drops pose_0 / speed-bias_0 and every landmark that starts in frame 0
+__host__ __device__ inline void keep_tables_old(const KeepSrc& S, int* kind, int* frame, int* idx, int* cam, int* n_out,
+                                                int* nb_out, int* m_out) {
+  bool pose_t[NF], sb_t[NF];
+  for (int f = 0; f < NF; ++f) { pose_t[f] = false; sb_t[f] = false; }
+  bool ex_t = false, frame0 = false;
+  int m = 0;
+  for (int p = 0; p < S.nP; ++p)
+    if (S.pt_start[p] == 0) { for (int k = 1; k < S.pt_nobs[p]; ++k) pose_t[k] = true; ex_t = frame0 = true; m += 1; }
+  for (int l = 0; l < S.nL; ++l)
+    if (S.ln_start[l] == 0 && S.ln_nobs[l] >= 2 && !(S.ln_removed && S.ln_removed[l])) {
+      for (int k = 1; k < S.ln_nobs[l]; ++k) pose_t[k] = true;
+      ex_t = frame0 = true; m += 4;
+    }
+  for (int b = 0; b < S.pr_nb; ++b) {
+    if (S.pr_kind[b] == 0) pose_t[S.pr_frame[b]] = true;
+    else if (S.pr_kind[b] == 1) sb_t[S.pr_frame[b]] = true;
+    else ex_t = true;
+  }
+  if (S.imu01) { pose_t[0] = pose_t[1] = true; sb_t[0] = sb_t[1] = true; }
+  int nb = 0, n = 0;
+  for (int f = 1; f < NF; ++f) if (pose_t[f]) { kind[nb] = 0; frame[nb] = f - 1; idx[nb] = n; cam[nb] = 15 * f; n += 6; ++nb; }
+  for (int f = 1; f < NF; ++f) if (sb_t[f]) { kind[nb] = 1; frame[nb] = f - 1; idx[nb] = n; cam[nb] = 15 * f + 6; n += 9; ++nb; }
+  if (ex_t) { kind[nb] = 2; frame[nb] = 0; idx[nb] = n; cam[nb] = 165; n += 6; ++nb; }
+  *n_out = n; *nb_out = nb;
+  *m_out = m + ((pose_t[0] || frame0) ? 6 : 0) + (sb_t[0] ? 9 : 0);
+}
+
+// MARGIN_SECOND_NEW (estimator.cpp:1380-1447): only the prior, pose of frame WINDOW_SIZE-1 dropped, frame 10 -> 9.
+// Returns 0 when the prior does not hold that pose (the reference then leaves its prior untouched), -1 when it holds
+// the speed/bias of frame WINDOW_SIZE-1 (ROS_ASSERT at :1395), 1 otherwise.
+__host__ __device__ inline int keep_tables_second_new(int pr_nb, const int* pr_kind, const int* pr_frame, int* kind,
+                                                       int* frame, int* idx, int* cam, int* n_out, int* nb_out) {
+  bool has = false;
+  for (int b = 0; b < pr_nb; ++b) {
+    if (pr_kind[b] == 0 && pr_frame[b] == NF - 2) has = true;
+    if (pr_kind[b] == 1 && pr_frame[b] == NF - 2) return -1;
+  }
+  *n_out = 0; *nb_out = 0;
+  if (!has) return 0;
+  int nb = 0, n = 0;
+  for (int k = 0; k < 3; ++k)
+    for (int f = 0; f < NF; ++f)
+      for (int b = 0; b < pr_nb; ++b) {
+        if (pr_kind[b] != k || (k < 2 && pr_frame[b] != f) || (k == 2 && f != 0)) continue;
+        if (k == 0 && f == NF - 2) continue;
+        kind[nb] = k; frame[nb] = (k < 2 && f == NF - 1) ? NF - 2 : (k == 2 ? 0 : f); idx[nb] = n;
+        cam[nb] = k == 0 ? 15 * f : (k == 1 ? 15 * f + 6 : 165);
+        n += k == 1 ? 9 : 6; ++nb;
+      }
+  *n_out = n; *nb_out = nb;
+  return 1;
+}
 
 }  // namespace vpl

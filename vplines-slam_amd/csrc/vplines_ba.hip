@@ -35,6 +35,9 @@ struct vpl_ctx {
   std::vector<std::string> kname_store;
   // host-side marg structure of the uploaded windows
   std::vector<int> h_mg_m;
+  std::vector<int> h_passthrough;              // MARGIN_SECOND_NEW: window keeps its input prior (index into h_pass_priors or -1)
+  std::vector<vpl_prior> h_pass_priors;
+  bool any_second_new = false;
   std::vector<int> h_nP, h_nL;
   size_t marg_smem = 0;
 };
@@ -184,7 +187,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(scale, W * B.nfull); AL(diag, W * B.nfull); AL(grad, W * B.nfull); AL(gn, W * B.nfull); AL(delta, W * B.nfull);
   AL(mg_n, W); AL(mg_nb, W); AL(mg_kind, W * MAXPB); AL(mg_frame, W * MAXPB); AL(mg_idx, W * MAXPB);
   AL(mg_cam, W * MAXPB); AL(mg_x0, W * MAXPB * 9); AL(mg_J0, W * MAXKEEP * MAXKEEP); AL(mg_r0, W * MAXKEEP);
-  AL(mg_A, W * MAXKEEP * MAXKEEP); AL(mg_b, W * MAXKEEP); AL(mg_m, W); AL(dbg, W * 64);
+  AL(mg_A, W * MAXKEEP * MAXKEEP); AL(mg_b, W * MAXKEEP); AL(mg_m, W); AL(dbg, W * 64); AL(ln_removed, W * B.maxL);
 #undef AL
   if (e != hipSuccess) {
     for (void* p : c->allocs) hipFree(p);
@@ -192,8 +195,8 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
     return VPL_E_HIP;
   }
   if (lin_smem(c->maxL) > 158 * 1024) { for (void* p : c->allocs) hipFree(p); delete c; return VPL_E_CAPACITY; }
-  hipFuncSetAttribute((const void*)k_lin<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxL));
-  hipFuncSetAttribute((const void*)k_lin<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxL));
+  hipFuncSetAttribute((const void*)k_lin<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxL));
+  hipFuncSetAttribute((const void*)k_lin<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxL));
   hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
   hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SMEM);
   hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -354,9 +357,9 @@ int vpl_line_orth_plus(vpl_ctx* c, int n, const double* x, const double* delta, 
 int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt) {
   if (!c || !win || !opt || nW < 1) return VPL_E_INVALID;
   if (nW > c->maxW) return fail(c, VPL_E_CAPACITY, "more windows than max_windows");
-  if (opt->marginalization_flag == VPL_MARGIN_SECOND_NEW)
-    return fail(c, VPL_E_INVALID, "MARGIN_SECOND_NEW is not implemented on the device path yet");
-  if (opt->remove_line_outliers) return fail(c, VPL_E_INVALID, "remove_line_outliers is not implemented on the device path yet");
+  if (opt->marginalization_flag != VPL_MARGIN_OLD && opt->marginalization_flag != VPL_MARGIN_SECOND_NEW &&
+      opt->marginalization_flag != VPL_MARGIN_NONE)
+    return fail(c, VPL_E_INVALID, "unknown marginalization_flag");
   HIPCHK(c, hipSetDevice(c->device));
   c->opt = *opt;
   c->nW = nW;
@@ -385,6 +388,9 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
   std::vector<int> mg_n(W, 0), mg_nb(W, 0), mg_kind(W * MAXPB, 0), mg_frame(W * MAXPB, 0), mg_idx(W * MAXPB, 0),
       mg_cam(W * MAXPB, 0);
   c->h_mg_m.assign(W, 0);
+  c->h_passthrough.assign(W, -1);
+  c->h_pass_priors.clear();
+  c->any_second_new = false;
   c->h_nP.assign(W, 0);
   c->h_nL.assign(W, 0);
 
@@ -396,9 +402,6 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
     std::memcpy(&ex[w * 7], v.ex_pose, 7 * 8);
     nP[w] = v.n_points; nL[w] = v.n_lines;
     c->h_nP[w] = v.n_points; c->h_nL[w] = v.n_lines;
-    bool pose_touched[NF] = {false};
-    bool any_landmark0 = false;
-    int m = 0;
     int off = 0;
     for (int p = 0; p < v.n_points; ++p) {
       const int s = v.point_start[p], no = v.point_nobs[p];
@@ -407,7 +410,6 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
       pt_start[w * B.maxP + p] = s; pt_nobs[w * B.maxP + p] = no; pt_off[w * B.maxP + p] = off;
       std::memcpy(&pt_obs[(w * B.maxPO + off) * 3], v.point_obs + (size_t)off * 3, (size_t)no * 3 * 8);
       invd[w * B.maxP + p] = v.inv_depth[p];
-      if (s == 0) { for (int k = 1; k < no; ++k) pose_touched[k] = true; any_landmark0 = true; m += 1; }
       off += no;
     }
     {   // counting sort of the point tracks by start frame
@@ -427,15 +429,11 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
       ln_start[w * B.maxL + l] = s; ln_nobs[w * B.maxL + l] = no; ln_off[w * B.maxL + l] = off;
       std::memcpy(&ln_obs[(w * B.maxLO + off) * 8], v.line_obs + (size_t)off * 8, (size_t)no * 8 * 8);
       std::memcpy(&plk[(w * B.maxL + l) * 6], v.line_plk + (size_t)l * 6, 6 * 8);
-      if (s == 0 && no >= 2) { for (int k = 1; k < no; ++k) pose_touched[k] = true; any_landmark0 = true; m += 4; }
       for (int k = 0; k < no; ++k) lo_ln[w * B.maxLO + off + k] = l;
       off += no;
     }
     nLO[w] = off;
     for (int j = 0; j < NF; ++j) to_dev_preint(v.preint[j], pre[w * NF + j]);
-    bool sb_touched[NF] = {false};
-    bool ex_touched = any_landmark0;
-    bool frame0 = any_landmark0;
     if (v.has_prior && v.prior) {
       const vpl_prior& pr = *v.prior;
       if (pr.n < 0 || pr.n > MAXPN || pr.n_blocks < 0 || pr.n_blocks > MAXPB) return fail(c, VPL_E_INVALID, "bad prior");
@@ -445,29 +443,38 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
         pr_frame[w * MAXPB + b] = pr.block_frame[b];
         pr_idx[w * MAXPB + b] = pr.block_idx[b];
         std::memcpy(&pr_x0[(w * MAXPB + b) * 9], pr.x0[b], 9 * 8);
-        if (pr.block_kind[b] == VPL_BLOCK_POSE) pose_touched[pr.block_frame[b]] = true;
-        else if (pr.block_kind[b] == VPL_BLOCK_SPEEDBIAS) sb_touched[pr.block_frame[b]] = true;
-        else ex_touched = true;
+        if (pr.block_kind[b] < 0 || pr.block_kind[b] > 2 || pr.block_frame[b] < 0 || pr.block_frame[b] >= NF)
+          return fail(c, VPL_E_INVALID, "bad prior block");
       }
       std::memcpy(&pr_r0[w * MAXPN], pr.r0, (size_t)pr.n * 8);
       HIPCHK(c, hipMemcpyAsync(B.pr_J0 + w * MAXPN * MAXPN, pr.J0, (size_t)pr.n * pr.n * 8, hipMemcpyHostToDevice, c->stream));
     }
-    if (v.preint[1].sum_dt < 10.0) { pose_touched[1] = true; sb_touched[1] = true; sb_touched[0] = true; pose_touched[0] = true; }
-    // kept blocks in the canonical (address) order of the reference's para_* layout
-    if (opt->marginalization_flag == VPL_MARGIN_OLD) {
-      int nb = 0, idx = 0;
-      auto add = [&](int kind, int frame, int cam, int ls) {
-        mg_kind[w * MAXPB + nb] = kind; mg_frame[w * MAXPB + nb] = frame; mg_idx[w * MAXPB + nb] = idx;
-        mg_cam[w * MAXPB + nb] = cam;
-        idx += ls; ++nb;
-      };
-      for (int f = 1; f < NF; ++f) if (pose_touched[f]) add(VPL_BLOCK_POSE, f - 1, 15 * f, 6);
-      for (int f = 1; f < NF; ++f) if (sb_touched[f]) add(VPL_BLOCK_SPEEDBIAS, f - 1, 15 * f + 6, 9);
-      if (ex_touched) add(VPL_BLOCK_EXPOSE, 0, 165, 6);
-      if (idx > MAXKEEP) return fail(c, VPL_E_CAPACITY, "marginalisation keeps more than MAXKEEP dims");
-      mg_n[w] = idx; mg_nb[w] = nb;
-      m += (pose_touched[0] || frame0 ? 6 : 0) + (sb_touched[0] ? 9 : 0);
-      c->h_mg_m[w] = m;
+    // kept blocks of the next prior in the canonical (address) order of the reference's para_* layout
+    {
+      int* kd = &mg_kind[w * MAXPB]; int* fr = &mg_frame[w * MAXPB]; int* ix = &mg_idx[w * MAXPB]; int* cm = &mg_cam[w * MAXPB];
+      const int pnb = (v.has_prior && v.prior) ? v.prior->n_blocks : 0;
+      const int* pk = pnb ? v.prior->block_kind : nullptr;
+      const int* pf = pnb ? v.prior->block_frame : nullptr;
+      c->h_passthrough[w] = -1;
+      if (opt->marginalization_flag == VPL_MARGIN_OLD) {
+        KeepSrc S;
+        S.nP = v.n_points; S.pt_start = v.point_start; S.pt_nobs = v.point_nobs;
+        S.nL = v.n_lines; S.ln_start = v.line_start; S.ln_nobs = v.line_nobs; S.ln_removed = nullptr;
+        S.pr_nb = pnb; S.pr_kind = pk; S.pr_frame = pf;
+        S.imu01 = v.preint[1].sum_dt < 10.0;
+        int mm = 0;
+        keep_tables_old(S, kd, fr, ix, cm, &mg_n[w], &mg_nb[w], &mm);
+        c->h_mg_m[w] = mm;
+      } else if (opt->marginalization_flag == VPL_MARGIN_SECOND_NEW) {
+        const int rc = pnb ? keep_tables_second_new(pnb, pk, pf, kd, fr, ix, cm, &mg_n[w], &mg_nb[w]) : 0;
+        if (rc < 0) return fail(c, VPL_E_INVALID, "MARGIN_SECOND_NEW: the prior holds the speed/bias of frame WINDOW_SIZE-1");
+        if (rc == 1) { c->h_mg_m[w] = 6; c->any_second_new = true; }
+        else if (pnb) {   // the reference leaves last_marginalization_info as it is (estimator.cpp:1385)
+          c->h_passthrough[w] = (int)c->h_pass_priors.size();
+          c->h_pass_priors.push_back(*v.prior);
+        }
+      }
+      if (mg_n[w] > MAXKEEP) return fail(c, VPL_E_CAPACITY, "marginalisation keeps more than MAXKEEP dims");
     }
   }
   {
@@ -493,6 +500,7 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
   HIPCHK(c, up(c, B.pr_r0, pr_r0));
   HIPCHK(c, up(c, B.mg_n, mg_n)); HIPCHK(c, up(c, B.mg_nb, mg_nb)); HIPCHK(c, up(c, B.mg_kind, mg_kind));
   HIPCHK(c, up(c, B.mg_frame, mg_frame)); HIPCHK(c, up(c, B.mg_idx, mg_idx)); HIPCHK(c, up(c, B.mg_cam, mg_cam));
+  HIPCHK(c, up(c, B.mg_m, c->h_mg_m));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // host staging vectors die here
   return VPL_OK;
 }
@@ -516,18 +524,21 @@ int vpl_ba_solve(vpl_ctx* c) {
   const dim3 grid(c->nW);
   hipStream_t s = c->stream;
   { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(256), PREP_SMEM, s, B); }
-  { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<false>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
+  { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
   for (int it = 0; it < c->opt.num_iterations; ++it) {
     { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), SOLVE_SMEM, s, B); }
     { KTimer t(c, "k_cost"); hipLaunchKernelGGL(k_cost, grid, dim3(COST_THREADS), 0, s, B); }
     if (it + 1 < c->opt.num_iterations) {
       KTimer t(c, "k_lin");
-      hipLaunchKernelGGL(k_lin<false>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B);
+      hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B);
     }
   }
   { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
   if (c->opt.marginalization_flag == VPL_MARGIN_OLD) {
-    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<true>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
+    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<1>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
+    { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
+  } else if (c->any_second_new) {
+    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<2>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
     { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   }
   HIPCHK(c, hipGetLastError());
@@ -550,7 +561,10 @@ int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_
   HIPCHK(c, hipMemcpyAsync(tr.data(), B.tr, W * sizeof(TrState), hipMemcpyDeviceToHost, s));
   std::vector<int> mg_n, mg_nb, mg_kind, mg_frame, mg_idx;
   std::vector<double> mg_x0, mg_J0, mg_r0;
-  const bool marg = priors && c->opt.marginalization_flag == VPL_MARGIN_OLD;
+  const bool marg = priors != nullptr && c->opt.marginalization_flag != VPL_MARGIN_NONE;
+  std::vector<int> mg_m(W), removed(W * B.maxL);
+  HIPCHK(c, hipMemcpyAsync(mg_m.data(), B.mg_m, W * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(removed.data(), B.ln_removed, W * B.maxL * 4, hipMemcpyDeviceToHost, s));
   if (marg) {
     mg_n.resize(W); mg_nb.resize(W); mg_kind.resize(W * MAXPB); mg_frame.resize(W * MAXPB); mg_idx.resize(W * MAXPB);
     mg_x0.resize(W * MAXPB * 9); mg_J0.resize(W * MAXKEEP * MAXKEEP); mg_r0.resize(W * MAXKEEP);
@@ -579,10 +593,16 @@ int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_
       r.termination = tr[w].status == 1 ? 1 : tr[w].status == 2 ? 2 : 0;
       r.initial_cost = tr[w].initial_cost;
       r.final_cost = tr[w].x_cost;
-      r.prior_m = c->h_mg_m[w];
+      r.prior_m = mg_m[w];
       r.prior_n = marg ? mg_n[w] : 0;
+      for (int l = 0; l < v.n_lines; ++l) r.n_lines_removed += removed[w * B.maxL + l] ? 1 : 0;
     }
-    if (marg) {
+    if (v.line_removed)
+      for (int l = 0; l < v.n_lines; ++l) v.line_removed[l] = removed[w * B.maxL + l] ? 1 : 0;
+    if (marg && c->h_passthrough[w] >= 0) {
+      priors[w] = c->h_pass_priors[c->h_passthrough[w]];
+      if (reports) reports[w].prior_n = priors[w].n;
+    } else if (marg) {
       vpl_prior& p = priors[w];
       std::memset(&p, 0, sizeof(int) * (2 + 3 * VPL_MAX_PRIOR_BLOCKS));
       const int n = mg_n[w];

@@ -270,7 +270,7 @@ int vplw_generate(uint64_t seed, const vplw_config* cfg, double t_start, double*
   // points
   const int TL = cfg->track_len;
   for (int k = 0; k < cfg->n_points; ++k) {
-    int s = k % 6;
+    int s = k % (11 - TL + 1);   // track_len 6: start frames 0..5
     V3 pw{0, 0, 0};
     double d = 0;
     for (int tries = 0; tries < 10000; ++tries) {
@@ -310,7 +310,7 @@ int vplw_generate(uint64_t seed, const vplw_config* cfg, double t_start, double*
   M3 triad = mul(Rwc[5], Q0);  // columns = world directions of the 3 line families
 
   for (int k = 0; k < cfg->n_lines; ++k) {
-    int s = k % 6;
+    int s = k % (11 - TL + 1);   // track_len 6: start frames 0..5
     int ax = k % 3;
     V3 dir{triad.m[0][ax], triad.m[1][ax], triad.m[2][ax]};
     V3 e1{0, 0, 0}, e2{0, 0, 0};
