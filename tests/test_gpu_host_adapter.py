@@ -37,3 +37,34 @@ def test_host_adapter_classes_match_oracle(tmp_path):
     assert np.abs(vals["pose_plus"] - o.pose_plus(Pi[None], np.array([[0.01, -0.02, 0.03, 0.004, -0.005, 0.006]]))[0]).max() < 1e-14
     assert np.abs(vals["orth_plus"] - o.line_orth_plus(orth[None], np.array([[0.01, -0.02, 0.03, 0.004]]))[0]).max() < 1e-13
     assert list(vals["sizes"]) == [7, 6, 4, 4]
+
+
+def test_frontend_adapter_classes_match_oracle(tmp_path):
+    """EDLineDetector::EDline + LineMatching::Matching through the reference-shaped C++ classes"""
+    exe = str(tmp_path / "frontend_adapter_check")
+    libdir = os.path.join(ROOT, "vplines-slam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "frontend_adapter_check.cpp"),
+                           "-L", libdir, "-lvplines_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    imgs = [np.load(os.path.join(ROOT, "tests", "golden", "mh04_%d.npy" % i)) for i in (1, 2)]
+    paths = []
+    for i, im in enumerate(imgs):
+        p = str(tmp_path / ("f%d.raw" % i))
+        im.tofile(p)
+        paths.append(p)
+    out = subprocess.check_output([exe, paths[0], paths[1], "752", "480"], text=True)
+    vals = {ln.split()[0]: np.array([float(x) for x in ln.split()[1:]]) for ln in out.strip().splitlines()}
+    L = [o.edlines(im) for im in imgs]
+    key = lambda a: a[np.lexsort((np.round(a[:, 3], 2), np.round(a[:, 2], 2), np.round(a[:, 1], 2), np.round(a[:, 0], 2)))]
+    got = []
+    for k in range(2):
+        g = vals["lines%d" % k].reshape(-1, 10)
+        got.append(g)
+        assert len(g) == len(L[k])
+        assert np.abs(key(g)[:, :4] - key(L[k])[:, :4]).max() < 1e-3
+        assert np.abs(key(g)[:, 4:7] - key(L[k])[:, 4:7]).max() < 1e-9
+    # the matcher is checked on the device's own line order (chain order == the oracle's order)
+    ok, r2c, _ = o.line_match(imgs[0], imgs[1], got[0], got[1])
+    assert vals["match"][0] == 1 and ok
+    assert np.array_equal(vals["match"][1:].astype(int), r2c)
+    assert list(vals["empty"]) == [0, 55, 55]          # Matching() == false leaves the output vector alone

@@ -131,18 +131,21 @@ __global__ __launch_bounds__(128) void k_gauge(DevBatch B) {
 // ---------------------------------------------------------------------------------------------------
 // Spectral factor of a symmetric positive semi-definite matrix held in LDS (full storage, row stride ld):
 //     A = B B^T,  B = P^T G,  columns of G mutually orthogonal,  |g_k|^2 = lambda_k (eigenvalues of A).
-// Step 1: Cholesky with diagonal pivoting, P A P^T = L L^T (stops when no positive pivot is left).
+// Step 1: Cholesky with diagonal pivoting, P A P^T = L L^T (stops at the first pivot <= n eps max_i a_ii, as dpstrf).
 // Step 2: one-sided (Hestenes) Jacobi on the columns of L until they are orthogonal: G = L J.
 // The Cholesky factor of a graded PSD matrix is what makes Jacobi converge in a few sweeps and to high
 // RELATIVE accuracy of the small eigenvalues (Demmel & Veselic), which the marginalisation needs because it
 // consumes 1/lambda (pseudo-inverse) and 1/sqrt(lambda).  Round-robin ordering, 8 lanes per column pair,
 // one barrier per step.  On exit: A holds G (n x rank), lam[k] = |g_k|^2, perm[t] = original index of row t.
-// Returns the rank.  Needs blockDim.x >= 8 * ((n + 1) / 2).
-__device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* lam, double* red, int* iflag) {
+// Returns the rank.  Needs blockDim.x >= 8 * ((n + 1) / 2).  rel_tol: pivots <= max(n eps, rel_tol) * max_i a_ii stop the
+// factorisation (the trailing block is then treated as zero).
+__device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* lam, double* red, int* iflag,
+                                   double rel_tol) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
   for (int i = tid; i < n; i += T) perm[i] = i;
   __syncthreads();
   int rank = n;
+  double tol = 0.0;
   for (int k = 0; k < n; ++k) {
     // pivot: largest remaining diagonal (first index on ties), found by wave 0
     if (tid < 64) {
@@ -163,7 +166,10 @@ __device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* 
     __syncthreads();
     const int p = iflag[0];
     const double piv = red[0];
-    if (!(piv > 0.0)) { rank = k; break; }
+    // dpstrf-style stopping rule with a caller-supplied relative tolerance: a pivot at the noise level of the matrix
+    // must not be accepted -- dividing a column of noise by the root of a noise pivot fabricates an O(1) direction
+    if (k == 0) tol = fmax((double)n * 2.220446049250313e-16, rel_tol) * piv;
+    if (!(piv > tol)) { rank = k; break; }
     if (p != k) {   // symmetric swap k <-> p (rows, then columns), full storage
       for (int c = tid; c < n; c += T) { const double t = A[k * ld + c]; A[k * ld + c] = A[p * ld + c]; A[p * ld + c] = t; }
       __syncthreads();
@@ -247,6 +253,7 @@ __device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* 
 
 constexpr int MARG_THREADS = 512;
 constexpr double kMargEps = 1e-8;   // marginalization_factor.h:67
+constexpr double kMargNoiseRel = 1e-9;   // pivots of the kept block below this fraction of its largest diagonal are noise
 constexpr int MTROWS = 32;          // landmark rows staged per elimination pass
 static_assert(MAXKEEP <= 80, "psd_spectral_factor keeps 10 rows per lane (8 lanes per column pair)");
 
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     E15[i * 17 + j] = 0.5 * (Ad[i * ldd + j] + Ad[j * ldd + i]);
   }
   __syncthreads();
-  psd_spectral_factor(E15, md, 17, perm, lam, red, s_flag);
+  psd_spectral_factor(E15, md, 17, perm, lam, red, s_flag, 0.0);
   // tmp(n x 15) = Arm * Amm^+ :  first Y = Arm * B (n x 15), then tmp = (Y ./ lambda^2) * B^T
   double* Y = tile;   // n x 16 scratch (tile is free now)
   for (int it = tid; it < n * md; it += T) {
@@ -446,7 +453,11 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   }
   __syncthreads();
   // ---- spectral factor of the kept block (:349-357): J0 = sqrt(S) V^T = B^T, r0 = S^-1/2 V^T b ------
-  psd_spectral_factor(G, n, ldm, perm, lam, red, s_flag);
+  // The kept block is the difference of numbers five orders larger (A = Arr - Arm Amm^+ Amr after the landmark
+  // elimination): what the reference's eigen-solver reports below ~1e-10 lambda_max of it is rounding noise of either
+  // sign (it keeps the positive part above 1e-8 with a negligible weight).  Directions below 1e-9 lambda_max are
+  // dropped here.
+  psd_spectral_factor(G, n, ldm, perm, lam, red, s_flag, kMargNoiseRel);
   double* J0 = B.mg_J0 + (size_t)w * MAXKEEP * MAXKEEP;
   double* r0 = B.mg_r0 + (size_t)w * MAXKEEP;
   for (int it = tid; it < n * n; it += T) {

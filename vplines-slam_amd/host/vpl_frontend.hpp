@@ -1,0 +1,169 @@
+// Host-side mirror of the reference's line front-end interface, forwarding to the C ABI of
+// include/vplines_frontend.h (HIP kernels).  Same class names, constructor arguments, member-function names and
+// argument meaning as
+//   line_matching/src/line.h:8-17                    struct Line
+//   line_matching/src/edline_detector.h:32-40,55-84  EDLineParam, EDLineDetector::EDline
+//   line_matching/src/line_matching.h:14-33          LineMatching::LineMatching, LineMatching::Matching
+// so the tracker code (feature_tracker/src/line_feature_tracker.cpp:87,291-314) keeps its shape.
+// Frames are raw 8-bit single-channel buffers; with -DVPL_USE_OPENCV overloads taking cv::Mat are added
+// (cv::Mat::data of a continuous CV_8UC1 matrix is that buffer).  Nothing computes on the CPU: without a HIP device
+// the constructors throw.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "vplines_frontend.h"
+
+#ifdef VPL_USE_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+namespace vplhost {
+
+struct Line {   // numeric members of the reference's struct Line (the debug key-point vectors are not carried)
+  std::array<float, 4> line_endpoint;
+  std::array<double, 3> line_equation;
+  std::array<float, 2> center;
+  float length;
+};
+
+struct EDLineParam {
+  int ksize;
+  float sigma;
+  float gradientThreshold;
+  float anchorThreshold;
+  int scanIntervals;
+  int minLineLen;
+  double lineFitErrThreshold;
+};
+
+// One device context shared by the detector and the matcher of a tracker (two frames in flight).
+class FrontendDevice {
+ public:
+  FrontendDevice(int width, int height, int max_lines = 1024, int max_kps = 8192, int device = 0)
+      : w_(width), h_(height), max_lines_(max_lines) {
+    if (vpl_fe_create(&fe_, device, 2, width, height, max_lines) != 0)
+      throw std::runtime_error("vpl_fe_create failed (no HIP device? there is no CPU fallback)");
+    if (vpl_match_reserve(fe_, 1, max_kps) != 0) {
+      std::string m = vpl_fe_last_error(fe_);
+      vpl_fe_destroy(fe_);
+      throw std::runtime_error("vpl_match_reserve: " + m);
+    }
+  }
+  ~FrontendDevice() { vpl_fe_destroy(fe_); }
+  FrontendDevice(const FrontendDevice&) = delete;
+  FrontendDevice& operator=(const FrontendDevice&) = delete;
+  vpl_fe_ctx* ctx() const { return fe_; }
+  int width() const { return w_; }
+  int height() const { return h_; }
+  int max_lines() const { return max_lines_; }
+
+ private:
+  vpl_fe_ctx* fe_ = nullptr;
+  int w_, h_, max_lines_;
+};
+
+inline Line to_line(const vpl_line& v) {
+  Line l;
+  for (int k = 0; k < 4; ++k) l.line_endpoint[k] = v.line_endpoint[k];
+  for (int k = 0; k < 3; ++k) l.line_equation[k] = v.line_equation[k];
+  l.center = {v.center[0], v.center[1]};
+  l.length = v.length;
+  return l;
+}
+inline vpl_line from_line(const Line& l) {
+  vpl_line v;
+  std::memset(&v, 0, sizeof(v));
+  for (int k = 0; k < 4; ++k) v.line_endpoint[k] = l.line_endpoint[k];
+  for (int k = 0; k < 3; ++k) v.line_equation[k] = l.line_equation[k];
+  v.center[0] = l.center[0]; v.center[1] = l.center[1];
+  v.length = l.length;
+  return v;
+}
+
+class EDLineDetector {
+ public:
+  EDLineDetector(FrontendDevice& dev, EDLineParam param) : dev_(dev) {
+    p_.ksize = param.ksize; p_.sigma = param.sigma; p_.gradientThreshold = param.gradientThreshold;
+    p_.anchorThreshold = param.anchorThreshold; p_.scanIntervals = param.scanIntervals;
+    p_.minLineLen = param.minLineLen; p_.lineFitErrThreshold = param.lineFitErrThreshold;
+  }
+  // int EDLineDetector::EDline(cv::Mat& image, std::vector<Line>& lines, bool smoothed): returns 1, or -1 on error
+  // (edline_detector.cpp:1176-1198).  Only smoothed = true (the production call) exists on the device.
+  int EDline(const uint8_t* image, std::vector<Line>& lines, bool smoothed = true) {
+    if (!smoothed || !image) return -1;
+    std::vector<vpl_line> out(dev_.max_lines());
+    int n = 0;
+    if (vpl_edlines_detect_batch(dev_.ctx(), 1, image, &p_, out.data(), &n) != 0) return -1;
+    lines.clear();
+    for (int i = 0; i < n; ++i) lines.push_back(to_line(out[i]));
+    return 1;
+  }
+#ifdef VPL_USE_OPENCV
+  int EDline(cv::Mat& image, std::vector<Line>& lines, bool smoothed = true) {
+    if (image.type() != CV_8UC1 || !image.isContinuous() || image.cols != dev_.width() || image.rows != dev_.height()) return -1;
+    return EDline(image.data, lines, smoothed);
+  }
+#endif
+
+ private:
+  FrontendDevice& dev_;
+  vpl_edline_param p_;
+};
+
+class LineMatching {
+ public:
+  LineMatching(FrontendDevice& dev, int step = 10, float closest_line_threshold = 0.5f, float line_matching_ratio = 0.4f,
+               float line_distance_error_ratio = 3.f, float klt_error_threshold = 40.f)
+      : dev_(dev) {
+    vpl_match_default_param(&p_);
+    p_.step = step; p_.closest_line_threshold = closest_line_threshold; p_.line_matching_ratio = line_matching_ratio;
+    p_.line_distance_error_ratio = line_distance_error_ratio; p_.klt_error_threshold = klt_error_threshold;
+  }
+  // bool LineMatching::Matching(img_ref, img_cur, lines_ref, lines_cur, line_ref_to_line_cur, K_ref, K_cur, T_cur_ref,
+  //                             illumination_adapt, topological_filter, ...) with K/T = NULL (line_matching.cpp:605-690).
+  // Returns false (and leaves line_ref_to_line_cur untouched) when a line list is empty; throws on device errors.
+  bool Matching(const uint8_t* img_ref, const uint8_t* img_cur, const std::vector<Line>& lines_ref,
+                const std::vector<Line>& lines_cur, std::vector<int>& line_ref_to_line_cur,
+                bool illumination_adapt = false, bool topological_filter = true) {
+    const size_t px = (size_t)dev_.width() * dev_.height();
+    const int ML = dev_.max_lines();
+    if ((int)lines_ref.size() > ML || (int)lines_cur.size() > ML) throw std::runtime_error("more lines than max_lines");
+    std::vector<uint8_t> two(2 * px);
+    std::memcpy(two.data(), img_ref, px);
+    std::memcpy(two.data() + px, img_cur, px);
+    std::vector<vpl_line> lr(ML), lc(ML);
+    for (size_t i = 0; i < lines_ref.size(); ++i) lr[i] = from_line(lines_ref[i]);
+    for (size_t i = 0; i < lines_cur.size(); ++i) lc[i] = from_line(lines_cur[i]);
+    const int ref = 0, cur = 1, nr = (int)lines_ref.size(), nc = (int)lines_cur.size();
+    vpl_match_param p = p_;
+    p.illumination_adapt = illumination_adapt ? 1 : 0;
+    p.topological_filter = topological_filter ? 1 : 0;
+    std::vector<int> r2c(ML, -1);
+    int matched = 0;
+    if (vpl_line_match_batch(dev_.ctx(), 2, two.data(), 1, &ref, &cur, lr.data(), &nr, lc.data(), &nc, &p, r2c.data(),
+                             &matched) != 0)
+      throw std::runtime_error(std::string("vpl_line_match_batch: ") + vpl_fe_last_error(dev_.ctx()));
+    if (!matched) return false;
+    line_ref_to_line_cur.assign(r2c.begin(), r2c.begin() + nr);
+    return true;
+  }
+#ifdef VPL_USE_OPENCV
+  bool Matching(const cv::Mat& img_ref, const cv::Mat& img_cur, const std::vector<Line>& lines_ref,
+                const std::vector<Line>& lines_cur, std::vector<int>& line_ref_to_line_cur,
+                bool illumination_adapt = false, bool topological_filter = true) {
+    return Matching(img_ref.data, img_cur.data, lines_ref, lines_cur, line_ref_to_line_cur, illumination_adapt,
+                    topological_filter);
+  }
+#endif
+
+ private:
+  FrontendDevice& dev_;
+  vpl_match_param p_;
+};
+
+}  // namespace vplhost
