@@ -41,6 +41,21 @@ def algorithmic_bytes(P, L, n_prior, obs_p, obs_l):
     return dict(iteration=reads + writes, k_lin=k_lin, k_solve=k_solve, k_cost=k_cost)
 
 
+def pmc_traffic(kernel, nW, P, L):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/pmc_traffic.json, produced
+    by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this very command at the default workload,
+    corrected as MI355X_MICROARCH.md prescribes).  None when the workload differs from the profiled one."""
+    if (nW, P, L) != (512, 200, 80):
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1])).get("kernels", {})
+    key = {"k_lin": "k_lin<0>"}.get(kernel, kernel)
+    return k[key]["total"] if key in k else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,7 +165,7 @@ def main():
                        "windows_per_gpu": nW, "points": P, "lines": L, "track_len": TL, "prior_dim": n_prior,
                        "mean_tr_iterations": iters, "mean_successful_steps": succ, "parallelism": "batch-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, nW, P, L),
                          "avg_launch_ms": kavg[dom], "algorithmic_bytes_per_launch": ab[dom] * nW,
                          "pipeline_GBps": pipeline, "pipeline_frac": pipeline / HBM_PEAK_GBS},
             "kernels_ms_per_step": {k: ms / ksteps for k, (ms, _) in kt.items()},

@@ -122,6 +122,8 @@ typedef struct vpl_window {
   const double* line_obs;   /* [sum nobs][8] x1,y1,x2,y2, vp_x,vp_y,vp_z, vp_flag (estimator_node.cpp:375-407) */
   double* line_plk;         /* [n_lines][6] lineFeaturePerId::line_plucker, start-CAMERA frame (in/out) */
   int* line_removed;        /* [n_lines] out, may be NULL: 1 = erased by removeLineOutlier (options.remove_line_outliers) */
+  int* line_triangulated;   /* [n_lines] lineFeaturePerId::is_triangulation; NULL = every line is triangulated.  Lines with 0
+                             * take no part in the solves (estimator.cpp:1133); vpl_ba_triangulate_lines sets it (in/out) */
 
   /* pre_integrations[1..10]; entry 0 unused (estimator.cpp:1085-1093) */
   vpl_preintegration preint[VPL_NFRAMES];
@@ -218,6 +220,18 @@ int vpl_ctx_synchronize(vpl_ctx* ctx);
 /* Convenience: upload + solve + synchronize + download. */
 int vpl_ba_solve_windows(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt,
                          vpl_prior* priors_out, vpl_solve_report* reports);
+
+/* ---- line map maintenance that precedes the main solve (estimator.cpp:635-638) -------------------------------- */
+/* FeatureManager::triangulateLine (feature_manager.cpp:413-563): lines with line_triangulated[i] == 0 are triangulated
+ * from the two observations with the largest plane angle (skipped when cos > 0.998); on success line_plk[i] is written
+ * and line_triangulated[i] set.  Synchronous (upload, kernel, download). */
+int vpl_ba_triangulate_lines(vpl_ctx* ctx, int n_windows, vpl_window* windows);
+/* Estimator::onlyLineOpt (estimator.cpp:950-1039): line-only Levenberg-Marquardt with the poses and the extrinsic
+ * constant, CauchyLoss(1.0), at most options.num_iterations iterations, then double2vector + removeLineOutlier.
+ * Updates line_plk / line_removed of the triangulated lines; windows with fewer than four such lines are left untouched
+ * (as :1019-1022).  Synchronous. */
+int vpl_ba_only_line_opt(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt,
+                         vpl_solve_report* reports);
 
 /* ---- instrumentation (bench.py) ------------------------------------------ */
 /* Per-kernel device time of the last solve measured with hipEvents on the

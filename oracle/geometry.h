@@ -113,4 +113,10 @@ inline Vec4 pi_from_ppp(const Vec3& x1, const Vec3& x2, const Vec3& x3) {
   return Vec4{n[0], n[1], n[2], -x3.dot(cross(x1, x2))};
 }
 
+// pipi_plk (line_geometry.cpp:142-148): Pluecker line of the intersection of two planes, dp = pi1 pi2^T - pi2 pi1^T
+inline Vec6 pipi_plk(const Vec4& a, const Vec4& b) {
+  auto dp = [&](int i, int j) { return a[i] * b[j] - b[i] * a[j]; };
+  return Vec6{dp(0, 3), dp(1, 3), dp(2, 3), -dp(1, 2), dp(0, 2), -dp(0, 1)};
+}
+
 }  // namespace orc

@@ -8,6 +8,8 @@
 #include "problem.h"
 
 namespace orc {
+int triangulate_lines(vpl_window* w, const vpl_ba_options* opt);
+int only_line_opt(vpl_window* w, const vpl_ba_options* opt, vpl_solve_report* rep);
 int solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_out, vpl_solve_report* rep,
                  double* A_final_out, double* b_final_out);
 }
@@ -138,6 +140,9 @@ int orc_solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_
                      double* A_final, double* b_final) {
   return solve_window(w, opt, prior_out, rep, A_final, b_final);
 }
+
+int orc_triangulate_lines(vpl_window* w, const vpl_ba_options* opt) { return triangulate_lines(w, opt); }
+int orc_only_line_opt(vpl_window* w, const vpl_ba_options* opt, vpl_solve_report* rep) { return only_line_opt(w, opt, rep); }
 
 // windows fanned over `threads` host threads (cpu_baseline leg of bench.py)
 int orc_solve_windows(int n, vpl_window* w, const vpl_ba_options* opt, vpl_prior* priors_out, vpl_solve_report* reps,

@@ -466,16 +466,62 @@ struct Dogleg {
   void StepIsInvalid() { mu *= mu_increase_factor; reuse = false; }
 };
 
+// ---- ceres LevenbergMarquardtStrategy, levenberg_marquardt_strategy.cc (ceres 1.12, restated from the published
+//      algorithm): D = sqrt(clamp(diag(J^T J)) / radius), step = -(J^T J + D^2)^-1 J^T r through the same dense Schur
+//      solver; accepted: radius /= max(1/3, 1 - (2 rho - 1)^3), decrease_factor = 2; rejected: radius /= decrease_factor,
+//      decrease_factor *= 2.  The diagonal is re-used after a rejected step.
+struct LevenbergMarquardt {
+  double radius, max_radius, min_diagonal, max_diagonal;
+  double decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  VecX diagonal, lm_diagonal;
+  // members the debug print of Solve() reads for the dogleg strategy
+  VecX gauss_newton_step;
+  double dogleg_step_norm = 0.0, mu = 0.0;
+
+  explicit LevenbergMarquardt(const SolverOptions& o)
+      : radius(o.initial_trust_region_radius), max_radius(o.max_trust_region_radius),
+        min_diagonal(o.min_lm_diagonal), max_diagonal(o.max_lm_diagonal) {}
+
+  LinearSolverStatus ComputeStep(const Program& pr, const std::vector<RowBlock>& J, const VecX& residuals, VecX& step) {
+    const int n = pr.num_cols;
+    if (!reuse_diagonal) {
+      SquaredColumnNorm(pr, J, diagonal);
+      for (int i = 0; i < n; ++i) diagonal[i] = std::min(std::max(diagonal[i], min_diagonal), max_diagonal);
+    }
+    lm_diagonal.resize(n);
+    for (int i = 0; i < n; ++i) lm_diagonal[i] = std::sqrt(diagonal[i] / radius);
+    LinearSolverStatus st = DenseSchurSolve(pr, J, residuals, lm_diagonal, step);
+    if (st == LS_FAILURE) return st;
+    for (double& v : step) v = -v;
+    reuse_diagonal = true;
+    return st;
+  }
+  void StepAccepted(double step_quality) {
+    radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * step_quality - 1.0, 3));
+    radius = std::min(max_radius, radius);
+    decrease_factor = 2.0;
+    reuse_diagonal = false;
+  }
+  void StepRejected(double) {
+    radius = radius / decrease_factor;
+    decrease_factor *= 2.0;
+    reuse_diagonal = true;
+  }
+  void StepIsInvalid() {}
+};
+
 }  // namespace
 
 // ---- ceres TrustRegionMinimizer::Minimize (monotonic, unconstrained) ------------
-void Solve(const SolverOptions& opt, Problem* problem, SolverSummary* sum) {
+template <class Strategy>
+static void SolveWith(const SolverOptions& opt, Problem* problem, SolverSummary* sum) {
   Program pr(problem);
   VecX x, candidate_x, residuals, gradient, scale, step, delta, model_residuals;
   std::vector<RowBlock> J;
   pr.StateFromUser(x);
   double x_cost = 0, candidate_cost = 0, model_cost_change = 0;
-  Dogleg strategy(opt);
+  Strategy strategy(opt);
   int num_consecutive_invalid_steps = 0;
   IterationSummary it;
   auto norm = [](const VecX& v) { double s = 0; for (double a : v) s += a * a; return std::sqrt(s); };
@@ -603,6 +649,11 @@ void Solve(const SolverOptions& opt, Problem* problem, SolverSummary* sum) {
   }
   sum->final_cost = x_cost;
   pr.StateToUser(x);
+}
+
+void Solve(const SolverOptions& opt, Problem* problem, SolverSummary* sum) {
+  if (opt.use_dogleg) SolveWith<Dogleg>(opt, problem, sum);
+  else SolveWith<LevenbergMarquardt>(opt, problem, sum);
 }
 
 }  // namespace orc

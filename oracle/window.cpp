@@ -19,6 +19,8 @@ struct LineTrack {
   int start_frame;
   std::vector<Mat<8, 1>> obs;  // lineobs (4) + lineobs_vp (4)
   Vec6 line_plucker;           // start camera frame
+  bool is_triangulation = true;
+  int index = 0;               // position in the vpl_window arrays
 };
 struct PointTrack {
   int start_frame;
@@ -82,8 +84,9 @@ struct Est {
     }
   }
 
-  // estimator.cpp:810-900
-  void double2vector2() {
+  // estimator.cpp:810-900 (double2vector2) and :707-808 (double2vector: identical except that the lines are not carried
+  // through the yaw/position gauge transform -- setLineOrth receives the optimised orth as it is)
+  void double2vector2(bool line_gauge = true) {
     Vec3 origin_R0 = R2ypr(Rs[0]);
     Vec3 origin_P0 = Ps[0];
     Vec3 origin_R00 = R2ypr(Quat(para_Pose[0][6], para_Pose[0][3], para_Pose[0][4], para_Pose[0][5]).toRotationMatrix());
@@ -104,9 +107,11 @@ struct Est {
     Vec3 twow1 = -(Rwow1 * tw1b) + origin_P0;
     for (size_t i = 0; i < linefeature.size(); ++i) {
       Vec4 orth{para_LineFeature[i][0], para_LineFeature[i][1], para_LineFeature[i][2], para_LineFeature[i][3]};
-      Vec6 line_w1 = orth_to_plk(orth);
-      Vec6 line_wo = plk_to_pose(line_w1, Rwow1, twow1);
-      orth = plk_to_orth(line_wo);
+      if (line_gauge) {
+        Vec6 line_w1 = orth_to_plk(orth);
+        Vec6 line_wo = plk_to_pose(line_w1, Rwow1, twow1);
+        orth = plk_to_orth(line_wo);
+      }
       // setLineOrth (feature_manager.cpp:367-388)
       Vec6 line_w = orth_to_plk(orth);
       int imu_i = linefeature[i].start_frame;
@@ -119,6 +124,59 @@ struct Est {
       feature[i].estimated_depth = 1.0 / para_Feature[i][0];
       feature[i].solve_flag = feature[i].estimated_depth < 0 ? 2 : 1;
     }
+  }
+
+  // FeatureManager::triangulateLine, feature_manager.cpp:413-563; returns the number of lines triangulated now
+  int triangulateLine() {
+    int done = 0;
+    for (LineTrack& L : linefeature) {
+      if (L.is_triangulation) continue;
+      int imu_i = L.start_frame, imu_j = imu_i - 1;
+      Vec3 t0 = Ps[imu_i] + Rs[imu_i] * tic;
+      Mat3 R0 = Rs[imu_i] * ric;
+      double min_cos_theta = 1.0;
+      Vec3 tij{0, 0, 0};
+      Mat3 Rij;
+      Vec4 obsj{0, 0, 0, 0};
+      Vec4 pii{0, 0, 0, 0};
+      Vec3 ni{0, 0, 0};
+      for (auto& ob : L.obs) {
+        imu_j++;
+        if (imu_j == imu_i) {
+          Vec3 p1{ob[0], ob[1], 1}, p2{ob[2], ob[3], 1};
+          pii = pi_from_ppp(p1, p2, Vec3{0, 0, 0});
+          ni = Vec3{pii[0], pii[1], pii[2]};
+          ni = ni / ni.norm();
+          continue;
+        }
+        Vec3 t1 = Ps[imu_j] + Rs[imu_j] * tic;
+        Mat3 R1 = Rs[imu_j] * ric;
+        Vec3 t = R0.T() * (t1 - t0);
+        Mat3 R = R0.T() * R1;
+        Vec3 p3{ob[0], ob[1], 1}, p4{ob[2], ob[3], 1};
+        p3 = R * p3 + t;
+        p4 = R * p4 + t;
+        Vec4 pij = pi_from_ppp(p3, p4, t);
+        Vec3 nj{pij[0], pij[1], pij[2]};
+        nj = nj / nj.norm();
+        double cos_theta = ni.dot(nj);
+        if (cos_theta < min_cos_theta) {
+          min_cos_theta = cos_theta;
+          tij = t;
+          Rij = R;
+          obsj = Vec4{ob[0], ob[1], ob[2], ob[3]};
+        }
+      }
+      if (min_cos_theta > 0.998) continue;
+      Vec3 p3{obsj[0], obsj[1], 1}, p4{obsj[2], obsj[3], 1};
+      p3 = Rij * p3 + tij;
+      p4 = Rij * p4 + tij;
+      Vec4 pij = pi_from_ppp(p3, p4, tij);
+      L.line_plucker = pipi_plk(pii, pij);
+      L.is_triangulation = true;
+      ++done;
+    }
+    return done;
   }
 
   // feature_manager.cpp:390-411
@@ -174,7 +232,7 @@ struct Est {
         }
         if (allerr > 3.0 / 500.0) erase = true;
       }
-      if (erase) { ++removed; if (removed_index) removed_index->push_back((int)li); }
+      if (erase) { ++removed; if (removed_index) removed_index->push_back(L.index); }
       else kept.push_back(L);
     }
     linefeature.swap(kept);
@@ -183,7 +241,7 @@ struct Est {
   }
 };
 
-void load_window(const vpl_window& w, const vpl_ba_options& opt, Est& e) {
+void load_window(const vpl_window& w, const vpl_ba_options& opt, Est& e, bool all_lines = false) {
   for (int i = 0; i < VPL_NFRAMES; ++i) {
     e.Ps[i] = Vec3{w.pose[i][0], w.pose[i][1], w.pose[i][2]};
     e.Rs[i] = Quat(w.pose[i][6], w.pose[i][3], w.pose[i][4], w.pose[i][5]).normalized().toRotationMatrix();
@@ -213,7 +271,10 @@ void load_window(const vpl_window& w, const vpl_ba_options& opt, Est& e) {
       t.obs.push_back(o);
     }
     for (int c = 0; c < 6; ++c) t.line_plucker[c] = w.line_plk[6 * i + c];
-    e.linefeature.push_back(t);
+    t.index = i;
+    t.is_triangulation = !w.line_triangulated || w.line_triangulated[i] != 0;
+    // the solve sees the lines that pass the filter of estimator.cpp:1132-1133, of which is_triangulation is a part
+    if (all_lines || t.is_triangulation) e.linefeature.push_back(t);
   }
   e.para_Feature.resize(e.feature.size());
   e.para_LineFeature.resize(e.linefeature.size());
@@ -505,9 +566,80 @@ int solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_out,
   }
   for (int k = 0; k < 7; ++k) w->ex_pose[k] = e.para_Ex_Pose[0][k];
   for (size_t i = 0; i < e.feature.size(); ++i) w->inv_depth[i] = 1.0 / e.feature[i].estimated_depth;
-  if (!opt->remove_line_outliers)
-    for (size_t i = 0; i < e.linefeature.size(); ++i)
-      for (int c = 0; c < 6; ++c) w->line_plk[6 * i + c] = e.linefeature[i].line_plucker[c];
+  // erased tracks are gone from e.linefeature: their line_plk keeps the caller's value
+  for (size_t i = 0; i < e.linefeature.size(); ++i)
+      for (int c = 0; c < 6; ++c) w->line_plk[6 * e.linefeature[i].index + c] = e.linefeature[i].line_plucker[c];
+  if (rep) *rep = report;
+  return 0;
+}
+
+// FeatureManager::triangulateLine (feature_manager.cpp:413-563) on the lines of the window whose line_triangulated flag is
+// 0; writes line_plk and the flag of every line it triangulated.  Returns the number of such lines.
+int triangulate_lines(vpl_window* w, const vpl_ba_options* opt) {
+  Est e;
+  load_window(*w, *opt, e, /*all_lines=*/true);
+  const int done = e.triangulateLine();
+  for (auto& L : e.linefeature) {
+    if (!L.is_triangulation) continue;
+    for (int c = 0; c < 6; ++c) w->line_plk[6 * L.index + c] = L.line_plucker[c];
+    if (w->line_triangulated) w->line_triangulated[L.index] = 1;
+  }
+  return done;
+}
+
+// Estimator::onlyLineOpt (estimator.cpp:950-1039): poses and extrinsic constant, line factors only (no VP factors),
+// CauchyLoss(1.0), ceres defaults otherwise (LEVENBERG_MARQUARDT, DENSE_SCHUR), NUM_ITERATIONS; then double2vector() and
+// removeLineOutlier.  With fewer than four line tracks the function returns before the solve (:1019-1022).
+int only_line_opt(vpl_window* w, const vpl_ba_options* opt, vpl_solve_report* rep) {
+  Est e;
+  load_window(*w, *opt, e);
+  lineProjectionFactor::sqrt_info = opt->line_factor;
+  vpl_solve_report report;
+  std::memset(&report, 0, sizeof(report));
+  if (w->line_removed)
+    for (int i = 0; i < w->n_lines; ++i) w->line_removed[i] = 0;
+  e.vector2double();
+  const int feature_index = (int)e.linefeature.size() - 1;
+  if (feature_index >= 3) {
+    LossFunction* loss_function = new CauchyLoss(1.0);
+    Problem problem;
+    for (int i = 0; i < VPL_WINDOW_SIZE + 1; i++) {
+      problem.AddParameterBlock(e.para_Pose[i], 7, new PoseLocalParameterization());
+      problem.SetParameterBlockConstant(e.para_Pose[i]);
+    }
+    problem.AddParameterBlock(e.para_Ex_Pose[0], 7, new PoseLocalParameterization());
+    problem.SetParameterBlockConstant(e.para_Ex_Pose[0]);
+    for (size_t li = 0; li < e.linefeature.size(); ++li) {
+      problem.AddParameterBlock(e.para_LineFeature[li].data(), 4, new LineOrthParameterization());
+      int imu_j = e.linefeature[li].start_frame - 1;
+      for (auto& ob : e.linefeature[li].obs) {
+        imu_j++;
+        Vec4 obs{ob[0], ob[1], ob[2], ob[3]};
+        problem.AddResidualBlock(new lineProjectionFactor(obs), loss_function,
+                                 {e.para_Pose[imu_j], e.para_Ex_Pose[0], e.para_LineFeature[li].data()});
+      }
+    }
+    SolverOptions options;
+    options.use_dogleg = false;
+    options.max_num_iterations = opt->num_iterations;
+    SolverSummary summary;
+    Solve(options, &problem, &summary);
+    report.iterations = (int)summary.iterations.size() - 1;
+    report.num_successful_steps = summary.num_successful_steps - 1;
+    report.termination = (int)summary.termination_type;
+    report.initial_cost = summary.initial_cost;
+    report.final_cost = summary.final_cost;
+    for (auto& rb : problem.residuals_)
+      if (rb.loss == loss_function) rb.loss = nullptr;
+    delete loss_function;
+    e.double2vector2(/*line_gauge=*/false);
+    std::vector<int> removed_index;
+    report.n_lines_removed = e.removeLineOutlier(&removed_index);
+    if (w->line_removed)
+      for (int i : removed_index) w->line_removed[i] = 1;
+    for (auto& L : e.linefeature)
+      for (int c = 0; c < 6; ++c) w->line_plk[6 * L.index + c] = L.line_plucker[c];
+  }
   if (rep) *rep = report;
   return 0;
 }

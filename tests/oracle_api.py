@@ -268,3 +268,21 @@ def line_match(img_ref, img_cur, lines_ref, lines_cur, prm=None, cap_kps=65536):
     n = min(nk.value, cap_kps)
     return bool(ok), r2c[:len(lines_ref)], dict(kps_ref=kr[:n], kps_cur=kc[:n], status=st[:n], err=er[:n],
                                                 kp2line_cur=k2l[:n])
+
+
+# ---- line map maintenance before the main solve (estimator.cpp:635-638) ----------------------------------
+def triangulate_lines(w, opt):
+    """FeatureManager::triangulateLine on Window w (lines with line_triangulated == 0). Returns the number done."""
+    lib = load()
+    cw = w.to_c()
+    return lib.orc_triangulate_lines(C.byref(cw), C.byref(opt))
+
+
+def only_line_opt(w, opt):
+    """Estimator::onlyLineOpt in place on Window w. Returns the report."""
+    lib = load()
+    cw = w.to_c()
+    rep = SolveReport()
+    rc = lib.orc_only_line_opt(C.byref(cw), C.byref(opt), C.byref(rep))
+    assert rc == 0
+    return rep

@@ -8,7 +8,8 @@ nw = 512
 ctx = v.Context(device=0, max_windows=nw)
 ws, opt = make_windows(nw, 200, 80, True)
 opt.num_iterations = 1
-ctx.solve_windows(ws, opt)
+pri, _ = ctx.solve_windows(ws, opt)
+print('prior n', pri[0].n)
 ctx.lib.vpl_ba_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
 for w in (0, 1, 300):
     out = (C.c_longlong * 64)()
@@ -16,3 +17,4 @@ for w in (0, 1, 300):
     s = list(out)
     print("window", w, "k_solve phases (cycles):", [s[i + 1] - s[i] for i in range(0, 7)])
     print("   k_lin: prior %d imu %d zero %d points %d lines+out %d assemble %d" % (s[18]-s[16], s[22]-s[24], s[23]-s[18], s[24]-s[23], s[20]-s[22], s[21]-s[20]))
+    print("   k_marg: setup+Ad %d landmark-elim %d E15 %d schur %d G-factor %d out %d" % (s[33]-s[32], 0, s[34]-s[33], s[35]-s[34], s[36]-s[35], s[37]-s[36]))

@@ -64,7 +64,7 @@ class CWindow(C.Structure):
                 ("n_points", C.c_int), ("point_start", _ip), ("point_nobs", _ip), ("point_obs", _dp),
                 ("inv_depth", _dp),
                 ("n_lines", C.c_int), ("line_start", _ip), ("line_nobs", _ip), ("line_obs", _dp), ("line_plk", _dp),
-                ("line_removed", _ip),
+                ("line_removed", _ip), ("line_triangulated", _ip),
                 ("preint", Preintegration * NF), ("has_prior", C.c_int), ("prior", C.POINTER(Prior))]
 
 
@@ -95,6 +95,7 @@ class Window:
         self.line_obs = _arr(line_obs, np.float64).reshape(-1, 8).copy()
         self.line_plk = _arr(line_plk, np.float64).reshape(-1, 6).copy()
         self.line_removed = np.zeros(max(len(self.line_start), 1), np.int32)   # out: removeLineOutlier flags
+        self.line_triangulated = np.ones(max(len(self.line_start), 1), np.int32)   # is_triangulation (in/out)
         self.preint = preint if preint is not None else (Preintegration * NF)()
         self.prior = prior
         self.extra = {}
@@ -105,6 +106,7 @@ class Window:
         w = Window(self.pose, self.speed_bias, self.ex_pose, self.point_start, self.point_nobs, self.point_obs,
                    self.inv_depth, self.line_start, self.line_nobs, self.line_obs, self.line_plk, pre, self.prior)
         w.extra = dict(self.extra)
+        w.line_triangulated[:] = self.line_triangulated
         return w
 
     def to_c(self, cw=None):
@@ -123,6 +125,7 @@ class Window:
         cw.line_obs = self.line_obs.ctypes.data_as(_dp)
         cw.line_plk = self.line_plk.ctypes.data_as(_dp)
         cw.line_removed = self.line_removed.ctypes.data_as(_ip)
+        cw.line_triangulated = self.line_triangulated.ctypes.data_as(_ip)
         C.memmove(cw.preint, self.preint, C.sizeof(Preintegration) * NF)
         cw.has_prior = 1 if self.prior is not None else 0
         cw.prior = C.pointer(self.prior) if self.prior is not None else C.POINTER(Prior)()
@@ -171,6 +174,8 @@ def load_hip_library():
     lib.vpl_ctx_synchronize.argtypes = [vp]
     lib.vpl_ba_solve_windows.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(Prior),
                                          C.POINTER(SolveReport)]
+    lib.vpl_ba_triangulate_lines.argtypes = [vp, C.c_int, C.POINTER(CWindow)]
+    lib.vpl_ba_only_line_opt.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(SolveReport)]
     lib.vpl_ba_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.vpl_ba_kernel_times.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), _dp, _ip]
     _hip = lib
@@ -313,6 +318,24 @@ class Context:
         self.solve()
         self.synchronize()
         return self.download()
+
+    def triangulate_lines(self, windows):
+        """FeatureManager::triangulateLine on the device; updates line_plk / line_triangulated of the Windows in place"""
+        n = len(windows)
+        cw = (CWindow * n)()
+        for i, w in enumerate(windows):
+            w.to_c(cw[i])
+        self._check(self.lib.vpl_ba_triangulate_lines(self.h, n, cw), "vpl_ba_triangulate_lines")
+
+    def only_line_opt(self, windows, opt):
+        """Estimator::onlyLineOpt on the device; updates line_plk / line_removed in place, returns the reports"""
+        n = len(windows)
+        cw = (CWindow * n)()
+        for i, w in enumerate(windows):
+            w.to_c(cw[i])
+        reps = (SolveReport * n)()
+        self._check(self.lib.vpl_ba_only_line_opt(self.h, n, cw, C.byref(opt), reps), "vpl_ba_only_line_opt")
+        return reps
 
     def enable_kernel_timing(self, on=True):
         self._check(self.lib.vpl_ba_enable_kernel_timing(self.h, 1 if on else 0), "vpl_ba_enable_kernel_timing")

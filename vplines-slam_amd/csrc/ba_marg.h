@@ -322,6 +322,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     s_nl0 = c;
   }
   __syncthreads();
+  VPL_STAMP(B, w, 32);
   const double* Hcc = B.Hcc + (size_t)w * NCP;
   const double* gc = B.gc + (size_t)w * NC;
   // ---- landmark elimination (plain inverse of the block-diagonal landmark part, :316-326) --------
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     __syncthreads();
   }
 
+  VPL_STAMP(B, w, 33);
   // ---- marginalise the md pose-like dims through the eigen pseudo-inverse (:329-346) ----------
   //      Amm^+ = sum_{lambda_k > eps} b_k b_k^T / lambda_k^2   with Amm = B B^T, b_k orthogonal, |b_k|^2 = lambda_k
   for (int it = tid; it < md * md; it += T) {
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   }
   __syncthreads();
   psd_spectral_factor(E15, md, 17, perm, lam, red, s_flag, 0.0);
+  VPL_STAMP(B, w, 34);
   // tmp(n x 15) = Arm * Amm^+ :  first Y = Arm * B (n x 15), then tmp = (Y ./ lambda^2) * B^T
   double* Y = tile;   // n x 16 scratch (tile is free now)
   for (int it = tid; it < n * md; it += T) {
@@ -453,11 +456,13 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   }
   __syncthreads();
   // ---- spectral factor of the kept block (:349-357): J0 = sqrt(S) V^T = B^T, r0 = S^-1/2 V^T b ------
+  VPL_STAMP(B, w, 35);
   // The kept block is the difference of numbers five orders larger (A = Arr - Arm Amm^+ Amr after the landmark
   // elimination): what the reference's eigen-solver reports below ~1e-10 lambda_max of it is rounding noise of either
   // sign (it keeps the positive part above 1e-8 with a negligible weight).  Directions below 1e-9 lambda_max are
   // dropped here.
   psd_spectral_factor(G, n, ldm, perm, lam, red, s_flag, kMargNoiseRel);
+  VPL_STAMP(B, w, 36);
   double* J0 = B.mg_J0 + (size_t)w * MAXKEEP * MAXKEEP;
   double* r0 = B.mg_r0 + (size_t)w * MAXKEEP;
   for (int it = tid; it < n * n; it += T) {
@@ -481,6 +486,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     const int gs = kind == 1 ? 9 : 7;
     for (int k = 0; k < 9; ++k) B.mg_x0[((size_t)w * MAXPB + tid) * 9 + k] = k < gs ? x[k] : 0.0;
   }
+  VPL_STAMP(B, w, 37);
 }
 
 }  // namespace vpl

@@ -72,6 +72,7 @@ struct DevBatch {
   double *ln_obs;                                // [W][maxLO][8]
   int *nLO, *lo_ln;                              // [W] line observation count ; [W][maxLO] observation -> line
   int *ln_removed;                               // [W][maxL] 1 = erased by removeLineOutlier (k_gauge)
+  int *ln_tri;                                   // [W][maxL] lineFeaturePerId::is_triangulation (k_triangulate)
 
   DevPreint *pre;                                // [W][11]
 

@@ -17,6 +17,7 @@
 #include "ba_lin.h"
 #include "ba_solve.h"
 #include "ba_marg.h"
+#include "ba_lineopt.h"
 #include "ba_factors.h"
 
 using namespace vpl;
@@ -39,6 +40,7 @@ struct vpl_ctx {
   std::vector<vpl_prior> h_pass_priors;
   bool any_second_new = false;
   std::vector<int> h_nP, h_nL;
+  std::vector<std::vector<int>> h_lmap;          // per window: device line index -> index in the vpl_window arrays
   size_t marg_smem = 0;
 };
 
@@ -187,7 +189,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(scale, W * B.nfull); AL(diag, W * B.nfull); AL(grad, W * B.nfull); AL(gn, W * B.nfull); AL(delta, W * B.nfull);
   AL(mg_n, W); AL(mg_nb, W); AL(mg_kind, W * MAXPB); AL(mg_frame, W * MAXPB); AL(mg_idx, W * MAXPB);
   AL(mg_cam, W * MAXPB); AL(mg_x0, W * MAXPB * 9); AL(mg_J0, W * MAXKEEP * MAXKEEP); AL(mg_r0, W * MAXKEEP);
-  AL(mg_A, W * MAXKEEP * MAXKEEP); AL(mg_b, W * MAXKEEP); AL(mg_m, W); AL(dbg, W * 64); AL(ln_removed, W * B.maxL);
+  AL(mg_A, W * MAXKEEP * MAXKEEP); AL(mg_b, W * MAXKEEP); AL(mg_m, W); AL(dbg, W * 64); AL(ln_removed, W * B.maxL); AL(ln_tri, W * B.maxL);
 #undef AL
   if (e != hipSuccess) {
     for (void* p : c->allocs) hipFree(p);
@@ -354,7 +356,7 @@ int vpl_line_orth_plus(vpl_ctx* c, int n, const double* x, const double* delta, 
 }
 
 // ---- window batch: upload / solve / download ------------------------------------------------------------
-int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt) {
+static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt, bool all_lines) {
   if (!c || !win || !opt || nW < 1) return VPL_E_INVALID;
   if (nW > c->maxW) return fail(c, VPL_E_CAPACITY, "more windows than max_windows");
   if (opt->marginalization_flag != VPL_MARGIN_OLD && opt->marginalization_flag != VPL_MARGIN_SECOND_NEW &&
@@ -378,7 +380,7 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
   const size_t W = nW;
   std::vector<double> pose(W * 77), sb(W * 99), ex(W * 7), invd(W * B.maxP, 1.0), plk(W * B.maxL * 6, 0.0);
   std::vector<int> nP(W), nL(W), pt_start(W * B.maxP, 0), pt_nobs(W * B.maxP, 0), pt_off(W * B.maxP, 0);
-  std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0);
+  std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0), ln_tri(W * B.maxL, 1);
   std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0);
   std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
@@ -393,6 +395,7 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
   c->any_second_new = false;
   c->h_nP.assign(W, 0);
   c->h_nL.assign(W, 0);
+  c->h_lmap.resize(W);
 
   for (size_t w = 0; w < W; ++w) {
     const vpl_window& v = win[w];
@@ -400,8 +403,8 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
     std::memcpy(&pose[w * 77], v.pose, 77 * 8);
     std::memcpy(&sb[w * 99], v.speed_bias, 99 * 8);
     std::memcpy(&ex[w * 7], v.ex_pose, 7 * 8);
-    nP[w] = v.n_points; nL[w] = v.n_lines;
-    c->h_nP[w] = v.n_points; c->h_nL[w] = v.n_lines;
+    nP[w] = v.n_points;
+    c->h_nP[w] = v.n_points;
     int off = 0;
     for (int p = 0; p < v.n_points; ++p) {
       const int s = v.point_start[p], no = v.point_nobs[p];
@@ -422,16 +425,30 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
       for (int p = 0; p < v.n_points; ++p) ps_list[w * B.maxP + pos[v.point_start[p]]++] = p;
     }
     off = 0;
+    int woff = 0, nl = 0;
+    std::vector<int>& lmap = c->h_lmap[w];
+    lmap.clear();
     for (int l = 0; l < v.n_lines; ++l) {
       const int s = v.line_start[l], no = v.line_nobs[l];
       if (s < 0 || no < 1 || s + no > NF) return fail(c, VPL_E_INVALID, "line track outside the window");
-      if (off + no > B.maxLO) return fail(c, VPL_E_CAPACITY, "too many line observations");
-      ln_start[w * B.maxL + l] = s; ln_nobs[w * B.maxL + l] = no; ln_off[w * B.maxL + l] = off;
-      std::memcpy(&ln_obs[(w * B.maxLO + off) * 8], v.line_obs + (size_t)off * 8, (size_t)no * 8 * 8);
-      std::memcpy(&plk[(w * B.maxL + l) * 6], v.line_plk + (size_t)l * 6, 6 * 8);
-      for (int k = 0; k < no; ++k) lo_ln[w * B.maxLO + off + k] = l;
-      off += no;
+      const int tri_flag = (!v.line_triangulated || v.line_triangulated[l]) ? 1 : 0;
+      // lines that are not triangulated take no part in the solves (estimator.cpp:1133); they travel only for
+      // vpl_ba_triangulate_lines
+      if (all_lines || tri_flag) {
+        if (off + no > B.maxLO) return fail(c, VPL_E_CAPACITY, "too many line observations");
+        const size_t dl = w * B.maxL + nl;
+        ln_start[dl] = s; ln_nobs[dl] = no; ln_off[dl] = off; ln_tri[dl] = tri_flag;
+        std::memcpy(&ln_obs[(w * B.maxLO + off) * 8], v.line_obs + (size_t)woff * 8, (size_t)no * 8 * 8);
+        std::memcpy(&plk[dl * 6], v.line_plk + (size_t)l * 6, 6 * 8);
+        for (int k = 0; k < no; ++k) lo_ln[w * B.maxLO + off + k] = nl;
+        off += no;
+        lmap.push_back(l);
+        ++nl;
+      }
+      woff += no;
     }
+    nL[w] = nl;
+    c->h_nL[w] = nl;
     nLO[w] = off;
     for (int j = 0; j < NF; ++j) to_dev_preint(v.preint[j], pre[w * NF + j]);
     if (v.has_prior && v.prior) {
@@ -459,7 +476,7 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
       if (opt->marginalization_flag == VPL_MARGIN_OLD) {
         KeepSrc S;
         S.nP = v.n_points; S.pt_start = v.point_start; S.pt_nobs = v.point_nobs;
-        S.nL = v.n_lines; S.ln_start = v.line_start; S.ln_nobs = v.line_nobs; S.ln_removed = nullptr;
+        S.nL = nL[w]; S.ln_start = &ln_start[w * B.maxL]; S.ln_nobs = &ln_nobs[w * B.maxL]; S.ln_removed = nullptr;
         S.pr_nb = pnb; S.pr_kind = pk; S.pr_frame = pf;
         S.imu01 = v.preint[1].sum_dt < 10.0;
         int mm = 0;
@@ -492,7 +509,7 @@ int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_option
   HIPCHK(c, up(c, B.pt_obs, pt_obs));
   HIPCHK(c, up(c, B.ps_list, ps_list)); HIPCHK(c, up(c, B.ps_cnt, ps_cnt));
   HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
-  HIPCHK(c, up(c, B.ln_obs, ln_obs));
+  HIPCHK(c, up(c, B.ln_obs, ln_obs)); HIPCHK(c, up(c, B.ln_tri, ln_tri));
   HIPCHK(c, up(c, B.nLO, nLO)); HIPCHK(c, up(c, B.lo_ln, lo_ln));
   HIPCHK(c, up(c, B.pre, pre));
   HIPCHK(c, up(c, B.pr_n, pr_n)); HIPCHK(c, up(c, B.pr_nb, pr_nb)); HIPCHK(c, up(c, B.pr_kind, pr_kind));
@@ -514,6 +531,93 @@ int vpl_ba_reset_state(vpl_ctx* c) {
   HIPCHK(c, hipMemcpyAsync(B.ex, B.ex_0, W * 7 * 8, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(B.invd, B.invd_0, W * B.maxP * 8, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(B.plk, B.plk_0, W * B.maxL * 6 * 8, hipMemcpyDeviceToDevice, c->stream));
+  return VPL_OK;
+}
+
+int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt) {
+  return upload_impl(c, nW, win, opt, false);
+}
+
+// FeatureManager::triangulateLine for a batch: upload (every line), k_triangulate, flags + Pluecker vectors back
+int vpl_ba_triangulate_lines(vpl_ctx* c, int nW, vpl_window* win) {
+  if (!c || !win || nW < 1) return VPL_E_INVALID;
+  for (int w = 0; w < nW; ++w)
+    if (win[w].n_lines > 0 && !win[w].line_triangulated) return fail(c, VPL_E_INVALID, "line_triangulated is required");
+  vpl_ba_options opt;
+  vpl_ba_default_options(&opt);
+  opt.marginalization_flag = VPL_MARGIN_NONE;
+  int rc = upload_impl(c, nW, win, &opt, true);
+  if (rc) return rc;
+  DevBatch& B = c->B;
+  hipStream_t s = c->stream;
+  { KTimer t(c, "k_triangulate"); hipLaunchKernelGGL(k_triangulate, dim3(nW), dim3(128), 0, s, B); }
+  HIPCHK(c, hipGetLastError());
+  const size_t W = nW;
+  std::vector<double> plk(W * B.maxL * 6);
+  std::vector<int> tri(W * B.maxL);
+  HIPCHK(c, hipMemcpyAsync(plk.data(), B.plk, plk.size() * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(tri.data(), B.ln_tri, tri.size() * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (size_t w = 0; w < W; ++w) {
+    vpl_window& v = win[w];
+    const std::vector<int>& lmap = c->h_lmap[w];
+    for (size_t dl = 0; dl < lmap.size(); ++dl) {
+      const int l = lmap[dl];
+      if (!v.line_triangulated[l] && tri[w * B.maxL + dl]) {
+        std::memcpy(v.line_plk + (size_t)l * 6, &plk[(w * B.maxL + dl) * 6], 6 * 8);
+        v.line_triangulated[l] = 1;
+      }
+    }
+  }
+  return VPL_OK;
+}
+
+// Estimator::onlyLineOpt for a batch: upload (triangulated lines), k_prep (world orth of the lines), k_line_opt (the LM
+// loop), k_gauge (setLineOrth + removeLineOutlier; the gauge transform is the identity, the poses did not move)
+int vpl_ba_only_line_opt(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt_in, vpl_solve_report* reports) {
+  if (!c || !win || !opt_in || nW < 1) return VPL_E_INVALID;
+  if (c->maxL > LOPT_THREADS) return fail(c, VPL_E_CAPACITY, "onlyLineOpt handles at most 256 lines per window");
+  vpl_ba_options opt = *opt_in;
+  opt.marginalization_flag = VPL_MARGIN_NONE;
+  opt.remove_line_outliers = 1;          // f_manager.removeLineOutlier at the end of onlyLineOpt (estimator.cpp:1037)
+  int rc = upload_impl(c, nW, win, &opt, false);
+  if (rc) return rc;
+  DevBatch& B = c->B;
+  const dim3 grid(nW);
+  hipStream_t s = c->stream;
+  { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(256), PREP_SMEM, s, B); }
+  { KTimer t(c, "k_line_opt"); hipLaunchKernelGGL(k_line_opt, grid, dim3(LOPT_THREADS), 0, s, B); }
+  { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
+  HIPCHK(c, hipGetLastError());
+  const size_t W = nW;
+  std::vector<double> plk(W * B.maxL * 6);
+  std::vector<int> removed(W * B.maxL);
+  std::vector<TrState> tr(W);
+  HIPCHK(c, hipMemcpyAsync(plk.data(), B.plk, plk.size() * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(removed.data(), B.ln_removed, removed.size() * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(tr.data(), B.tr, W * sizeof(TrState), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (size_t w = 0; w < W; ++w) {
+    vpl_window& v = win[w];
+    const std::vector<int>& lmap = c->h_lmap[w];
+    if (v.line_removed)
+      for (int l = 0; l < v.n_lines; ++l) v.line_removed[l] = 0;
+    if (reports) std::memset(&reports[w], 0, sizeof(reports[w]));
+    if (lmap.size() < 4) continue;       // "if (feature_index < 3) return;" -- nothing is touched
+    for (size_t dl = 0; dl < lmap.size(); ++dl) {
+      if (!removed[w * B.maxL + dl]) std::memcpy(v.line_plk + (size_t)lmap[dl] * 6, &plk[(w * B.maxL + dl) * 6], 6 * 8);
+      if (v.line_removed) v.line_removed[lmap[dl]] = removed[w * B.maxL + dl] ? 1 : 0;
+      if (reports) reports[w].n_lines_removed += removed[w * B.maxL + dl] ? 1 : 0;
+    }
+    if (reports) {
+      vpl_solve_report& r = reports[w];
+      r.iterations = tr[w].iter;
+      r.num_successful_steps = tr[w].num_successful;
+      r.termination = tr[w].status == 1 ? 1 : tr[w].status == 2 ? 2 : 0;
+      r.initial_cost = tr[w].initial_cost;
+      r.final_cost = tr[w].x_cost;
+    }
+  }
   return VPL_OK;
 }
 
@@ -584,7 +688,9 @@ int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_
     std::memcpy(v.speed_bias, &sb[w * 99], 99 * 8);
     std::memcpy(v.ex_pose, &ex[w * 7], 7 * 8);
     for (int p = 0; p < v.n_points; ++p) v.inv_depth[p] = invd[w * B.maxP + p];
-    for (int l = 0; l < v.n_lines; ++l) std::memcpy(v.line_plk + (size_t)l * 6, &plk[(w * B.maxL + l) * 6], 6 * 8);
+    const std::vector<int>& lmap = c->h_lmap[w];
+    for (size_t dl = 0; dl < lmap.size(); ++dl)   // erased tracks keep the caller's value (they are gone from f_manager)
+      if (!removed[w * B.maxL + dl]) std::memcpy(v.line_plk + (size_t)lmap[dl] * 6, &plk[(w * B.maxL + dl) * 6], 6 * 8);
     if (reports) {
       vpl_solve_report& r = reports[w];
       std::memset(&r, 0, sizeof(r));
@@ -595,10 +701,12 @@ int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_
       r.final_cost = tr[w].x_cost;
       r.prior_m = mg_m[w];
       r.prior_n = marg ? mg_n[w] : 0;
-      for (int l = 0; l < v.n_lines; ++l) r.n_lines_removed += removed[w * B.maxL + l] ? 1 : 0;
+      for (size_t dl = 0; dl < lmap.size(); ++dl) r.n_lines_removed += removed[w * B.maxL + dl] ? 1 : 0;
     }
-    if (v.line_removed)
-      for (int l = 0; l < v.n_lines; ++l) v.line_removed[l] = removed[w * B.maxL + l] ? 1 : 0;
+    if (v.line_removed) {
+      for (int l = 0; l < v.n_lines; ++l) v.line_removed[l] = 0;
+      for (size_t dl = 0; dl < lmap.size(); ++dl) v.line_removed[lmap[dl]] = removed[w * B.maxL + dl] ? 1 : 0;
+    }
     if (marg && c->h_passthrough[w] >= 0) {
       priors[w] = c->h_pass_priors[c->h_passthrough[w]];
       if (reports) reports[w].prior_n = priors[w].n;
