@@ -1,0 +1,64 @@
+"""Secondary metric of SURVEY 8(d), config 4: frames/s of the whole line front-end -- EDLines on 64 frames 752x480 plus KLT
+line matching of the 63 consecutive pairs -- with the frames resident in HBM.  The detected lines pass through the host
+between the two stages, as they do in the reference (the tracker owns them); that round trip is inside the timed region.
+Prints one JSON line."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.dirname(__file__))
+import numpy as np
+import torch
+import vplines_slam_amd as v
+from bench_edlines import frames
+
+
+def main():
+    n, steps, warm = 64, 10, 2
+    dev = torch.device("cuda", 0)
+    imgs = frames(n)
+    fe = v.frontend.FrontendContext(device=0, max_images=n, width=752, height=480, max_lines=256,
+                                    stream=torch.cuda.current_stream(dev).cuda_stream)
+    fe.match_reserve(n - 1, 4096)
+    fe.upload(imgs)
+    pairs = [(i, i + 1) for i in range(n - 1)]
+
+    def step():
+        fe.detect()
+        fe.synchronize()
+        lines = fe.download()
+        lines = [l[:256] for l in lines]
+        fe.match_upload(pairs, [lines[a] for a, _ in pairs], [lines[b] for _, b in pairs])
+        fe.match_run()
+        fe.synchronize()
+        return lines, fe.match_download()
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lines, (r2c, ok) = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    # device-only share: the kernels of one batch, timed with events
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record(); fe.detect(); e1.record(); fe.match_run(); e2.record()
+    torch.cuda.synchronize(dev)
+    import oracle_api as o
+    tc = time.perf_counter()
+    same = 0
+    for i in range(4):
+        la, lb = o.edlines(imgs[i]), o.edlines(imgs[i + 1])
+        _, ro, _ = o.line_match(imgs[i], imgs[i + 1], la, lb)
+        same += int(len(la) == len(lines[i]) and np.array_equal(ro, r2c[i]))
+    tc = (time.perf_counter() - tc) / 4
+    print(json.dumps({"metric": "line front-end frames/s (EDLines + KLT matching, 752x480, batch 64)", "value": n / dt,
+                      "unit": "frames/s", "ms_per_batch": 1e3 * dt, "device_ms_detect": e0.elapsed_time(e1),
+                      "device_ms_match": e1.elapsed_time(e2), "host_round_trip_ms": 1e3 * dt - e0.elapsed_time(e2),
+                      "mean_lines_per_frame": float(np.mean([len(l) for l in lines])),
+                      "mean_matches_per_pair": float(np.mean([(r >= 0).sum() for r in r2c])),
+                      "cpu_oracle_frames_per_s_1thread": 1.0 / tc, "identical_on_4_pairs": same}))
+    fe.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,33 @@ def default_match_param(illumination_adapt=True, topological_filter=True):
     return MatchParam(10, 0.5, 0.4, 3.0, 40.0, int(illumination_adapt), int(topological_filter), 15.0, 0.2, 0.05)
 
 
+# numpy view of vpl_line (56 bytes) for bulk packing / unpacking without per-line Python loops
+LINE_DTYPE = np.dtype({"names": ["line_endpoint", "line_equation", "center", "length"],
+                       "formats": [("<f4", 4), ("<f8", 3), ("<f4", 2), "<f4"],
+                       "offsets": [0, 16, 40, 48], "itemsize": 56})
+assert LINE_DTYPE.itemsize == C.sizeof(Line)
+
+
+def lines_to_records(a, out):
+    """[n,10] doubles (x1,y1,x2,y2,eq0..2,cx,cy,len) -> out[:n] (LINE_DTYPE records)"""
+    n = len(a)
+    if n:
+        a = np.asarray(a, np.float64)
+        out["line_endpoint"][:n] = a[:, 0:4]
+        out["line_equation"][:n] = a[:, 4:7]
+        out["center"][:n] = a[:, 7:9]
+        out["length"][:n] = a[:, 9]
+
+
+def records_to_lines(rec):
+    out = np.empty((len(rec), 10))
+    out[:, 0:4] = rec["line_endpoint"]
+    out[:, 4:7] = rec["line_equation"]
+    out[:, 7:9] = rec["center"]
+    out[:, 9] = rec["length"]
+    return out
+
+
 def default_param():
     """production values: line_feature_tracker_node.cpp:203 / config/euroc/euroc_config.yaml:84-87"""
     p = EdlineParam()
@@ -118,21 +145,11 @@ class FrontendContext:
         self._check(self.lib.vpl_fe_synchronize(self.h), "vpl_fe_synchronize")
 
     def download(self):
-        lines = (Line * (self.n * self.max_lines))()
+        rec = np.zeros(self.n * self.max_lines, LINE_DTYPE)
         counts = (C.c_int * self.n)()
-        self._check(self.lib.vpl_edlines_download(self.h, self.n, lines, counts), "vpl_edlines_download")
-        out = []
-        for i in range(self.n):
-            m = counts[i]
-            arr = np.zeros((m, 10))
-            for k in range(m):
-                ln = lines[i * self.max_lines + k]
-                arr[k, 0:4] = ln.line_endpoint[:]
-                arr[k, 4:7] = ln.line_equation[:]
-                arr[k, 7:9] = ln.center[:]
-                arr[k, 9] = ln.length
-            out.append(arr)
-        return out
+        self._check(self.lib.vpl_edlines_download(self.h, self.n, rec.ctypes.data_as(C.POINTER(Line)), counts),
+                    "vpl_edlines_download")
+        return [records_to_lines(rec[i * self.max_lines:i * self.max_lines + counts[i]]) for i in range(self.n)]
 
     def detect_batch(self, images, param=None):
         self.upload(images)
@@ -167,19 +184,13 @@ class FrontendContext:
         self._check(self.lib.vpl_match_reserve(self.h, max_pairs, max_kps), "vpl_match_reserve")
 
     def _pack_lines(self, per_pair):
-        arr = (Line * (len(per_pair) * self.max_lines))()
+        rec = np.zeros(len(per_pair) * self.max_lines, LINE_DTYPE)
         cnt = (C.c_int * len(per_pair))()
         for i, L in enumerate(per_pair):
             cnt[i] = len(L)
-            if len(L) > self.max_lines:
-                continue   # the library reports VPL_E_CAPACITY
-            for k, r in enumerate(L):
-                ln = arr[i * self.max_lines + k]
-                ln.line_endpoint[:] = [float(x) for x in r[0:4]]
-                ln.line_equation[:] = [float(x) for x in r[4:7]]
-                ln.center[:] = [float(x) for x in r[7:9]]
-                ln.length = float(r[9])
-        return arr, cnt
+            if len(L) <= self.max_lines:   # otherwise the library reports VPL_E_CAPACITY
+                lines_to_records(L, rec[i * self.max_lines:(i + 1) * self.max_lines])
+        return rec, cnt
 
     def match_upload(self, pairs, lines_ref, lines_cur):
         """pairs: list of (ref image index, cur image index); lines_*: per pair [n,10] arrays"""
@@ -189,19 +200,18 @@ class FrontendContext:
         lr, nr = self._pack_lines(lines_ref)
         lc, nc = self._pack_lines(lines_cur)
         self._nref = [len(L) for L in lines_ref]
-        self._check(self.lib.vpl_match_upload(self.h, self.n_pairs, ri, ci, lr, nr, lc, nc), "vpl_match_upload")
+        self._check(self.lib.vpl_match_upload(self.h, self.n_pairs, ri, ci, lr.ctypes.data_as(C.POINTER(Line)), nr,
+                                              lc.ctypes.data_as(C.POINTER(Line)), nc), "vpl_match_upload")
 
     def match_run(self, param=None):
         self._mparam = param or default_match_param()
         self._check(self.lib.vpl_match_run(self.h, C.byref(self._mparam)), "vpl_match_run")
 
     def match_download(self):
-        r2c = (C.c_int * (self.n_pairs * self.max_lines))()
-        for i in range(len(r2c)):
-            r2c[i] = -2
+        a = np.full((self.n_pairs, self.max_lines), -2, np.int32)
         ok = (C.c_int * self.n_pairs)()
-        self._check(self.lib.vpl_match_download(self.h, self.n_pairs, r2c, ok), "vpl_match_download")
-        a = np.ctypeslib.as_array(r2c).reshape(self.n_pairs, self.max_lines)
+        self._check(self.lib.vpl_match_download(self.h, self.n_pairs, a.ctypes.data_as(C.POINTER(C.c_int)), ok),
+                    "vpl_match_download")
         return [a[i, :self._nref[i]].copy() for i in range(self.n_pairs)], [int(x) for x in ok]
 
     def match_batch(self, images, pairs, lines_ref, lines_cur, param=None):
