@@ -139,8 +139,12 @@ __global__ __launch_bounds__(128) void k_gauge(DevBatch B) {
 // one barrier per step.  On exit: A holds G (n x rank), lam[k] = |g_k|^2, perm[t] = original index of row t.
 // Returns the rank.  Needs blockDim.x >= 8 * ((n + 1) / 2).  rel_tol: pivots <= max(n eps, rel_tol) * max_i a_ii stop the
 // factorisation (the trailing block is then treated as zero).
-__device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* lam, double* red, int* iflag,
-                                   double rel_tol) {
+// Cholesky with diagonal pivoting of the PSD matrix A (LDS, full storage): P A P^T = L L^T, L = n x rank lower trapezoidal
+// left in A (upper part zeroed), perm[t] = original index of row t.  An optional right-hand side c (length n, permuted in
+// step) rides along: on exit c[k] = y_k for k < rank, where L(0:rank,0:rank) y = (P c)(0:rank).
+// Stops at the first pivot <= max(abs_tol, max(n eps, rel_tol) * max_i a_ii); the trailing block is then treated as zero.
+__device__ int psd_pivoted_cholesky(double* A, int n, int ld, int* perm, double* red, int* iflag, double rel_tol,
+                                    double abs_tol, double* c) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
   for (int i = tid; i < n; i += T) perm[i] = i;
   __syncthreads();
@@ -168,13 +172,16 @@ __device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* 
     const double piv = red[0];
     // dpstrf-style stopping rule with a caller-supplied relative tolerance: a pivot at the noise level of the matrix
     // must not be accepted -- dividing a column of noise by the root of a noise pivot fabricates an O(1) direction
-    if (k == 0) tol = fmax((double)n * 2.220446049250313e-16, rel_tol) * piv;
+    if (k == 0) tol = fmax(abs_tol, fmax((double)n * 2.220446049250313e-16, rel_tol) * piv);
     if (!(piv > tol)) { rank = k; break; }
     if (p != k) {   // symmetric swap k <-> p (rows, then columns), full storage
       for (int c = tid; c < n; c += T) { const double t = A[k * ld + c]; A[k * ld + c] = A[p * ld + c]; A[p * ld + c] = t; }
       __syncthreads();
       for (int r = tid; r < n; r += T) { const double t = A[r * ld + k]; A[r * ld + k] = A[r * ld + p]; A[r * ld + p] = t; }
-      if (tid == 0) { const int t = perm[k]; perm[k] = perm[p]; perm[p] = t; }
+      if (tid == 0) {
+        const int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+        if (c) { const double tc = c[k]; c[k] = c[p]; c[p] = tc; }
+      }
       __syncthreads();
     }
     const double lkk = sqrt(piv);
@@ -184,7 +191,12 @@ __device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* 
       const int i = k + 1 + it / (n - k - 1), j = k + 1 + it % (n - k - 1);
       A[i * ld + j] -= A[i * ld + k] * A[j * ld + k] / piv;
     }
+    if (c) {   // forward substitution rides along: c_i -= a_ik c_k / piv, then y_k = c_k / sqrt(piv)
+      const double ck = c[k];
+      for (int i = k + 1 + tid; i < n; i += T) c[i] -= A[i * ld + k] * ck / piv;
+    }
     __syncthreads();
+    if (c && tid == 0) c[k] *= inv;
     for (int i = k + tid; i < n; i += T) {
       A[i * ld + k] = (i == k) ? lkk : A[i * ld + k] * inv;
       if (i > k) A[k * ld + i] = 0.0;   // upper part of row k is not part of L
@@ -195,6 +207,13 @@ __device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* 
   // columns rank..n-1 do not exist
   for (int it = tid; it < n * (n - rank); it += T) A[(it / (n - rank)) * ld + rank + it % (n - rank)] = 0.0;
   __syncthreads();
+  return rank;
+}
+
+__device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* lam, double* red, int* iflag,
+                                   double rel_tol) {
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int rank = psd_pivoted_cholesky(A, n, ld, perm, red, iflag, rel_tol, 0.0, nullptr);
   // ---- one-sided Jacobi on the rank columns ----
   const int m = (rank + 1) & ~1, half = m / 2;
   const int P = tid >> 3, sub = tid & 7;
@@ -408,24 +427,51 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     E15[i * 17 + j] = 0.5 * (Ad[i * ldd + j] + Ad[j * ldd + i]);
   }
   __syncthreads();
-  psd_spectral_factor(E15, md, 17, perm, lam, red, s_flag, 0.0);
-  VPL_STAMP(B, w, 34);
-  // tmp(n x 15) = Arm * Amm^+ :  first Y = Arm * B (n x 15), then tmp = (Y ./ lambda^2) * B^T
+  // Positive definite Amm (every eigenvalue far above the reference's 1e-8): the pseudo-inverse is the inverse and two
+  // triangular solves per row of Arm replace the eigen-decomposition.  A rank-deficient Amm (a pivot at the rounding
+  // level) takes the spectral route, which reproduces the eigenvalue test of :334-346.
   double* Y = tile;   // n x 16 scratch (tile is free now)
-  for (int it = tid; it < n * md; it += T) {
-    const int i = it / md, k = it % md;
-    double s = 0;
-    for (int t = 0; t < md; ++t) s += Ad[(md + i) * ldd + perm[t]] * E15[t * 17 + k];
-    Y[i * 16 + k] = lam[k] > kMargEps ? s / (lam[k] * lam[k]) : 0.0;
-  }
+  for (int it = tid; it < md * md; it += T) Y[it] = E15[(it / md) * 17 + it % md];   // keep a copy for the fallback
   __syncthreads();
-  for (int it = tid; it < n * md; it += T) {
-    const int i = it / md, t = it % md;   // column perm[t] of tmp
-    double s = 0;
-    for (int k = 0; k < md; ++k) s += Y[i * 16 + k] * E15[t * 17 + k];
-    tmp[i * 16 + perm[t]] = s;
+  const int rank_mm = psd_pivoted_cholesky(E15, md, 17, perm, red, s_flag, 0.0, kMargEps, nullptr);
+  if (rank_mm == md) {
+    VPL_STAMP(B, w, 34);
+    for (int i = tid; i < n; i += T) {   // tmp(i, :) = Arm(i, :) Amm^-1 :  L L^T x = P a
+      double x[15];
+      for (int t = 0; t < md; ++t) {
+        double s2 = Ad[(md + i) * ldd + perm[t]];
+        for (int k = 0; k < t; ++k) s2 -= E15[t * 17 + k] * x[k];
+        x[t] = s2 / E15[t * 17 + t];
+      }
+      for (int t = md - 1; t >= 0; --t) {
+        double s2 = x[t];
+        for (int k = t + 1; k < md; ++k) s2 -= E15[k * 17 + t] * x[k];
+        x[t] = s2 / E15[t * 17 + t];
+      }
+      for (int t = 0; t < md; ++t) tmp[i * 16 + perm[t]] = x[t];
+    }
+    __syncthreads();
+  } else {
+    for (int it = tid; it < md * md; it += T) E15[(it / md) * 17 + it % md] = Y[it];
+    __syncthreads();
+    psd_spectral_factor(E15, md, 17, perm, lam, red, s_flag, 0.0);
+    VPL_STAMP(B, w, 34);
+    // tmp(n x md) = Arm * Amm^+ :  first Y = Arm * B (n x md), then tmp = (Y ./ lambda^2) * B^T
+    for (int it = tid; it < n * md; it += T) {
+      const int i = it / md, k = it % md;
+      double s = 0;
+      for (int t = 0; t < md; ++t) s += Ad[(md + i) * ldd + perm[t]] * E15[t * 17 + k];
+      Y[i * 16 + k] = lam[k] > kMargEps ? s / (lam[k] * lam[k]) : 0.0;
+    }
+    __syncthreads();
+    for (int it = tid; it < n * md; it += T) {
+      const int i = it / md, t = it % md;   // column perm[t] of tmp
+      double s = 0;
+      for (int k = 0; k < md; ++k) s += Y[i * 16 + k] * E15[t * 17 + k];
+      tmp[i * 16 + perm[t]] = s;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // G <- Arr - tmp * Amr ; b <- brr - tmp * bmm
   double* Aout = B.mg_A + (size_t)w * MAXKEEP * MAXKEEP;
   double* bout = B.mg_b + (size_t)w * MAXKEEP;
@@ -455,28 +501,25 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     if (i < j) G[i * ldm + j] = G[j * ldm + i];
   }
   __syncthreads();
-  // ---- spectral factor of the kept block (:349-357): J0 = sqrt(S) V^T = B^T, r0 = S^-1/2 V^T b ------
-  VPL_STAMP(B, w, 35);
+  // ---- factor of the kept block (:349-357) ------------------------------------------------------------------
+  // The reference sets J0 = sqrt(S) V^T, r0 = S^-1/2 V^T b from A = V S V^T.  The prior enters every later computation
+  // only through |r0 + J0 dx|^2, i.e. through J0^T J0 = A and J0^T r0 = (b projected on range A); any J0' = Q J0,
+  // r0' = Q r0 with Q orthogonal is the same prior.  The pivoted Cholesky factor is such a pair and needs no
+  // eigen-iteration:  P A P^T = L L^T,  J0 = L^T P^T,  L(0:r,0:r) r0 = (P b)(0:r)  (the forward substitution rides along).
   // The kept block is the difference of numbers five orders larger (A = Arr - Arm Amm^+ Amr after the landmark
   // elimination): what the reference's eigen-solver reports below ~1e-10 lambda_max of it is rounding noise of either
-  // sign (it keeps the positive part above 1e-8 with a negligible weight).  Directions below 1e-9 lambda_max are
-  // dropped here.
-  psd_spectral_factor(G, n, ldm, perm, lam, red, s_flag, kMargNoiseRel);
+  // sign (it keeps the positive part above 1e-8 with a negligible weight).  Pivots below max(1e-8, 1e-9 max diagonal)
+  // end the factorisation; the trailing block is treated as zero.
+  VPL_STAMP(B, w, 35);
+  const int rank = psd_pivoted_cholesky(G, n, ldm, perm, red, s_flag, kMargNoiseRel, kMargEps, bv);
   VPL_STAMP(B, w, 36);
   double* J0 = B.mg_J0 + (size_t)w * MAXKEEP * MAXKEEP;
   double* r0 = B.mg_r0 + (size_t)w * MAXKEEP;
   for (int it = tid; it < n * n; it += T) {
-    const int k = it / n, t = it % n;   // J0[k][perm[t]] = G[t][k]
-    J0[k * n + perm[t]] = lam[k] > kMargEps ? G[t * ldm + k] : 0.0;
+    const int k = it / n, t = it % n;   // J0[k][perm[t]] = L[t][k]
+    J0[k * n + perm[t]] = (k < rank && t >= k) ? G[t * ldm + k] : 0.0;
   }
-  for (int k = tid; k < n; k += T) {
-    double vb = 0;
-    if (lam[k] > kMargEps) {
-      for (int t = 0; t < n; ++t) vb += G[t * ldm + k] * bv[perm[t]];
-      vb /= lam[k];
-    }
-    r0[k] = vb;
-  }
+  for (int k = tid; k < n; k += T) r0[k] = k < rank ? bv[k] : 0.0;
   // x0 of the kept blocks: the linearisation point (preMarginalize copies, :110-129)
   if (tid < nb) {
     const int kind = B.mg_kind[(size_t)w * MAXPB + tid];
