@@ -46,7 +46,8 @@ __device__ __forceinline__ int cam2vis(int c) {
 
 // decode a packed lower-triangular index into (r, c), r >= c
 __device__ __forceinline__ void tri_decode(int idx, int& r, int& c) {
-  int rr = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+  // single-precision root (one v_sqrt_f32) as the first guess; the two loops make it exact for any idx < 2^23
+  int rr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
   while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
   while (rr * (rr + 1) / 2 > idx) --rr;
   r = rr;

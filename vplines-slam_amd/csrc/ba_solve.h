@@ -196,51 +196,100 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
       const int nch = nchP + nchL;
       double* buf0 = S;
       double* buf1 = S + CROWS * CW;
+      // Per-landmark constants of the row transform go to LDS once (behind the two staging buffers): row scale and
+      // e-value of the points, Cholesky factor / scale / e-vector of the lines.
+      double* pS = S + 2 * CROWS * CW;        // nP   s / sqrt(A)
+      double* pE = pS + B.maxP;               // nP   e = u / (s / sqrt(A))
+      double* lC = pE + B.maxP;               // nL x 10
+      double* lS = lC + 10 * B.maxL;          // nL x 4   jacobi scale
+      double* lE = lS + 4 * B.maxL;           // nL x 4   e = C^T (u ./ s),  u = s g~ / d  =>  u/s = g~/d
+      for (int p = tid; p < nP; p += T) {
+        const double smv = ggn[LP + p];
+        pS[p] = smv;
+        pE[p] = (gscale[LP + p] * ggrad[LP + p] / gdiag[LP + p]) / smv;
+      }
+      for (int l = tid; l < nL; l += T) {
+        double C[10], us[4];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { C[q] = lch[l * 10 + q]; lC[l * 10 + q] = C[q]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          lS[4 * l + a] = gscale[LL + 4 * l + a];
+          us[a] = ggrad[LL + 4 * l + a] / gdiag[LL + 4 * l + a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          double s2 = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (q >= a) s2 += C[tri(q, a)] * us[q];
+          lE[4 * l + a] = s2;
+        }
+      }
+      __syncthreads();
+      // Loads first, arithmetic and LDS stores after: a loop that stores each element before loading the next one
+      // pays the L2 / HBM latency once per element (10 times per chunk); batched, twice per chunk.
       auto stage = [&](int ch, double* buf) {
         if (ch < nchP) {
           const int r0 = ch * CROWS, cnt = min(CROWS, nP - r0);
-          for (int it = tid; it < CROWS * CW; it += T) {
-            const int rr = it / CW, c = it - rr * CW;
-            double v = 0.0;
-            if (rr < cnt && c < 74) {
-              const int p = r0 + rr;
-              const size_t pi = (size_t)w * B.maxP + p;
-              const double smv = ggn[LP + p];
-              if (c < NV) v = smv * B.Wp[pi * NV + c];
-              else if (c == NV) v = smv * B.gp[pi];
-              else v = (gscale[LP + p] * ggrad[LP + p] / gdiag[LP + p]) / smv;   // e = u / (s/sqrt(A))
+          constexpr int NIT = CROWS * CW / SOLVE_THREADS / 2;   // 2 x 5 elements per thread
+#pragma unroll 1
+          for (int half = 0; half < 2; ++half) {
+            double raw[NIT];
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+              const int it = tid + (half * NIT + k) * T;
+              const int rr = it / CW, c = it - rr * CW;
+              raw[k] = 0.0;
+              if (rr < cnt && c <= NV) {
+                const size_t pi = (size_t)w * B.maxP + r0 + rr;
+                raw[k] = c < NV ? B.Wp[pi * NV + c] : B.gp[pi];
+              }
             }
-            buf[it] = v;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+              const int it = tid + (half * NIT + k) * T;
+              const int rr = it / CW, c = it - rr * CW;
+              double v = 0.0;
+              if (rr < cnt && c < 74) v = c <= NV ? pS[r0 + rr] * raw[k] : pE[r0 + rr];
+              buf[it] = v;
+            }
           }
         } else {
           const int l0 = (ch - nchP) * (CROWS / 4), cnt = min(CROWS / 4, nL - l0);
-          for (int it = tid; it < (CROWS / 4) * CW; it += T) {
+          constexpr int NIT = ((CROWS / 4) * CW + SOLVE_THREADS - 1) / SOLVE_THREADS;   // 3 items per thread
+          double wv4[NIT][4];
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) {
+            const int it = tid + k * T;
+            const int ll = it / CW, c = it - ll * CW;
+            const bool on = it < (CROWS / 4) * CW && ll < cnt && c <= NV;
+            const size_t li = (size_t)w * B.maxL + l0 + (on ? ll : 0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              wv4[k][a] = 0.0;
+              if (on) wv4[k][a] = c < NV ? B.Wl[(li * 4 + a) * NV + c] : B.gl[li * 4 + a];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) {
+            const int it = tid + k * T;
+            if (it >= (CROWS / 4) * CW) break;
             const int ll = it / CW, c = it - ll * CW;
             double x[4] = {0, 0, 0, 0};
             if (ll < cnt && c < 74) {
               const int l = l0 + ll;
-              const size_t li = (size_t)w * B.maxL + l;
-              const double* C = lch + l * 10;
               if (c <= NV) {
+                const double* C = lC + l * 10;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                  const double v = c < NV ? B.Wl[(li * 4 + a) * NV + c] : B.gl[li * 4 + a];
-                  double s2 = gscale[LL + 4 * l + a] * v;
+                  double s2 = lS[4 * l + a] * wv4[k][a];
 #pragma unroll
-                  for (int k = 0; k < 4; ++k) if (k < a) s2 -= C[tri(a, k)] * x[k];
+                  for (int q = 0; q < 4; ++q) if (q < a) s2 -= C[tri(a, q)] * x[q];
                   x[a] = s2 / C[tri(a, a)];
                 }
-              } else {   // e = C^T (u ./ s),  u = s g~ / d  =>  u/s = g~/d
-                double us[4];
+              } else {
 #pragma unroll
-                for (int a = 0; a < 4; ++a) us[a] = ggrad[LL + 4 * l + a] / gdiag[LL + 4 * l + a];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                  double s2 = 0;
-#pragma unroll
-                  for (int k = 0; k < 4; ++k) if (k >= a) s2 += C[tri(k, a)] * us[k];
-                  x[a] = s2;
-                }
+                for (int a = 0; a < 4; ++a) x[a] = lE[4 * l + a];
               }
             }
 #pragma unroll
@@ -271,13 +320,25 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
       for (int idx = tid; idx < NAP; idx += T) S[idx] = 0.0;
       __syncthreads();
       double qq = 0.0;
-      for (int idx = tid; idx < NCP; idx += T) {
-        int r, c;
-        tri_decode(idx, r, c);
-        const double h = Hcc[idx];
-        S[tix(r, c)] = h;
-        if ((r >> 4) == (c >> 4)) S[tix(c, r)] = h;   // diagonal tiles are kept as full squares
-        qq += (r == c ? 1.0 : 2.0) * uc[r] * h * uc[c];
+      for (int base = 0; base < NCP; base += 8 * T) {   // eight loads in flight per thread, then the LDS scatter
+        double hh[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * T + tid;
+          hh[u] = idx < NCP ? Hcc[idx] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * T + tid;
+          if (idx < NCP) {
+            int r, c;
+            tri_decode(idx, r, c);
+            const double h = hh[u];
+            S[tix(r, c)] = h;
+            if ((r >> 4) == (c >> 4)) S[tix(c, r)] = h;   // diagonal tiles are kept as full squares
+            qq += (r == c ? 1.0 : 2.0) * uc[r] * h * uc[c];
+          }
+        }
       }
       for (int c = tid; c < NC; c += T) S[tix(NC, c)] = gc[c];
       if (tid < 5) S[tix(NC + tid, NC + tid)] = 1.0;   // padding rows 171..175: unit pivots, never used
