@@ -163,6 +163,8 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   c->maxPO = max_point_obs > 0 ? max_point_obs : 1;
   c->maxL = max_lines > 0 ? max_lines : 1;
   c->maxLO = max_line_obs > 0 ? max_line_obs : 1;
+  // k_solve keeps 2 doubles per point and 18 per line in the LDS space behind its two staging buffers
+  if (2 * c->maxP + 18 * c->maxL > NAP - 2 * CROWS * CW) { delete c; return VPL_E_CAPACITY; }
   DevBatch& B = c->B;
   std::memset(&B, 0, sizeof(B));
   B.maxP = c->maxP; B.maxPO = c->maxPO; B.maxL = c->maxL; B.maxLO = c->maxLO;
