@@ -524,40 +524,55 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   // ---- assemble the packed cam Hessian and gradient in HBM -----------------------------------
   double* Hout = B.Hcc + (size_t)w * NCP;
   const double* pH = B.pr_H + (size_t)w * MAXPN * MAXPN;
-  for (int idx = tid; idx < NCP; idx += T) {
-    int r, c;
-    tri_decode(idx, r, c);
-    double v = 0.0;
-    const int vr = cam2vis(r), vc = cam2vis(c);
-    if (vr >= 0 && vc >= 0) v += Hv[vr * NV + vc];
-    if (r < 165) {
-      const int fr = r / 15, fc = c / 15;
-      if (fc == fr || fc == fr - 1) {
-        const int t0 = fr - 1;
-        if (t0 >= 0 && imuact[t0]) {
-          const double* J = imuJ + 450 * t0;
-          const int a = r - 15 * t0, b = c - 15 * t0;
-          double s = 0;
+  for (int base = 0; base < NCP; base += 8 * T) {   // the prior's share first (8 global loads in flight), then the rest
+    double ph[8];
+    int rr[8], cc[8];
 #pragma unroll
-          for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b];
-          v += s;
-        }
-        if (fc == fr && fr < 10 && imuact[fr]) {
-          const double* J = imuJ + 450 * fr;
-          const int a = r - 15 * fr, b = c - 15 * fr;
-          double s = 0;
-#pragma unroll
-          for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b];
-          v += s;
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * T + tid;
+      ph[u] = 0.0;
+      rr[u] = 0; cc[u] = 0;
+      if (idx < NCP) {
+        tri_decode(idx, rr[u], cc[u]);
+        if (n > 0) {
+          const int pr = invmap[rr[u]], pc = invmap[cc[u]];
+          if (pr >= 0 && pc >= 0) ph[u] = pH[(size_t)pr * n + pc];
         }
       }
     }
-    if (n > 0) {
-      const int pr = invmap[r], pc = invmap[c];
-      if (pr >= 0 && pc >= 0) v += pH[(size_t)pr * n + pc];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * T + tid;
+      if (idx >= NCP) continue;
+      const int r = rr[u], c = cc[u];
+      double v = ph[u];
+      const int vr = cam2vis(r), vc = cam2vis(c);
+      if (vr >= 0 && vc >= 0) v += Hv[vr * NV + vc];
+      if (r < 165) {
+        const int fr = r / 15, fc = c / 15;
+        if (fc == fr || fc == fr - 1) {
+          const int t0 = fr - 1;
+          if (t0 >= 0 && imuact[t0]) {
+            const double* J = imuJ + 450 * t0;
+            const int a = r - 15 * t0, b = c - 15 * t0;
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b];
+            v += s;
+          }
+          if (fc == fr && fr < 10 && imuact[fr]) {
+            const double* J = imuJ + 450 * fr;
+            const int a = r - 15 * fr, b = c - 15 * fr;
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b];
+            v += s;
+          }
+        }
+      }
+      if (!ex_free && r >= 165) v = 0.0;
+      Hout[idx] = v;
     }
-    if (!ex_free && r >= 165) v = 0.0;
-    Hout[idx] = v;
   }
   for (int r = tid; r < NC; r += T) {
     double v = 0.0;
