@@ -30,10 +30,13 @@ constexpr double kMinRelDecrease = 1e-3, kFuncTol = 1e-6, kParamTol = 1e-8, kMin
 constexpr int kMaxInvalid = 5;
 
 __device__ __forceinline__ int tcol2row(int a) { return a < NV ? vis2cam(a) : NC; }
+// Offset of element (r, c) inside a 16x16 tile.  Rows are XOR-swizzled: a column read by 16 lanes (the MFMA operands,
+// one lane per row in the triangular solves) would otherwise land in one LDS bank pair.
+__device__ __forceinline__ int tsw(int r, int c) { return (r << 4) + (c ^ r); }
 // tile-major index of element (r, c), r >= c (or both inside a diagonal tile)
 __device__ __forceinline__ int tix(int r, int c) {
   const int I = r >> 4, J = c >> 4;
-  return ((I * (I + 1) / 2 + J) << 8) + ((r & 15) << 4) + (c & 15);
+  return ((I * (I + 1) / 2 + J) << 8) + tsw(r & 15, c & 15);
 }
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -58,6 +61,39 @@ __device__ __forceinline__ void chol4(double* A, bool& ok) {   // packed lower 4
 #pragma unroll
       for (int k = 0; k < 4; ++k) if (k < j) s2 -= A[tri(i, k)] * A[tri(j, k)];
       A[tri(i, j)] = s2 / d;
+    }
+  }
+}
+
+// cross-lane helpers of the register-resident diagonal-tile factorisation
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {   // srclane uniform (compile-time after unrolling)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+template <int J>
+__device__ __forceinline__ double swizzle_row_f64(double v) {   // value of lane (lane & 48) | J: ds_swizzle, bit-mask mode
+  constexpr int pat = (J << 5) | 0x10;                           // and_mask 0x10 keeps the row group inside the 32-lane half
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+  return __hiloint2double(hi, lo);
+}
+
+// one column step of the right-looking factorisation of the 16x16 diagonal tile held in registers
+template <int J>
+__device__ __forceinline__ void diag_tile_step(double (&d)[4], int r4, int cc, int ncol, double& pivc, bool& bad) {
+  if (J < ncol && !bad) {
+    const double ajj = readlane_f64(d[J >> 2], ((J & 3) << 4) | J);
+    if (!(ajj > 0.0)) {
+      bad = true;
+    } else {
+      if (cc == J) pivc = ajj;
+      const double f = __shfl(d[J >> 2], ((J & 3) << 4) | cc, 64) * (1.0 / ajj);   // D[J][cc] / a_JJ
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double cv = swizzle_row_f64<J>(d[v]);                                 // D[r4 + 4v][J]
+        if (r4 + 4 * v > J && cc > J) d[v] -= cv * f;
+      }
     }
   }
 }
@@ -369,7 +405,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
       alpha = a1 / (q + qq);   // DoglegStrategy::ComputeCauchyPoint
       // scale to the Jacobi-scaled space and add the LM diagonal
       for (int idx = tid; idx < NAP; idx += T) {
-        const int tl = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
+        const int tl = idx >> 8, rr = (idx >> 4) & 15, cc = (idx & 15) ^ rr;   // physical slot -> logical column
         int I, J;
         tri_decode(tl, I, J);
         const int r = 16 * I + rr, c = 16 * J + cc;
@@ -390,62 +426,68 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
       //   (b) factor the diagonal tile (one wave, 16 column steps)
       //   (c) rows below: x = a L(K,K)^-T, one lane per row
       // The rhs row (row NC, inside tile row 10) rides along: forward substitution for free.
+#ifdef VPL_STAMPS
+      long long ta = 0, tb = 0, tc = 0, t0 = __builtin_readcyclecounter();
+#endif
       for (int K = 0; K < NT16; ++K) {
         if (K > 0) {
           for (int I = K + wv; I < NT16; I += SOLVE_THREADS / 64) {
             const int m = lane & 15, kk = lane >> 4;
             double* Ct = S + ((I * (I + 1) / 2 + K) << 8);
             v4d c;
-            c.x = Ct[kk * 16 + m]; c.y = Ct[(kk + 4) * 16 + m]; c.z = Ct[(kk + 8) * 16 + m]; c.w = Ct[(kk + 12) * 16 + m];
+            c.x = Ct[tsw(kk, m)]; c.y = Ct[tsw(kk + 4, m)]; c.z = Ct[tsw(kk + 8, m)]; c.w = Ct[tsw(kk + 12, m)];
             for (int J = 0; J < K; ++J) {
               const double* Ai = S + ((I * (I + 1) / 2 + J) << 8);
               const double* Bk = S + ((K * (K + 1) / 2 + J) << 8);
 #pragma unroll
               for (int ks = 0; ks < 4; ++ks) {
-                const double av = -Ai[m * 16 + 4 * ks + kk];
-                const double bv = Bk[m * 16 + 4 * ks + kk];
+                const double av = -Ai[tsw(m, 4 * ks + kk)];
+                const double bv = Bk[tsw(m, 4 * ks + kk)];
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
               }
             }
-            Ct[kk * 16 + m] = c.x; Ct[(kk + 4) * 16 + m] = c.y; Ct[(kk + 8) * 16 + m] = c.z; Ct[(kk + 12) * 16 + m] = c.w;
+            Ct[tsw(kk, m)] = c.x; Ct[tsw(kk + 4, m)] = c.y; Ct[tsw(kk + 8, m)] = c.z; Ct[tsw(kk + 12, m)] = c.w;
           }
           __syncthreads();
         }
-        if (wv == 0) {   // diagonal tile: right-looking 16x16, lanes tile the trailing block
+#ifdef VPL_STAMPS
+        { const long long t1 = __builtin_readcyclecounter(); ta += t1 - t0; t0 = t1; }
+#endif
+        if (wv == 0) {
+          // Diagonal tile in registers: lane (r4, cc) holds rows r4, r4+4, r4+8, r4+12 of column cc of the (symmetric)
+          // tile.  Per column step the pivot comes by v_readlane, the pivot column of the lane's rows by ds_swizzle inside
+          // its 16-lane row group, the pivot row entry D[j][cc] (= D[cc][j]) by one ds_bpermute -- no LDS round trips.
           double* D = S + ((K * (K + 1) / 2 + K) << 8);
-          const int r4 = lane >> 4, cc = lane & 15;   // lane handles rows r4, r4+4, r4+8, r4+12 of column cc
-          for (int j = 0; j < 16; ++j) {
-            const int gj = 16 * K + j;
-            if (gj >= NC) break;
-            const double ajj = D[j * 16 + j];
-            if (!(ajj > 0.0)) { if (lane == 0) flag[0] = 1; break; }
-            const double inv = 1.0 / ajj;
-            const double lcj = D[cc * 16 + j];
+          const int r4 = lane >> 4, cc = lane & 15;
+          double d[4];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const int r = r4 + 4 * v;
-              if (r > j && cc > j && cc <= r) D[r * 16 + cc] -= D[r * 16 + j] * lcj * inv;
+          for (int v = 0; v < 4; ++v) d[v] = D[tsw(r4 + 4 * v, cc)];
+          const int ncol = min(16, NC - 16 * K);
+          double pivc = 1.0;
+          bool bad = false;
+#define VPL_DSTEP(J) diag_tile_step<J>(d, r4, cc, ncol, pivc, bad);
+          VPL_DSTEP(0) VPL_DSTEP(1) VPL_DSTEP(2) VPL_DSTEP(3) VPL_DSTEP(4) VPL_DSTEP(5) VPL_DSTEP(6) VPL_DSTEP(7)
+          VPL_DSTEP(8) VPL_DSTEP(9) VPL_DSTEP(10) VPL_DSTEP(11) VPL_DSTEP(12) VPL_DSTEP(13) VPL_DSTEP(14) VPL_DSTEP(15)
+#undef VPL_DSTEP
+          if (bad) {
+            if (lane == 0) flag[0] = 1;
+          } else {
+            // scale columns: L_ij = a_ij / sqrt(a_jj); publish 1/L_jj
+            const double sq = sqrt(pivc);
+            if (cc < ncol) {
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const int r = r4 + 4 * v;
+                if (r > cc) D[tsw(r, cc)] = d[v] / sq;
+                else if (r == cc) { const double id = 1.0 / sq; isd[16 * K + cc] = id; D[tsw(r, cc)] = 1.0 / id; }
+              }
             }
-            __builtin_amdgcn_wave_barrier();
           }
-          // scale columns: L_ij = a_ij / sqrt(a_jj); publish 1/L_jj
-          for (int it = lane; it < 256; it += 64) {
-            const int r = it >> 4, c = it & 15;
-            const int gc2 = 16 * K + c;
-            if (gc2 < NC && r >= c) {
-              const double d = sqrt(D[c * 16 + c]);
-              if (r > c) D[r * 16 + c] = D[r * 16 + c] / d;
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (lane < 16 && 16 * K + lane < NC) {
-            const double d = sqrt(D[lane * 16 + lane]);
-            isd[16 * K + lane] = 1.0 / d;
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (lane < 16 && 16 * K + lane < NC) D[lane * 16 + lane] = 1.0 / isd[16 * K + lane];
         }
         __syncthreads();
+#ifdef VPL_STAMPS
+        { const long long t1 = __builtin_readcyclecounter(); tb += t1 - t0; t0 = t1; }
+#endif
         if (flag[0]) break;
         {   // rows below the diagonal tile (including the rest of the rhs row's tile row)
           const int nrow = 16 * (NT16 - 1 - K);
@@ -454,21 +496,28 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
           for (int rr = tid; rr < nrow; rr += T) {
             const int r = 16 * (K + 1) + rr;
             if (r > NC) continue;
-            double* Ar = S + (((r >> 4) * ((r >> 4) + 1) / 2 + K) << 8) + (r & 15) * 16;
+            double* Ar = S + (((r >> 4) * ((r >> 4) + 1) / 2 + K) << 8) + (r & 15) * 16;   // row r of tile (r/16, K)
+            const int rx = r & 15;                                                          // its swizzle key
             double x[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-              double s2 = Ar[j];
+              double s2 = Ar[j ^ rx];
 #pragma unroll
-              for (int k = 0; k < 16; ++k) if (k < j) s2 -= x[k] * D[j * 16 + k];
+              for (int k = 0; k < 16; ++k) if (k < j) s2 -= x[k] * D[tsw(j, k)];
               x[j] = j < ncol ? s2 * isd[16 * K + j] : 0.0;
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) if (j < ncol) Ar[j] = x[j];
+            for (int j = 0; j < 16; ++j) if (j < ncol) Ar[j ^ rx] = x[j];
           }
         }
         __syncthreads();
+#ifdef VPL_STAMPS
+        { const long long t1 = __builtin_readcyclecounter(); tc += t1 - t0; t0 = t1; }
+#endif
       }
+#ifdef VPL_STAMPS
+      if (tid == 0) { B.dbg[(size_t)w * 64 + 40] = ta; B.dbg[(size_t)w * 64 + 41] = tb; B.dbg[(size_t)w * 64 + 42] = tc; }
+#endif
       __syncthreads();
       if (flag[0]) {   // LINEAR_SOLVER_FAILURE: raise mu and retry from the stored linearisation
         mu *= kMuIncrease;
@@ -496,27 +545,36 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
     }
     VPL_STAMP(B, w, 4);
     // ---- back substitution L^T y = z, tile by tile from the bottom: the diagonal tile is solved by one
-    //      wave (16 dependent steps), the update z_J -= L(K,J)^T y_K is spread over the workgroup.
+    //      wave (16 dependent register steps), the update z_J -= L(K,J)^T y_K is spread over the workgroup.
     for (int c = tid; c < 176; c += T) yv[c] = c < NC ? S[tix(NC, c)] : 0.0;
     __syncthreads();
     for (int K = NT16 - 1; K >= 0; --K) {
       const double* D = S + ((K * (K + 1) / 2 + K) << 8);
       if (wv == 0) {
-        volatile double* yy = yv + 16 * K;
+        // diagonal tile: lane i keeps y_i in a register and has its column L[j][i] preloaded; the 16 dependent steps are
+        // a v_readlane + two multiplies each (no LDS round trip inside the chain)
         const int ncol = min(16, NC - 16 * K);
-        for (int j = ncol - 1; j >= 0; --j) {
-          const double yj = yy[j] * isd[16 * K + j];
-          if (lane < j) yy[lane] -= D[j * 16 + lane] * yj;
-          if (lane == 0) yy[j] = yj;
-          __builtin_amdgcn_wave_barrier();
+        double yl = lane < 16 ? yv[16 * K + lane] : 0.0;
+        const double isdl = lane < ncol ? isd[16 * K + lane] : 0.0;
+        double Lcol[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Lcol[j] = (lane < j && j < ncol) ? D[tsw(j, lane & 15)] : 0.0;
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+          if (j < ncol) {
+            const double yj = readlane_f64(yl, j) * readlane_f64(isdl, j);
+            if (lane < j) yl -= Lcol[j] * yj;
+            if (lane == j) yl = yj;
+          }
         }
+        if (lane < ncol) yv[16 * K + lane] = yl;
       }
       __syncthreads();
       for (int c = tid; c < 16 * K; c += T) {
-        const double* Lk = S + ((K * (K + 1) / 2 + (c >> 4)) << 8) + (c & 15);
+        const double* Lk = S + ((K * (K + 1) / 2 + (c >> 4)) << 8);
         double s2 = 0.0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s2 += Lk[r * 16] * yv[16 * K + r];
+        for (int r = 0; r < 16; ++r) s2 += Lk[tsw(r, c & 15)] * yv[16 * K + r];
         yv[c] -= s2;
       }
       __syncthreads();
