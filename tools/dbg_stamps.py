@@ -10,6 +10,12 @@ ws, opt = make_windows(nw, 200, 80, True)
 opt.num_iterations = 1
 pri, _ = ctx.solve_windows(ws, opt)
 print('prior n', pri[0].n)
+# second pass WITH the priors (the benchmark's situation)
+keep = []
+for i, w in enumerate(ws):
+    p = v.Prior(); C.memmove(C.byref(p), C.byref(pri[i]), C.sizeof(p)); keep.append(p); w.prior = p
+opt.marginalization_flag = int(os.environ.get("VPL_DBG_MARG", "0"))
+ctx.solve_windows(ws, opt)
 ctx.lib.vpl_ba_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
 for w in (0, 1, 300):
     out = (C.c_longlong * 64)()
@@ -17,5 +23,6 @@ for w in (0, 1, 300):
     s = list(out)
     print("window", w, "k_solve phases (cycles):", [s[i + 1] - s[i] for i in range(0, 7)])
     print("   cholesky split: update(a) %d diag(b) %d trsm(c) %d" % (s[40], s[41], s[42]))
+    print("   line phase (thread 0): ctx %d math %d atomics %d ext-reduce %d" % (s[44], s[45], s[46], s[47]))
     print("   k_lin: prior %d imu %d zero %d points %d lines+out %d assemble %d" % (s[18]-s[16], s[22]-s[24], s[23]-s[18], s[24]-s[23], s[20]-s[22], s[21]-s[20]))
     print("   k_marg: setup+Ad %d landmark-elim %d E15 %d schur %d G-factor %d out %d" % (s[33]-s[32], 0, s[34]-s[33], s[35]-s[34], s[36]-s[35], s[37]-s[36]))

@@ -18,6 +18,21 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// sum over each row of 16 lanes with DPP row_shr (no LDS / bpermute traffic); valid in lane 15 of the row
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum16(double v) {
+  v += dpp_shr_f64<0x111>(v);   // row_shr:1
+  v += dpp_shr_f64<0x112>(v);   // row_shr:2
+  v += dpp_shr_f64<0x114>(v);   // row_shr:4
+  v += dpp_shr_f64<0x118>(v);   // row_shr:8
+  return v;
+}
+
 // sum over the whole workgroup; `red` is LDS scratch of >= 17 doubles; result broadcast
 __device__ __forceinline__ double block_sum(double v, double* red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

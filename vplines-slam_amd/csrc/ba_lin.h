@@ -213,15 +213,23 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     for (int i = tid; i < n; i += T) invmap[B.pr_map[(size_t)w * MAXPN + i]] = i;
     __syncthreads();
     const double* J0 = B.pr_J0 + (size_t)w * MAXPN * MAXPN;
-    for (int r = tid; r < n; r += T) {
-      double s = B.pr_r0[(size_t)w * MAXPN + r];
-      for (int c = 0; c < n; ++c) s += J0[(size_t)r * n + c] * prdx[c];
-      prr[r] = s;
-      cost += 0.5 * s * s;
+    // r = r0 + J0 dx: eight lanes per row (coalesced along the row), g = J0^T r: one lane per column, loads unrolled
+    for (int r = tid >> 3; r < n; r += T >> 3) {
+      const int sub = tid & 7;
+      double s = 0;
+#pragma unroll 4
+      for (int c = sub; c < n; c += 8) s += J0[(size_t)r * n + c] * prdx[c];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      if (sub == 0) {
+        s += B.pr_r0[(size_t)w * MAXPN + r];
+        prr[r] = s;
+        cost += 0.5 * s * s;
+      }
     }
     __syncthreads();
     for (int c = tid; c < n; c += T) {
       double s = 0;
+#pragma unroll 8
       for (int r = 0; r < n; ++r) s += J0[(size_t)r * n + c] * prr[r];
       prg[c] = s;
     }
@@ -436,8 +444,14 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
       // MARG: start-frame obs skipped (estimator.cpp:1322-1326), erased lines are no longer in f_manager.linefeature
       const bool act = inb && !PRIOR_ONLY && (!MARG || (s == 0 && k >= 1 && !B.ln_removed[li]));
       const double* ob = B.ln_obs + ((size_t)w * B.maxLO + (inb ? o : 0)) * 8;
+#ifdef VPL_STAMPS
+      long long lt0 = __builtin_readcyclecounter(), lt_ctx = 0, lt_math = 0, lt_atom = 0, lt_ext = 0;
+#endif
       LineCtx c;
       if (act) c = line_ctx(xp + 7 * j, xe, B.orth + li * 4);
+#ifdef VPL_STAMPS
+      { const long long t = __builtin_readcyclecounter(); lt_ctx += t - lt0; lt0 = t; }
+#endif
       double Wj[24];
 #pragma unroll
       for (int q = 0; q < 24; ++q) Wj[q] = 0.0;
@@ -465,6 +479,9 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
 #pragma unroll
             for (int q = 0; q < 12; ++q) Je[q] = 0.0;
           }
+#ifdef VPL_STAMPS
+          { const long long tt = __builtin_readcyclecounter(); lt_math += tt - lt0; lt0 = tt; }
+#endif
           int t = 0;
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
@@ -480,19 +497,34 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
           acc_diag(Hv, j, Jp);
           acc_off(Hv, 11, j, Je, Jp);
           acc_g(gv, j, Jp, r);
+#ifdef VPL_STAMPS
+          { const long long tt = __builtin_readcyclecounter(); lt_atom += tt - lt0; lt0 = tt; }
+#endif
         }
-        int t = 0;
+#ifdef VPL_STAMPS
+        lt0 = __builtin_readcyclecounter();
+#endif
+        // extrinsic block: every factor touches it.  Reduction over the wave in two levels: DPP row_shr inside each row of
+        // 16 lanes (VALU only), then the four row leaders add to the LDS Hessian (4-way same-address atomics instead of six
+        // bpermute levels per value)
+        {
+          const bool leader = (lane & 15) == 15;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const double gev = wave_sum(Je[a] * r[0] + Je[6 + a] * r[1]);
-          if (lane == 0) lds_add(&gv[66 + a], gev);
+          for (int a = 0; a < 6; ++a) {
+            const double gev = row_sum16(Je[a] * r[0] + Je[6 + a] * r[1]);
+            if (leader) lds_add(&gv[66 + a], gev);
 #pragma unroll
-          for (int c2 = 0; c2 <= a; ++c2, ++t) {
-            const double v = wave_sum(Je[a] * Je[c2] + Je[6 + a] * Je[6 + c2]);
-            if (lane == 0) lds_add(&Hv[(66 + a) * NV + 66 + c2], v);
+            for (int c2 = 0; c2 <= a; ++c2) {
+              const double v = row_sum16(Je[a] * Je[c2] + Je[6 + a] * Je[6 + c2]);
+              if (leader) lds_add(&Hv[(66 + a) * NV + 66 + c2], v);
+            }
           }
         }
       }
+#ifdef VPL_STAMPS
+      { const long long tt = __builtin_readcyclecounter(); lt_ext += tt - lt0; lt0 = tt; }
+      if (tid == 0) { B.dbg[(size_t)w * 64 + 44] = lt_ctx; B.dbg[(size_t)w * 64 + 45] = lt_math; B.dbg[(size_t)w * 64 + 46] = lt_atom; B.dbg[(size_t)w * 64 + 47] = lt_ext; }
+#endif
       if (act) {
         double* Wl = B.Wl + li * 4 * NV;
 #pragma unroll
