@@ -456,7 +456,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
 #pragma unroll
       for (int q = 0; q < 24; ++q) Wj[q] = 0.0;
       double* la = lacc + l * 38;
-#pragma unroll 1
+#pragma unroll
       for (int fct = 0; fct < 2; ++fct) {
         // VP factor only in the solve and only when flagged (estimator.cpp:1153, :1341-1351)
         const bool fa = act && (fct == 0 || (!MARG && ob[7] == 1.0));
