@@ -264,14 +264,14 @@ VPL_HD PoseR unpack_pose(const double* x) {
 }
 
 VPL_HD void tangent_basis(V3 pts_j, V3* b1, V3* b2) {  // projection_factor.cpp:9-18
-  double n = norm(pts_j);
-  V3 a{pts_j.x / n, pts_j.y / n, pts_j.z / n};
+  const double rn = 1.0 / norm(pts_j);   // one division, three multiplies (an f64 divide is ~12 instructions)
+  V3 a{pts_j.x * rn, pts_j.y * rn, pts_j.z * rn};
   V3 tmp{0, 0, 1};
   if (a.x == 0.0 && a.y == 0.0 && a.z == 1.0) tmp = V3{1, 0, 0};
   double at = dot(a, tmp);
   V3 t = tmp - a * at;
-  double tn = norm(t);
-  *b1 = V3{t.x / tn, t.y / tn, t.z / tn};
+  const double rtn = 1.0 / norm(t);
+  *b1 = V3{t.x * rtn, t.y * rtn, t.z * rtn};
   *b2 = cross(a, *b1);
 }
 
@@ -282,25 +282,26 @@ VPL_HD void projection_factor(const double* pi, const double* pj, const double* 
                               double* Je, double* Jl) {
   V3 Pi{pi[0], pi[1], pi[2]}, Pj{pj[0], pj[1], pj[2]}, tic{ex[0], ex[1], ex[2]};
   Q4 Qi = qpose(pi), Qj = qpose(pj), qic = qpose(ex);
-  V3 pts_camera_i{pts_i.x / inv_dep, pts_i.y / inv_dep, pts_i.z / inv_dep};
+  const double dep = 1.0 / inv_dep;
+  V3 pts_camera_i{pts_i.x * dep, pts_i.y * dep, pts_i.z * dep};
   V3 pts_imu_i = qrot(qic, pts_camera_i) + tic;
   V3 pts_w = qrot(Qi, pts_imu_i) + Pi;
   V3 pts_imu_j = qrot(qinv(Qj), pts_w - Pj);
   V3 pts_camera_j = qrot(qinv(qic), pts_imu_j - tic);
   V3 b1, b2;
   tangent_basis(pts_j, &b1, &b2);
-  double ncj = norm(pts_camera_j), nj = norm(pts_j);
-  V3 diff{pts_camera_j.x / ncj - pts_j.x / nj, pts_camera_j.y / ncj - pts_j.y / nj, pts_camera_j.z / ncj - pts_j.z / nj};
+  const double ncj = norm(pts_camera_j), rncj = 1.0 / ncj, rnj = 1.0 / norm(pts_j);
+  V3 diff{pts_camera_j.x * rncj - pts_j.x * rnj, pts_camera_j.y * rncj - pts_j.y * rnj, pts_camera_j.z * rncj - pts_j.z * rnj};
   r[0] = sqrt_info * dot(b1, diff);
   r[1] = sqrt_info * dot(b2, diff);
   if (!want_jac) return;
 
   M3 Ri = qmat(Qi), Rj = qmat(Qj), ric = qmat(qic);
-  double n3 = ncj * ncj * ncj;
+  const double rn3 = rncj * rncj * rncj;
   double x1 = pts_camera_j.x, x2 = pts_camera_j.y, x3 = pts_camera_j.z;
-  M3 nj_{{1.0 / ncj - x1 * x1 / n3, -x1 * x2 / n3, -x1 * x3 / n3,
-          -x1 * x2 / n3, 1.0 / ncj - x2 * x2 / n3, -x2 * x3 / n3,
-          -x1 * x3 / n3, -x2 * x3 / n3, 1.0 / ncj - x3 * x3 / n3}};
+  M3 nj_{{rncj - x1 * x1 * rn3, -x1 * x2 * rn3, -x1 * x3 * rn3,
+          -x1 * x2 * rn3, rncj - x2 * x2 * rn3, -x2 * x3 * rn3,
+          -x1 * x3 * rn3, -x2 * x3 * rn3, rncj - x3 * x3 * rn3}};
   // reduce (2x3) = sqrt_info * tangent_base * norm_jaco
   double red[6];
 #pragma unroll
@@ -328,7 +329,7 @@ VPL_HD void projection_factor(const double* pi, const double* pj, const double* 
 #pragma unroll
   for (int k = 0; k < 9; ++k) De.m[k] = -TS.m[k] + S2.m[k] + S3.m[k];
   V3 tl = mul(T, pts_i);
-  double sl = -1.0 / (inv_dep * inv_dep);
+  double sl = -(dep * dep);
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
     const double a0 = red[3 * rr], a1 = red[3 * rr + 1], a2 = red[3 * rr + 2];
@@ -386,10 +387,11 @@ VPL_HD void line_chain_jac(const LineCtx& c, const double* jel, int sel, double*
   M3 Rwc = mul(c.Rwb, c.Rbc);
   V3 twc = mul(c.Rwb, c.tbc) + c.twb;
   double nn = norm(c.Lw.n), vn = norm(c.Lw.v);
-  V3 u1{c.Lw.n.x / nn, c.Lw.n.y / nn, c.Lw.n.z / nn}, u2{c.Lw.v.x / vn, c.Lw.v.y / vn, c.Lw.v.z / vn};
+  const double rnn = 1.0 / nn, rvn = 1.0 / vn;
+  V3 u1{c.Lw.n.x * rnn, c.Lw.n.y * rnn, c.Lw.n.z * rnn}, u2{c.Lw.v.x * rvn, c.Lw.v.y * rvn, c.Lw.v.z * rvn};
   V3 u3 = cross(u1, u2);
-  double wn = sqrt(nn * nn + vn * vn);
-  double w0 = nn / wn, w1 = vn / wn;
+  const double rwn = 1.0 / sqrt(nn * nn + vn * vn);
+  double w0 = nn * rwn, w1 = vn * rwn;
   // K columns (6x4): c0 = [0; w1 u3], c1 = [-w0 u3; 0], c2 = [w0 u2; -w1 u1], c3 = [-w1 u1; w0 u2]
   V3 Kt[4] = {V3{0, 0, 0}, u3 * (-w0), u2 * w0, u1 * (-w1)};   // top (normal) halves
   V3 Kb[4] = {u3 * w1, V3{0, 0, 0}, u1 * (-w1), u2 * w0};      // bottom (direction) halves
@@ -432,15 +434,17 @@ VPL_HD void line_factor_res(const LineCtx& c, const double* obs, double sqrt_inf
   double l_trinorm = l_norm * l_sqrtnorm;
   double e1 = obs[0] * nc.x + obs[1] * nc.y + nc.z;
   double e2 = obs[2] * nc.x + obs[3] * nc.y + nc.z;
-  r[0] = sqrt_info * (e1 / l_sqrtnorm);
-  r[1] = sqrt_info * (e2 / l_sqrtnorm);
+  const double rs = 1.0 / l_sqrtnorm;
+  r[0] = sqrt_info * (e1 * rs);
+  r[1] = sqrt_info * (e2 * rs);
   if (jel) {
-    jel[0] = sqrt_info * (obs[0] / l_sqrtnorm - nc.x * e1 / l_trinorm);
-    jel[1] = sqrt_info * (obs[1] / l_sqrtnorm - nc.y * e1 / l_trinorm);
-    jel[2] = sqrt_info * (1.0 / l_sqrtnorm);
-    jel[3] = sqrt_info * (obs[2] / l_sqrtnorm - nc.x * e2 / l_trinorm);
-    jel[4] = sqrt_info * (obs[3] / l_sqrtnorm - nc.y * e2 / l_trinorm);
-    jel[5] = sqrt_info * (1.0 / l_sqrtnorm);
+    const double rt = 1.0 / l_trinorm;
+    jel[0] = sqrt_info * (obs[0] * rs - nc.x * e1 * rt);
+    jel[1] = sqrt_info * (obs[1] * rs - nc.y * e1 * rt);
+    jel[2] = sqrt_info * rs;
+    jel[3] = sqrt_info * (obs[2] * rs - nc.x * e2 * rt);
+    jel[4] = sqrt_info * (obs[3] * rs - nc.y * e2 * rt);
+    jel[5] = sqrt_info * rs;
   }
 }
 // vpProjectionFactor: vp = (x,y,z); jel is the reference's literal matrix (sic)
