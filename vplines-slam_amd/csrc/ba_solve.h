@@ -801,10 +801,16 @@ __global__ __launch_bounds__(COST_THREADS) void k_cost(DevBatch B) {
     }
     __syncthreads();
     const double* J0 = B.pr_J0 + (size_t)w * MAXPN * MAXPN;
-    for (int r = tid; r < n; r += T) {
-      double s = B.pr_r0[(size_t)w * MAXPN + r];
-      for (int c = 0; c < n; ++c) s += J0[(size_t)r * n + c] * prdx[c];
-      cost += 0.5 * s * s;
+    for (int r = tid >> 3; r < n; r += T >> 3) {   // eight lanes per row of J0 (coalesced), loads unrolled
+      const int sub = tid & 7;
+      double s = 0;
+#pragma unroll 4
+      for (int c = sub; c < n; c += 8) s += J0[(size_t)r * n + c] * prdx[c];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      if (sub == 0) {
+        s += B.pr_r0[(size_t)w * MAXPN + r];
+        cost += 0.5 * s * s;
+      }
     }
   }
   // IMU (one lane per factor; cost only)
@@ -826,27 +832,30 @@ __global__ __launch_bounds__(COST_THREADS) void k_cost(DevBatch B) {
   }
   const double hub = B.opt.huber_delta;
   const double* xe = xp + 77;
-  for (int p = tid; p < nP; p += T) {
+  // one lane per factor (a lane per track would serialise 5 point / 6 line evaluations behind each other)
+  for (int it = tid; it < nP * (NF - 1); it += T) {
+    const int p = it % nP, k = 1 + it / nP;
     const size_t pi = (size_t)w * B.maxP + p;
-    const int s = B.pt_start[pi], no = B.pt_nobs[pi], off = B.pt_off[pi];
+    const int no = B.pt_nobs[pi];
+    if (k >= no) continue;
+    const int s = B.pt_start[pi], off = B.pt_off[pi];
     const double lam = B.invd_c[pi];
     const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + off) * 3;
-    V3 pts_i{o0[0], o0[1], o0[2]};
-    for (int k = 1; k < no; ++k) {
-      const double* oj = o0 + 3 * k;
-      double r[2], sc;
-      projection_factor(xp + 7 * s, xp + 7 * (s + k), xe, lam, pts_i, V3{oj[0], oj[1], oj[2]}, B.opt.sqrt_info_point, r,
-                        false, nullptr, nullptr, nullptr, nullptr);
-      cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
-    }
+    const double* oj = o0 + 3 * k;
+    double r[2], sc;
+    projection_factor(xp + 7 * s, xp + 7 * (s + k), xe, lam, V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]},
+                      B.opt.sqrt_info_point, r, false, nullptr, nullptr, nullptr, nullptr);
+    cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
   }
-  for (int l = T - 1 - tid; l < nL; l += T) {
-    const size_t li = (size_t)w * B.maxL + l;
-    const int s = B.ln_start[li], no = B.ln_nobs[li], off = B.ln_off[li];
-    const double* orth = B.orth_c + li * 4;
-    for (int k = 0; k < no; ++k) {
-      const double* ob = B.ln_obs + ((size_t)w * B.maxLO + off + k) * 8;
-      LineCtx c = line_ctx(xp + 7 * (s + k), xe, orth);
+  {
+    const int nLO = B.nLO[w];
+    const int* lo_ln = B.lo_ln + (size_t)w * B.maxLO;
+    for (int o = T - 1 - tid; o < nLO; o += T) {
+      const int l = lo_ln[o];
+      const size_t li = (size_t)w * B.maxL + l;
+      const int k = o - B.ln_off[li];
+      const double* ob = B.ln_obs + ((size_t)w * B.maxLO + o) * 8;
+      LineCtx c = line_ctx(xp + 7 * (B.ln_start[li] + k), xe, B.orth_c + li * 4);
       double r[2], sc;
       line_factor_res(c, ob, B.opt.sqrt_info_line, r, nullptr);
       cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
