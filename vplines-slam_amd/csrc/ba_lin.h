@@ -12,7 +12,8 @@ namespace vpl {
 
 typedef double v4d_lin __attribute__((ext_vector_type(4)));
 constexpr int LIN_THREADS = 512;
-constexpr int LIN_STAGE = 8 * 32 * 20;   // MFMA staging of the point phase (doubles)
+constexpr int STG_LD = 21;                // row stride of the MFMA staging tiles (odd: the 16 writer lanes spread over the banks)
+constexpr int LIN_STAGE = 8 * 32 * STG_LD;   // MFMA staging of the point phase (doubles)
 constexpr int PREP_NMAX = 120;            // prior dims staged in LDS by k_prep (larger priors read HBM/L2)
 constexpr size_t PREP_SMEM = (size_t)(4 * 675 + PREP_NMAX * PREP_NMAX) * sizeof(double);
 
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     const int wvi = tid >> 6, nwv = T >> 6;
     const int* plist = B.ps_list + (size_t)w * B.maxP;     // track ids sorted by start frame
     const int* pcnt = B.ps_cnt + (size_t)w * (NF + 1);     // prefix offsets per start frame
-    double* stg = imuJ + wvi * (32 * 20);                  // this wave's staging tile: 32 rows x 20
+    double* stg = imuJ + wvi * (32 * STG_LD);              // this wave's staging tile: 32 rows x 20 (stride STG_LD)
     const int m16 = lane & 15, kk = lane >> 4;
     for (int s = wvi; s < NF; s += nwv) {
       const int b0 = pcnt[s], b1 = pcnt[s + 1];
@@ -285,6 +286,9 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
         double hll = 0, gll = 0, Wi[6], We[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) { Wi[k] = 0.0; We[k] = 0.0; }
+#ifdef VPL_STAMPS
+        long long pt_m = 0, pt_s = 0, pt_a = 0, pt0 = __builtin_readcyclecounter();
+#endif
         for (int k = 1; k < nomax; ++k) {
           const bool act = live && k < no;
           double r[2] = {0, 0}, Ji[12], Jj[12], Je[12], Jl[2] = {0, 0};
@@ -313,28 +317,33 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
               Wrow[6 * j + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];
             }
           }
+#ifdef VPL_STAMPS
+          { const long long t = __builtin_readcyclecounter(); pt_m += t - pt0; pt0 = t; }
+#endif
           // ---- wave reduction of [Js Jj Je r]^T [Js Jj Je r] on the matrix cores ----
           v4d_lin c00 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
           for (int l0 = 0; l0 < nlive; l0 += 16) {
             __builtin_amdgcn_wave_barrier();
             if (lane >= l0 && lane < l0 + 16) {
-              double* d0 = stg + (2 * (lane - l0)) * 20;
+              double* d0 = stg + (2 * (lane - l0)) * STG_LD;
 #pragma unroll
               for (int rr = 0; rr < 2; ++rr) {
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
-                  d0[rr * 20 + a] = Ji[6 * rr + a];
-                  d0[rr * 20 + 6 + a] = Jj[6 * rr + a];
-                  d0[rr * 20 + 12 + a] = Je[6 * rr + a];
+                  d0[rr * STG_LD + a] = Ji[6 * rr + a];
+                  d0[rr * STG_LD + 6 + a] = Jj[6 * rr + a];
+                  d0[rr * STG_LD + 12 + a] = Je[6 * rr + a];
                 }
-                d0[rr * 20 + 18] = r[rr];
-                d0[rr * 20 + 19] = 0.0;
+                d0[rr * STG_LD + 18] = r[rr];
+                d0[rr * STG_LD + 19] = 0.0;
               }
             }
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-              const double* row = stg + (4 * ks + kk) * 20;
+            // a bucket of 33 tracks leaves one lane for the third pass: only the k-steps that hold its two rows are run
+            const int ksmax = (2 * min(16, nlive - l0) + 3) >> 2;
+#pragma unroll 2
+            for (int ks = 0; ks < ksmax; ++ks) {
+              const double* row = stg + (4 * ks + kk) * STG_LD;
               const double lo = row[m16];
               const double hi = m16 < 4 ? row[16 + m16] : 0.0;
               c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, c00, 0, 0, 0);
@@ -342,6 +351,9 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
               c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, c11, 0, 0, 0);
             }
           }
+#ifdef VPL_STAMPS
+          { const long long t = __builtin_readcyclecounter(); pt_s += t - pt0; pt0 = t; }
+#endif
           // accumulator entry (row a = kk + 4 v (+16), col b = m16 (+16)) -> LDS Hessian / gradient
           {
             const double v00[4] = {c00.x, c00.y, c00.z, c00.w}, v10[4] = {c10.x, c10.y, c10.z, c10.w},
@@ -361,7 +373,13 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
               }
             }
           }
+#ifdef VPL_STAMPS
+          { const long long t = __builtin_readcyclecounter(); pt_a += t - pt0; pt0 = t; }
+#endif
         }
+#ifdef VPL_STAMPS
+        if (tid == 0) { B.dbg[(size_t)w * 64 + 48] = pt_m; B.dbg[(size_t)w * 64 + 49] = pt_s; B.dbg[(size_t)w * 64 + 50] = pt_a; }
+#endif
         if (live) {
 #pragma unroll
           for (int a = 0; a < 6; ++a) { Wrow[6 * s + a] = Wi[a]; Wrow[66 + a] = We[a]; }
