@@ -5,7 +5,7 @@
 //   k_ed_code   : per-pixel routing byte (walkable, direction, arg-max forward neighbour for both senses of travel)
 //   k_ed_route  : smart routing (:166-707): inherently serial and order dependent per frame -> one wave per
 //                 frame; edge bitmap + a 128x128 tile of routing words in LDS; throughput comes from the batch
-//   k_ed_fit    : per edge chain least-squares fit / extension / Helmholtz validation (:729-1174), one lane per chain
+//   k_ed_fit    : per edge chain least-squares fit / extension / Helmholtz validation (:729-1174), one wave per chain
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -371,10 +371,26 @@ __device__ double ed_nfa(int n, int k, double p, double logNT) {
   return -log10(bin_tail) - logNT;
 }
 
+// One WAVE per edge chain (the blocks of a frame take chains e = blockIdx.x, blockIdx.x + gridDim.x, ...).  The reference
+// loops are sequential over the pixels of a chain; every quantity they produce is either an exact integer sum (normal
+// equations of the fit, gradient sums, aligned-pixel counts: order independent, computed lane-parallel), a per-pixel
+// predicate (distance to the line: computed lane-parallel, consumed in order through a ballot), or the fit error, whose
+// double sum is accumulated in pixel order from lane-parallel terms.  The results are bit-identical to the serial form.
+constexpr int ED_FIT_BLOCKS = 48;
+
+__device__ __forceinline__ double ed_wave_sum(double v) {   // exact for the integer-valued sums it is used on
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double ed_readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(64) void k_ed_fit(EdBatch B) {
-  const int n = blockIdx.y;
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e >= B.nEdges[n]) return;
+  const int n = blockIdx.y, lane = threadIdx.x;
   const int W = B.W, H = B.H;
   const uint32_t* xC = B.cX + (size_t)n * 2 * B.cap;
   const uint32_t* yC = B.cY + (size_t)n * 2 * B.cap;
@@ -385,133 +401,165 @@ __global__ __launch_bounds__(64) void k_ed_fit(EdBatch B) {
   const unsigned minLineLen = B.minLineLen;
   const double thr = B.fitErr;
   const double logNT = 2.0 * (log10((double)W) + log10((double)H));
-  unsigned offS = sId[e], offE = sId[e + 1];
-  int ordinal = 0;
-  float ATA0, ATA1, ATA2, ATA3, ATV0, ATV1;
-  while (offE > offS + minLineLen) {
-    double eq0 = 0, eq1 = 0, lineFitErr = 0;
+  const int nE = B.nEdges[n];
+  for (int e = blockIdx.x; e < nE; e += gridDim.x) {
+    unsigned offS = sId[e], offE = sId[e + 1];
+    int ordinal = 0;
+    float ATA0 = 0, ATA1 = 0, ATA2 = 0, ATA3 = 0, ATV0 = 0, ATV1 = 0;
+    // sums of u^2, u, u v, v over pixels [a, b) of the chain (u along the line's dominant axis): exact integers
+    auto sums = [&](unsigned a, unsigned b, bool hz, double& s_uu, double& s_u, double& s_uv, double& s_v) {
+      double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+      for (unsigned o = a + lane; o < b; o += 64) {
+        const unsigned x = xC[o], y = yC[o];
+        const double u = (double)(float)(hz ? x : y), v = (double)(float)(hz ? y : x);
+        p0 += u * u; p1 += u; p2 += u * v; p3 += v;
+      }
+      s_uu = ed_wave_sum(p0); s_u = ed_wave_sum(p1); s_uv = ed_wave_sum(p2); s_v = ed_wave_sum(p3);
+    };
     while (offE > offS + minLineLen) {
+      double eq0 = 0, eq1 = 0, lineFitErr = 0;
+      while (offE > offS + minLineLen) {
+        const bool hz = dir[yC[offS] * W + xC[offS]] == 255;
+        double s_uu, s_u, s_uv, s_v;
+        sums(offS, offS + minLineLen, hz, s_uu, s_u, s_uv, s_v);
+        ATA0 = (float)s_uu; ATA1 = (float)s_u; ATA2 = (float)s_u; ATA3 = (float)(double)minLineLen;
+        ATV0 = (float)s_uv; ATV1 = (float)s_v;
+        const double coef = 1.0 / (double(ATA0) * double(ATA3) - double(ATA1) * double(ATA2));
+        eq0 = coef * (double(ATA3) * double(ATV0) - double(ATA1) * double(ATV1));
+        eq1 = coef * (double(ATA0) * double(ATV1) - double(ATA2) * double(ATV0));
+        double err = 0;
+        for (unsigned i0 = 0; i0 < minLineLen; i0 += 64) {   // terms lane-parallel, the sum in pixel order
+          const unsigned i = i0 + lane;
+          double c2 = 0;
+          if (i < minLineLen) {
+            const unsigned x = xC[offS + i], y = yC[offS + i];
+            const double u = (double)(hz ? x : y), v = (double)(hz ? y : x);
+            const double c = v - u * eq0 - eq1;
+            c2 = c * c;
+          }
+          const int cnt = (int)min(64u, minLineLen - i0);
+          for (int l = 0; l < cnt; ++l) err += ed_readlane_f64(c2, l);
+        }
+        lineFitErr = sqrt(err);
+        if (lineFitErr <= thr) break;
+        offS += 2;
+      }
+      if (lineFitErr > thr) break;
       const bool hz = dir[yC[offS] * W + xC[offS]] == 255;
-      double s_uu = 0, s_u = 0, s_uv = 0, s_v = 0;
-      for (unsigned i = 0; i < minLineLen; ++i) {
-        const double u = (double)(float)(hz ? xC[offS + i] : yC[offS + i]);
-        const double v = (double)(float)(hz ? yC[offS + i] : xC[offS + i]);
-        s_uu += u * u; s_u += u; s_uv += u * v; s_v += v;
-      }
-      ATA0 = (float)s_uu; ATA1 = (float)s_u; ATA2 = (float)s_u; ATA3 = (float)(double)minLineLen;
-      ATV0 = (float)s_uv; ATV1 = (float)s_v;
-      const double coef = 1.0 / (double(ATA0) * double(ATA3) - double(ATA1) * double(ATA2));
-      eq0 = coef * (double(ATA3) * double(ATV0) - double(ATA1) * double(ATV1));
-      eq1 = coef * (double(ATA0) * double(ATV1) - double(ATA2) * double(ATV0));
-      double err = 0;
-      for (unsigned i = 0; i < minLineLen; ++i) {
-        const double u = (double)(hz ? xC[offS + i] : yC[offS + i]), v = (double)(hz ? yC[offS + i] : xC[offS + i]);
-        const double c = v - u * eq0 - eq1;
-        err += c * c;
-      }
-      lineFitErr = sqrt(err);
-      if (lineFitErr <= thr) break;
-      offS += 2;
-    }
-    if (lineFitErr > thr) break;
-    const bool hz = dir[yC[offS] * W + xC[offS]] == 255;
-    const unsigned offS_init = offS;
-    bool bExtended = true, bFirstTry = true;
-    int numOfOutlier = 0, tryTimes = 0;
-    unsigned newOffsetS = 0;
-    double coef1 = 0;
-    while (bExtended) {
-      tryTimes++;
-      if (bFirstTry) {
-        bFirstTry = false;
-        offS += minLineLen;
-      } else {
-        const int newLength = (int)offS - (int)newOffsetS;
-        if ((int)offS - (int)offS_init > 0 && newLength > 0) {
-          double s_uu = 0, s_u = 0, s_uv = 0, s_v = 0;
-          for (unsigned o = newOffsetS; o < offS; ++o) {
-            const double u = (double)(float)(hz ? xC[o] : yC[o]);
-            const double v = (double)(float)(hz ? yC[o] : xC[o]);
-            s_uu += u * u; s_u += u; s_uv += u * v; s_v += v;
-          }
-          const float t00 = (float)s_uu, t01 = (float)s_u, t11 = (float)(double)newLength, v0 = (float)s_uv, v1 = (float)s_v;
-          ATA0 = ATA0 + t00; ATA1 = ATA1 + t01; ATA2 = ATA2 + t01; ATA3 = ATA3 + t11;
-          ATV0 = ATV0 + v0; ATV1 = ATV1 + v1;
-          const double coef = 1.0 / (double(ATA0) * double(ATA3) - double(ATA1) * double(ATA2));
-          eq0 = coef * (double(ATA3) * double(ATV0) - double(ATA1) * double(ATV1));
-          eq1 = coef * (double(ATA0) * double(ATV1) - double(ATA2) * double(ATV0));
-        }
-      }
-      coef1 = 1 / sqrt(eq0 * eq0 + 1);
-      numOfOutlier = 0;
-      newOffsetS = offS;
-      while (offE > offS) {
-        const double d = hz ? fabs(eq0 * xC[offS] - yC[offS] + eq1) * coef1 : fabs(xC[offS] - eq0 * yC[offS] - eq1) * coef1;
-        offS++;
-        if (d > thr) {
-          numOfOutlier++;
-          if (numOfOutlier > 3) break;
+      const unsigned offS_init = offS;
+      bool bExtended = true, bFirstTry = true;
+      int numOfOutlier = 0, tryTimes = 0;
+      unsigned newOffsetS = 0;
+      double coef1 = 0;
+      while (bExtended) {
+        tryTimes++;
+        if (bFirstTry) {
+          bFirstTry = false;
+          offS += minLineLen;
         } else {
-          numOfOutlier = 0;
-        }
-      }
-      offS -= numOfOutlier;
-      if (offS - newOffsetS > 0 && tryTimes < 6) {} else bExtended = false;
-    }
-    double leq0, leq1, leq2;
-    if (hz) { leq0 = eq0 * coef1; leq1 = -1 * coef1; leq2 = eq1 * coef1; }
-    else { leq0 = 1 * coef1; leq1 = -eq0 * coef1; leq2 = -eq1 * coef1; }
-    // ---- LineValidation ----
-    bool valid;
-    {
-      const int np = (int)offS - (int)offS_init;
-      int mgx = 0, mgy = 0;
-      for (int i = 0; i < np; ++i) {
-        const int idx = yC[offS_init + i] * W + xC[offS_init + i];
-        mgx += dx[idx];
-        mgy += dy[idx];
-      }
-      const double ddx = fabs(leq1), ddy = fabs(leq0);
-      valid = !(mgx == 0 && mgy == 0);
-      if (valid) {
-        float direction = 0.f;
-        if (mgx > 0 && mgy >= 0) direction = (float)atan2(-ddy, ddx);
-        if (mgx <= 0 && mgy > 0) direction = (float)atan2(ddy, ddx);
-        if (mgx < 0 && mgy <= 0) direction = (float)atan2(ddy, -ddx);
-        if (mgx >= 0 && mgy < 0) direction = (float)atan2(-ddy, -ddx);
-        if (fabs(direction) < 0.15 || M_PI - fabs(direction) < 0.15)
-          if (fabs(leq2) < 10 || fabs(H - fabs(leq2)) < 10) valid = false;
-        if (valid && fabs(fabs(direction) - M_PI * 0.5) < 0.15)
-          if (fabs(leq2) < 10 || fabs(W - fabs(leq2)) < 10) valid = false;
-        if (valid) {
-          int k = 0;
-          for (int i = 0; i < np; ++i) {
-            const int idx = yC[offS_init + i] * W + xC[offS_init + i];
-            const double pd = atan2(-(double)dx[idx], (double)dy[idx]);
-            const double dd = fabs(direction - pd);
-            if (fabs(2 * M_PI - dd) < 0.392699 || dd < 0.392699) k++;
+          const int newLength = (int)offS - (int)newOffsetS;
+          if ((int)offS - (int)offS_init > 0 && newLength > 0) {
+            double s_uu, s_u, s_uv, s_v;
+            sums(newOffsetS, offS, hz, s_uu, s_u, s_uv, s_v);
+            const float t00 = (float)s_uu, t01 = (float)s_u, t11 = (float)(double)newLength, v0 = (float)s_uv, v1 = (float)s_v;
+            ATA0 = ATA0 + t00; ATA1 = ATA1 + t01; ATA2 = ATA2 + t01; ATA3 = ATA3 + t11;
+            ATV0 = ATV0 + v0; ATV1 = ATV1 + v1;
+            const double coef = 1.0 / (double(ATA0) * double(ATA3) - double(ATA1) * double(ATA2));
+            eq0 = coef * (double(ATA3) * double(ATV0) - double(ATA1) * double(ATV1));
+            eq1 = coef * (double(ATA0) * double(ATV1) - double(ATA2) * double(ATV0));
           }
-          valid = ed_nfa(np, k, 0.125, logNT) > 0;
+        }
+        coef1 = 1 / sqrt(eq0 * eq0 + 1);
+        numOfOutlier = 0;
+        newOffsetS = offS;
+        // "while (offE > offS) { d; offS++; if (d > thr) { if (++numOfOutlier > 3) break; } else numOfOutlier = 0; }"
+        bool stop = false;
+        while (offE > offS && !stop) {
+          const unsigned o = offS + lane;
+          bool out = false;
+          if (o < offE) {
+            const unsigned x = xC[o], y = yC[o];
+            const double d = hz ? fabs(eq0 * x - y + eq1) * coef1 : fabs(x - eq0 * y - eq1) * coef1;
+            out = d > thr;
+          }
+          const unsigned long long mask = __ballot(out);
+          const int nvalid = (int)min(64u, offE - offS);
+          int consumed = nvalid;
+          for (int p = 0; p < nvalid; ++p) {
+            if ((mask >> p) & 1ull) {
+              if (++numOfOutlier > 3) { consumed = p + 1; stop = true; break; }
+            } else {
+              numOfOutlier = 0;
+            }
+          }
+          offS += consumed;
+        }
+        offS -= numOfOutlier;
+        if (offS - newOffsetS > 0 && tryTimes < 6) {} else bExtended = false;
+      }
+      double leq0, leq1, leq2;
+      if (hz) { leq0 = eq0 * coef1; leq1 = -1 * coef1; leq2 = eq1 * coef1; }
+      else { leq0 = 1 * coef1; leq1 = -eq0 * coef1; leq2 = -eq1 * coef1; }
+      // ---- LineValidation ----
+      bool valid;
+      {
+        const int np = (int)offS - (int)offS_init;
+        double pgx = 0, pgy = 0;
+        for (int i = lane; i < np; i += 64) {
+          const int idx = yC[offS_init + i] * W + xC[offS_init + i];
+          pgx += (double)dx[idx];
+          pgy += (double)dy[idx];
+        }
+        const int mgx = (int)ed_wave_sum(pgx), mgy = (int)ed_wave_sum(pgy);
+        const double ddx = fabs(leq1), ddy = fabs(leq0);
+        valid = !(mgx == 0 && mgy == 0);
+        if (valid) {
+          float direction = 0.f;
+          if (mgx > 0 && mgy >= 0) direction = (float)atan2(-ddy, ddx);
+          if (mgx <= 0 && mgy > 0) direction = (float)atan2(ddy, ddx);
+          if (mgx < 0 && mgy <= 0) direction = (float)atan2(ddy, -ddx);
+          if (mgx >= 0 && mgy < 0) direction = (float)atan2(-ddy, -ddx);
+          if (fabs(direction) < 0.15 || M_PI - fabs(direction) < 0.15)
+            if (fabs(leq2) < 10 || fabs(H - fabs(leq2)) < 10) valid = false;
+          if (valid && fabs(fabs(direction) - M_PI * 0.5) < 0.15)
+            if (fabs(leq2) < 10 || fabs(W - fabs(leq2)) < 10) valid = false;
+          if (valid) {
+            int k = 0;
+            for (int i0 = 0; i0 < np; i0 += 64) {
+              const int i = i0 + lane;
+              bool al = false;
+              if (i < np) {
+                const int idx = yC[offS_init + i] * W + xC[offS_init + i];
+                const double pd = atan2(-(double)dx[idx], (double)dy[idx]);
+                const double dd = fabs(direction - pd);
+                al = fabs(2 * M_PI - dd) < 0.392699 || dd < 0.392699;
+              }
+              k += __popcll(__ballot(al));
+            }
+            valid = ed_nfa(np, k, 0.125, logNT) > 0;
+          }
         }
       }
-    }
-    if (valid) {
-      const int slot = atomicAdd(&B.nLines[n], 1);
-      if (slot < B.maxLines) {
-        const double a1 = leq1 * leq1, a2 = leq0 * leq0, a3 = leq0 * leq1, a4 = leq2 * leq0, a5 = leq2 * leq1;
-        unsigned Px = xC[offS_init], Py = yC[offS_init];
-        const float x1 = (float)(a1 * Px - a3 * Py - a4), y1 = (float)(a2 * Py - a3 * Px - a5);
-        Px = xC[offS - 1]; Py = yC[offS - 1];
-        const float x2 = (float)(a1 * Px - a3 * Py - a4), y2 = (float)(a2 * Py - a3 * Px - a5);
-        double* o = B.lines + ((size_t)n * B.maxLines + slot) * 10;
-        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = leq0; o[5] = leq1; o[6] = leq2;
-        o[7] = (float)((x1 + x2) / 2.0);
-        o[8] = (float)((y1 + y2) / 2.0);
-        o[9] = (float)sqrt(pow((double)(x2 - x1), 2) + pow((double)(y2 - y1), 2));
-        B.lkey[(size_t)n * B.maxLines + slot] = ((uint32_t)e << 8) | (uint32_t)(ordinal & 255);
+      if (valid) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&B.nLines[n], 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot < B.maxLines && lane == 0) {
+          const double a1 = leq1 * leq1, a2 = leq0 * leq0, a3 = leq0 * leq1, a4 = leq2 * leq0, a5 = leq2 * leq1;
+          unsigned Px = xC[offS_init], Py = yC[offS_init];
+          const float x1 = (float)(a1 * Px - a3 * Py - a4), y1 = (float)(a2 * Py - a3 * Px - a5);
+          Px = xC[offS - 1]; Py = yC[offS - 1];
+          const float x2 = (float)(a1 * Px - a3 * Py - a4), y2 = (float)(a2 * Py - a3 * Px - a5);
+          double* o = B.lines + ((size_t)n * B.maxLines + slot) * 10;
+          o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = leq0; o[5] = leq1; o[6] = leq2;
+          o[7] = (float)((x1 + x2) / 2.0);
+          o[8] = (float)((y1 + y2) / 2.0);
+          o[9] = (float)sqrt(pow((double)(x2 - x1), 2) + pow((double)(y2 - y1), 2));
+          B.lkey[(size_t)n * B.maxLines + slot] = ((uint32_t)e << 8) | (uint32_t)(ordinal & 255);
+        }
       }
+      ++ordinal;
     }
-    ++ordinal;
   }
 }
 

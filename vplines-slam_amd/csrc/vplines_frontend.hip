@@ -136,7 +136,7 @@ int vpl_edlines_detect(vpl_fe_ctx* c, const vpl_edline_param* p) {
   hipLaunchKernelGGL(k_ed_anchor, dim3(c->n), dim3(1024), 0, s, B);
   hipLaunchKernelGGL(k_ed_code, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B);
   hipLaunchKernelGGL(k_ed_route, dim3(c->n), dim3(64), c->routeSmem, s, B);
-  hipLaunchKernelGGL(k_ed_fit, dim3((B.capEdges + 63) / 64, c->n), dim3(64), 0, s, B);
+  hipLaunchKernelGGL(k_ed_fit, dim3(ED_FIT_BLOCKS, c->n), dim3(64), 0, s, B);
   FECHK(c, hipGetLastError());
   return VPL_OK;
 }
