@@ -21,7 +21,8 @@ def frames(n, seed=0x5EED0000 + 4000):
     return np.stack(out)
 
 def main():
-    n, steps, warm = 64, 20, 3
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 64   # SURVEY 8d config 4 is 64; larger batches fill more of the 256 CUs
+    steps, warm = 20, 3
     dev = torch.device("cuda", 0)
     imgs = frames(n)
     fe = v.frontend.FrontendContext(device=0, max_images=n, width=752, height=480, max_lines=1024,
@@ -44,7 +45,7 @@ def main():
     tc = time.perf_counter() - tc
     same = sum(len(ref[i]) == len(lines[i]) for i in range(16))
     px = 752 * 480
-    print(json.dumps({"metric": "EDLines frames/s (752x480, batch 64)", "value": n * steps / dt, "unit": "frames/s",
+    print(json.dumps({"metric": "EDLines frames/s (752x480, batch %d)" % n, "value": n * steps / dt, "unit": "frames/s",
                       "ms_per_batch": 1e3 * dt / steps, "mean_lines_per_frame": float(np.mean([len(l) for l in lines])),
                       "gradient_stage_algorithmic_bytes_per_frame": px * 8,
                       "cpu_oracle_frames_per_s_1thread": 16 / tc, "line_count_match_on_16_frames": same, "route_stats_frame0": rs, "anchors_frame0": na}))
