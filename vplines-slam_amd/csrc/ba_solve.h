@@ -88,7 +88,11 @@ __device__ __forceinline__ void diag_tile_step(double (&d)[4], int r4, int cc, i
       bad = true;
     } else {
       if (cc == J) pivc = ajj;
-      const double f = __shfl(d[J >> 2], ((J & 3) << 4) | cc, 64) * (1.0 / ajj);   // D[J][cc] / a_JJ
+      // 1 / a_JJ by v_rcp_f64 + two Newton steps (5 dependent instructions; an IEEE divide is ~10 on this chain)
+      double rinv = __builtin_amdgcn_rcp(ajj);
+      rinv = fma(rinv, fma(-ajj, rinv, 1.0), rinv);
+      rinv = fma(rinv, fma(-ajj, rinv, 1.0), rinv);
+      const double f = __shfl(d[J >> 2], ((J & 3) << 4) | cc, 64) * rinv;            // D[J][cc] / a_JJ
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const double cv = swizzle_row_f64<J>(d[v]);                                 // D[r4 + 4v][J]
@@ -353,7 +357,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
       }
       VPL_STAMP(B, w, 2);
       // ---- reduced system: S = Hcc - X^T X (tile-major), rhs row = gc - X^T z; Cauchy denominator ----
-      for (int idx = tid; idx < NAP; idx += T) S[idx] = 0.0;
+      // One pass: the entries go to their tile slots already in the Jacobi-scaled space with the LM diagonal added
+      // (every slot of tile rows 0..9 is written; only the last tile row, which holds padding, is zeroed first).
+      for (int idx = tid; idx < NT16 * 256; idx += T) S[(((NT16 - 1) * NT16 / 2) << 8) + idx] = 0.0;
       __syncthreads();
       double qq = 0.0;
       for (int base = 0; base < NCP; base += 8 * T) {   // eight loads in flight per thread, then the LDS scatter
@@ -370,13 +376,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
             int r, c;
             tri_decode(idx, r, c);
             const double h = hh[u];
-            S[tix(r, c)] = h;
-            if ((r >> 4) == (c >> 4)) S[tix(c, r)] = h;   // diagonal tiles are kept as full squares
+            double hs = h * (sc[r] * sc[c]);
+            if (r == c) hs += mu * dg[r] * dg[r];
+            S[tix(r, c)] = hs;
+            if ((r >> 4) == (c >> 4)) S[tix(c, r)] = hs;   // diagonal tiles are kept as full squares
             qq += (r == c ? 1.0 : 2.0) * uc[r] * h * uc[c];
           }
         }
       }
-      for (int c = tid; c < NC; c += T) S[tix(NC, c)] = gc[c];
+      for (int c = tid; c < NC; c += T) S[tix(NC, c)] = gc[c] * sc[c];
       if (tid < 5) S[tix(NC + tid, NC + tid)] = 1.0;   // padding rows 171..175: unit pivots, never used
       __syncthreads();
       {
@@ -393,8 +401,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
             if (a < b || b >= NV || a > NV + 1) continue;
             if (a <= NV) {
               const int ra = tcol2row(a), rb = vis2cam(b);
-              S[tix(ra, rb)] -= vals[v];
-              if ((ra >> 4) == (rb >> 4) && ra != rb) S[tix(rb, ra)] -= vals[v];
+              const double vs = vals[v] * (ra < NC ? sc[ra] * sc[rb] : sc[rb]);
+              S[tix(ra, rb)] -= vs;
+              if ((ra >> 4) == (rb >> 4) && ra != rb) S[tix(rb, ra)] -= vs;
             } else {
               qq += 2.0 * vals[v] * uc[vis2cam(b)];   // (W^T u)_b u_c,b
             }
@@ -403,22 +412,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
       }
       qq = block_sum(qq, red);
       alpha = a1 / (q + qq);   // DoglegStrategy::ComputeCauchyPoint
-      // scale to the Jacobi-scaled space and add the LM diagonal
-      for (int idx = tid; idx < NAP; idx += T) {
-        const int tl = idx >> 8, rr = (idx >> 4) & 15, cc = (idx & 15) ^ rr;   // physical slot -> logical column
-        int I, J;
-        tri_decode(tl, I, J);
-        const int r = 16 * I + rr, c = 16 * J + cc;
-        if (r > NC || c >= NC) continue;
-        double v = S[idx];
-        if (r < NC) {
-          v *= sc[r] * sc[c];
-          if (r == c) v += mu * dg[r] * dg[r];
-        } else {
-          v *= sc[c];
-        }
-        S[idx] = v;
-      }
       __syncthreads();
       VPL_STAMP(B, w, 3);
       // ---- left-looking tile Cholesky (16x16 tiles).  Per tile column K:
