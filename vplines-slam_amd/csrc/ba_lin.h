@@ -184,13 +184,15 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   double* prdx = prr + MAXPN;      // MAXPN
   double* prg = prdx + MAXPN;      // MAXPN  J0^T r
   double* red = prg + MAXPN;       // 18
-  int* invmap = (int*)(red + 18);  // NC
+  double* pacc = red + 18;         // maxP x 14: per-track sums over its factors  H_ll | g_l | W_s (6) | W_ext (6)
+  int* invmap = (int*)(pacc + 14 * B.maxP);  // NC
   int* imuact = invmap + NC;       // 10
 
   const int nP = B.nP[w], nL = B.nL[w];
   // the marginalisation evaluates every block, constant or not (marginalization_factor.cpp:3-69)
   const bool ex_free = MARG || B.opt.estimate_extrinsic != 0;
   for (int i = tid; i < NV * NV + NV; i += T) sm[i] = 0.0;
+  for (int i = tid; i < 14 * nP; i += T) pacc[i] = 0.0;
   for (int i = tid; i < 84; i += T) xp[i] = i < 77 ? B.pose[(size_t)w * 77 + i] : B.ex[(size_t)w * 7 + (i - 77)];
   for (int i = tid; i < 99; i += T) xs[i] = B.sb[(size_t)w * 99 + i];
   for (int i = tid; i < NC; i += T) invmap[i] = -1;
@@ -255,145 +257,128 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   __syncthreads();
 
   VPL_STAMP(B, w, 23);
-  // points: wave `wvi` owns the tracks that START in frame wvi (+8 for longer windows), so in a round
-  // (observation index k) every lane of the wave works on the same pair of frames (s, j = s + k) and all
-  // six 6x6 blocks a point factor touches are wave-uniform.  The sum over the wave of J^T [J | r]
-  // (19 x 19, J = [J_s J_j J_e]) is a rank-2*lanes update: lanes stage their two Jacobian rows in LDS
-  // (16 lanes = 32 rows per pass) and the FP64 matrix cores reduce them (3 tiles of 16x16, K = 4 per
-  // instruction); each lane then adds its accumulator entries to the LDS Hessian once per round.
+  // points: the work unit is (start frame s, chunk of <= 16 tracks that start there, observation index k) -- one QUARTER
+  // of a wave.  Inside a quarter every lane works on the same pair of frames (s, j = s + k), so the six 6x6 blocks a
+  // point factor touches are uniform over its 16 lanes and the sum of J^T [J | r] (19 x 19, J = [J_s J_j J_e]) over them
+  // is a rank-32 update: the lanes stage their two Jacobian rows in LDS and the FP64 matrix cores reduce them (3 tiles of
+  // 16x16, K = 4 per instruction), one pass per quarter; each lane then adds its accumulator entries to the LDS Hessian.
+  // The factor math of the four quarters of a wave runs concurrently (different (s, j) per quarter), so a window of 200
+  // tracks x 5 factors takes 3 rounds of the 8 waves.  Per-track sums over k (H_ll, g_l, W_s, W_ext) are LDS atomics into
+  // pacc, written out once at the end of the phase.
   {
     const int wvi = tid >> 6, nwv = T >> 6;
     const int* plist = B.ps_list + (size_t)w * B.maxP;     // track ids sorted by start frame
-    const int* pcnt = B.ps_cnt + (size_t)w * (NF + 1);     // prefix offsets per start frame
+    const int nU = B.pu_cnt[w];
+    const int* pu = B.pu_tab + (size_t)w * B.maxPU * 4;    // (s, first index in plist, tracks, k) per unit
     double* stg = imuJ + wvi * (32 * STG_LD);              // this wave's staging tile: 32 rows x 20 (stride STG_LD)
     const int m16 = lane & 15, kk = lane >> 4;
-    for (int s = wvi; s < NF; s += nwv) {
-      const int b0 = pcnt[s], b1 = pcnt[s + 1];
-      if ((MARG && s != 0) || PRIOR_ONLY) continue;
-      for (int q0 = b0; q0 < b1; q0 += 64) {
-        const int qi = q0 + lane;
-        const bool live = qi < b1;
-        const int p = live ? plist[qi] : 0;
-        const size_t pi = (size_t)w * B.maxP + p;
-        const int no = live ? B.pt_nobs[pi] : 0, off = live ? B.pt_off[pi] : 0;
-        int nomax = no;
+    for (int u0 = 4 * wvi; u0 < nU; u0 += 4 * nwv) {
+      const int u = u0 + kk;
+      const bool has = u < nU;
+      const int s = has ? pu[4 * u] : 0, k = has ? pu[4 * u + 3] : 1, ucnt = has ? pu[4 * u + 2] : 0;
+      const bool live = has && m16 < ucnt && !(MARG && s != 0) && !PRIOR_ONLY;
+      const int p = live ? plist[pu[4 * u + 1] + m16] : 0;
+      const size_t pi = (size_t)w * B.maxP + p;
+      const int no = live ? B.pt_nobs[pi] : 0, off = live ? B.pt_off[pi] : 0;
+      const bool act = live && k < no;
+      const int j = s + k;
+      double* Wrow = B.Wp + pi * NV;
+      double r[2] = {0, 0}, Ji[12], Jj[12], Je[12];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nomax = max(nomax, __shfl_xor(nomax, o, 64));
-        const int nlive = min(64, b1 - q0);
-        double* Wrow = B.Wp + pi * NV;
-        const double lam = live ? B.invd[pi] : 1.0;
+      for (int q = 0; q < 12; ++q) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
+      if (act) {
+        const double lam = B.invd[pi];
         const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + off) * 3;
-        double hll = 0, gll = 0, Wi[6], We[6];
+        const double* oj = o0 + 3 * k;
+        double Jl[2] = {0, 0};
+        projection_factor(xp + 7 * s, xp + 7 * j, xe, lam, V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]},
+                          B.opt.sqrt_info_point, r, true, Ji, Jj, Je, Jl);
+        double sc;
+        cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
+        r[0] *= sc; r[1] *= sc; Jl[0] *= sc; Jl[1] *= sc;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { Wi[k] = 0.0; We[k] = 0.0; }
-#ifdef VPL_STAMPS
-        long long pt_m = 0, pt_s = 0, pt_a = 0, pt0 = __builtin_readcyclecounter();
-#endif
-        for (int k = 1; k < nomax; ++k) {
-          const bool act = live && k < no;
-          double r[2] = {0, 0}, Ji[12], Jj[12], Je[12], Jl[2] = {0, 0};
+        for (int q = 0; q < 12; ++q) { Ji[q] *= sc; Jj[q] *= sc; Je[q] *= sc; }
+        if (!ex_free) {
 #pragma unroll
-          for (int q = 0; q < 12; ++q) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
-          const int j = s + k;
-          if (act) {
-            const double* oj = o0 + 3 * k;
-            projection_factor(xp + 7 * s, xp + 7 * j, xe, lam, V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]},
-                              B.opt.sqrt_info_point, r, true, Ji, Jj, Je, Jl);
-            double sc;
-            cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
-            r[0] *= sc; r[1] *= sc; Jl[0] *= sc; Jl[1] *= sc;
+          for (int q = 0; q < 12; ++q) Je[q] = 0.0;
+        }
+        double* pa = pacc + 14 * p;
+        lds_add(&pa[0], Jl[0] * Jl[0] + Jl[1] * Jl[1]);
+        lds_add(&pa[1], Jl[0] * r[0] + Jl[1] * r[1]);
 #pragma unroll
-            for (int q = 0; q < 12; ++q) { Ji[q] *= sc; Jj[q] *= sc; Je[q] *= sc; }
-            if (!ex_free) {
+        for (int a = 0; a < 6; ++a) {
+          lds_add(&pa[2 + a], Jl[0] * Ji[a] + Jl[1] * Ji[6 + a]);
+          lds_add(&pa[8 + a], Jl[0] * Je[a] + Jl[1] * Je[6 + a]);
+          Wrow[6 * j + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];   // this (track, frame) entry has one writer
+        }
+      }
+      // ---- per quarter: reduction of [Js Jj Je r]^T [Js Jj Je r] over its 16 lanes on the matrix cores ----
+      const unsigned long long actmask = __ballot(act);
+#pragma unroll 1
+      for (int qq = 0; qq < 4; ++qq) {
+        const unsigned qmask = (unsigned)((actmask >> (16 * qq)) & 0xffffull);
+        if (qmask == 0) continue;   // uniform
+        const int sq = __builtin_amdgcn_readlane(s, 16 * qq), jq = __builtin_amdgcn_readlane(j, 16 * qq);
+        const int rows = 2 * (32 - __builtin_clz(qmask));   // staged rows that can be non-zero
+        __builtin_amdgcn_wave_barrier();
+        if (kk == qq) {
+          double* d0 = stg + (2 * m16) * STG_LD;
 #pragma unroll
-              for (int q = 0; q < 12; ++q) Je[q] = 0.0;
-            }
-            hll += Jl[0] * Jl[0] + Jl[1] * Jl[1];
-            gll += Jl[0] * r[0] + Jl[1] * r[1];
+          for (int rr = 0; rr < 2; ++rr) {
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
-              Wi[a] += Jl[0] * Ji[a] + Jl[1] * Ji[6 + a];
-              We[a] += Jl[0] * Je[a] + Jl[1] * Je[6 + a];
-              Wrow[6 * j + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];
+              d0[rr * STG_LD + a] = Ji[6 * rr + a];
+              d0[rr * STG_LD + 6 + a] = Jj[6 * rr + a];
+              d0[rr * STG_LD + 12 + a] = Je[6 * rr + a];
             }
+            d0[rr * STG_LD + 18] = r[rr];
+            d0[rr * STG_LD + 19] = 0.0;
           }
-#ifdef VPL_STAMPS
-          { const long long t = __builtin_readcyclecounter(); pt_m += t - pt0; pt0 = t; }
-#endif
-          // ---- wave reduction of [Js Jj Je r]^T [Js Jj Je r] on the matrix cores ----
-          v4d_lin c00 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
-          for (int l0 = 0; l0 < nlive; l0 += 16) {
-            __builtin_amdgcn_wave_barrier();
-            if (lane >= l0 && lane < l0 + 16) {
-              double* d0 = stg + (2 * (lane - l0)) * STG_LD;
-#pragma unroll
-              for (int rr = 0; rr < 2; ++rr) {
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                  d0[rr * STG_LD + a] = Ji[6 * rr + a];
-                  d0[rr * STG_LD + 6 + a] = Jj[6 * rr + a];
-                  d0[rr * STG_LD + 12 + a] = Je[6 * rr + a];
-                }
-                d0[rr * STG_LD + 18] = r[rr];
-                d0[rr * STG_LD + 19] = 0.0;
-              }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // a bucket of 33 tracks leaves one lane for the third pass: only the k-steps that hold its two rows are run
-            const int ksmax = (2 * min(16, nlive - l0) + 3) >> 2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        v4d_lin c00 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+        const int ksmax = (rows + 3) >> 2;
 #pragma unroll 2
-            for (int ks = 0; ks < ksmax; ++ks) {
-              const double* row = stg + (4 * ks + kk) * STG_LD;
-              const double lo = row[m16];
-              const double hi = m16 < 4 ? row[16 + m16] : 0.0;
-              c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, c00, 0, 0, 0);
-              c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, c10, 0, 0, 0);
-              c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, c11, 0, 0, 0);
-            }
-          }
-#ifdef VPL_STAMPS
-          { const long long t = __builtin_readcyclecounter(); pt_s += t - pt0; pt0 = t; }
-#endif
-          // accumulator entry (row a = kk + 4 v (+16), col b = m16 (+16)) -> LDS Hessian / gradient
-          {
-            const double v00[4] = {c00.x, c00.y, c00.z, c00.w}, v10[4] = {c10.x, c10.y, c10.z, c10.w},
-                         v11[4] = {c11.x, c11.y, c11.z, c11.w};
-            auto visof = [&](int a) { return a < 6 ? 6 * s + a : (a < 12 ? 6 * j + (a - 6) : 66 + (a - 12)); };
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const int a0 = kk + 4 * v, bcol = m16;
-              if (a0 >= bcol) lds_add(&Hv[visof(a0) * NV + visof(bcol)], v00[v]);
-              const int a1 = 16 + kk + 4 * v;
-              if (a1 < 18) lds_add(&Hv[visof(a1) * NV + visof(bcol)], v10[v]);
-              else if (a1 == 18) lds_add(&gv[visof(bcol)], v10[v]);
-              const int b1c = 16 + m16;
-              if (b1c < 18) {
-                if (a1 < 18 && a1 >= b1c) lds_add(&Hv[visof(a1) * NV + visof(b1c)], v11[v]);
-                else if (a1 == 18) lds_add(&gv[visof(b1c)], v11[v]);
-              }
-            }
-          }
-#ifdef VPL_STAMPS
-          { const long long t = __builtin_readcyclecounter(); pt_a += t - pt0; pt0 = t; }
-#endif
+        for (int ks = 0; ks < ksmax; ++ks) {
+          const double* row = stg + (4 * ks + kk) * STG_LD;
+          const double lo = row[m16];
+          const double hi = m16 < 4 ? row[16 + m16] : 0.0;
+          c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, c00, 0, 0, 0);
+          c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, c10, 0, 0, 0);
+          c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, c11, 0, 0, 0);
         }
-#ifdef VPL_STAMPS
-        if (tid == 0) { B.dbg[(size_t)w * 64 + 48] = pt_m; B.dbg[(size_t)w * 64 + 49] = pt_s; B.dbg[(size_t)w * 64 + 50] = pt_a; }
-#endif
-        if (live) {
+        // accumulator entry (row a = kk + 4 v (+16), col b = m16 (+16)) -> LDS Hessian / gradient
+        {
+          const double v00[4] = {c00.x, c00.y, c00.z, c00.w}, v10[4] = {c10.x, c10.y, c10.z, c10.w},
+                       v11[4] = {c11.x, c11.y, c11.z, c11.w};
+          auto visof = [&](int a) { return a < 6 ? 6 * sq + a : (a < 12 ? 6 * jq + (a - 6) : 66 + (a - 12)); };
 #pragma unroll
-          for (int a = 0; a < 6; ++a) { Wrow[6 * s + a] = Wi[a]; Wrow[66 + a] = We[a]; }
-          B.Hpp[pi] = hll;
-          B.gp[pi] = gll;
+          for (int v = 0; v < 4; ++v) {
+            const int a0 = kk + 4 * v, bcol = m16;
+            if (a0 >= bcol) lds_add(&Hv[visof(a0) * NV + visof(bcol)], v00[v]);
+            const int a1 = 16 + kk + 4 * v;
+            if (a1 < 18) lds_add(&Hv[visof(a1) * NV + visof(bcol)], v10[v]);
+            else if (a1 == 18) lds_add(&gv[visof(bcol)], v10[v]);
+            const int b1c = 16 + m16;
+            if (b1c < 18) {
+              if (a1 < 18 && a1 >= b1c) lds_add(&Hv[visof(a1) * NV + visof(b1c)], v11[v]);
+              else if (a1 == 18) lds_add(&gv[visof(b1c)], v11[v]);
+            }
+          }
         }
       }
     }
-    if (MARG) {   // tracks that do not start in frame 0 take no part in the marginalisation
-      for (int p = tid; p < nP; p += T) {
-        const size_t pi = (size_t)w * B.maxP + p;
-        if (B.pt_start[pi] != 0) { B.Hpp[pi] = 0.0; B.gp[pi] = 0.0; }
-      }
-    }
+  }
+  __syncthreads();
+  for (int p = tid; p < nP; p += T) {   // per-track sums out of LDS
+    const size_t pi = (size_t)w * B.maxP + p;
+    const double* pa = pacc + 14 * p;
+    double* Wrow = B.Wp + pi * NV;
+    const int s0 = B.pt_start[pi];
+    B.Hpp[pi] = pa[0];
+    B.gp[pi] = pa[1];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { Wrow[6 * s0 + a] = pa[2 + a]; Wrow[66 + a] = pa[8 + a]; }
   }
   __syncthreads();   // staging space is handed over to the IMU / line phases
   VPL_STAMP(B, w, 24);
@@ -662,9 +647,9 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   }
 }
 
-inline size_t lin_smem(int maxL) {
+inline size_t lin_smem(int maxP, int maxL) {
   const int stg = LIN_STAGE > 4650 + 38 * maxL ? LIN_STAGE : 4650 + 38 * maxL;
-  return (size_t)(NV * NV + NV + 84 + 99 + stg + 3 * MAXPN + 18) * sizeof(double) + (size_t)(NC + 12) * sizeof(int);
+  return (size_t)(NV * NV + NV + 84 + 99 + stg + 3 * MAXPN + 18 + 14 * maxP) * sizeof(double) + (size_t)(NC + 12) * sizeof(int);
 }
 
 }  // namespace vpl

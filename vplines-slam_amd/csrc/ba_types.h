@@ -68,6 +68,8 @@ struct DevBatch {
   int *pt_start, *pt_nobs, *pt_off;              // [W][maxP]
   double *pt_obs;                                // [W][maxPO][3]
   int *ps_list, *ps_cnt;                         // [W][maxP] track ids sorted by start frame ; [W][12] prefix offsets
+  int *pu_tab, *pu_cnt;                          // [W][maxPU][4] point work units (s, first index in ps_list, tracks <= 16, k) ; [W]
+  int maxPU;
   int *ln_start, *ln_nobs, *ln_off;              // [W][maxL]
   double *ln_obs;                                // [W][maxLO][8]
   int *nLO, *lo_ln;                              // [W] line observation count ; [W][maxLO] observation -> line

@@ -169,6 +169,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   std::memset(&B, 0, sizeof(B));
   B.maxP = c->maxP; B.maxPO = c->maxPO; B.maxL = c->maxL; B.maxLO = c->maxLO;
   B.nfull = NC + B.maxP + 4 * B.maxL;
+  B.maxPU = (B.maxP / 16 + NF) * (NF - 1);   // point work units of k_lin: (start frame, chunk of 16 tracks, observation)
   const size_t W = max_windows;
   hipError_t e = hipSuccess;
 #define AL(ptr, n) if (e == hipSuccess) e = dalloc(c, &B.ptr, (size_t)(n))
@@ -178,7 +179,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(plk, W * B.maxL * 6); AL(gauge, W * 4);
   AL(nP, W); AL(nL, W);
   AL(pt_start, W * B.maxP); AL(pt_nobs, W * B.maxP); AL(pt_off, W * B.maxP); AL(pt_obs, W * B.maxPO * 3);
-  AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1));
+  AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1)); AL(pu_tab, W * B.maxPU * 4); AL(pu_cnt, W);
   AL(ln_start, W * B.maxL); AL(ln_nobs, W * B.maxL); AL(ln_off, W * B.maxL); AL(ln_obs, W * B.maxLO * 8);
   AL(nLO, W); AL(lo_ln, W * B.maxLO);
   AL(pre, W * NF);
@@ -198,9 +199,10 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
     delete c;
     return VPL_E_HIP;
   }
-  if (lin_smem(c->maxL) > 158 * 1024) { for (void* p : c->allocs) hipFree(p); delete c; return VPL_E_CAPACITY; }
-  hipFuncSetAttribute((const void*)k_lin<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxL));
-  hipFuncSetAttribute((const void*)k_lin<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxL));
+  if (lin_smem(c->maxP, c->maxL) > 158 * 1024) { for (void* p : c->allocs) hipFree(p); delete c; return VPL_E_CAPACITY; }
+  hipFuncSetAttribute((const void*)k_lin<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxP, c->maxL));
+  hipFuncSetAttribute((const void*)k_lin<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxP, c->maxL));
+  hipFuncSetAttribute((const void*)k_lin<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxP, c->maxL));
   hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
   hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SMEM);
   hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -383,6 +385,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   std::vector<double> pose(W * 77), sb(W * 99), ex(W * 7), invd(W * B.maxP, 1.0), plk(W * B.maxL * 6, 0.0);
   std::vector<int> nP(W), nL(W), pt_start(W * B.maxP, 0), pt_nobs(W * B.maxP, 0), pt_off(W * B.maxP, 0);
   std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0), ln_tri(W * B.maxL, 1);
+  std::vector<int> pu_tab(W * B.maxPU * 4, 0), pu_cnt(W, 0);
   std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0);
   std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
@@ -425,6 +428,20 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       int pos[NF + 1];
       for (int f = 0; f <= NF; ++f) pos[f] = cnt[f];
       for (int p = 0; p < v.n_points; ++p) ps_list[w * B.maxP + pos[v.point_start[p]]++] = p;
+      // work units of the point phase of k_lin: (start frame, <= 16 tracks, observation index k >= 1)
+      int nu = 0;
+      for (int f = 0; f < NF; ++f) {
+        const int c0 = cnt[f], c1 = cnt[f + 1];
+        int maxno = 0;
+        for (int q = c0; q < c1; ++q) maxno = std::max(maxno, v.point_nobs[ps_list[w * B.maxP + q]]);
+        for (int k = 1; k < maxno; ++k)
+          for (int q = c0; q < c1; q += 16) {
+            int* t = &pu_tab[(w * B.maxPU + nu) * 4];
+            t[0] = f; t[1] = q; t[2] = std::min(16, c1 - q); t[3] = k;
+            ++nu;
+          }
+      }
+      pu_cnt[w] = nu;
     }
     off = 0;
     int woff = 0, nl = 0;
@@ -510,6 +527,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.pt_start, pt_start)); HIPCHK(c, up(c, B.pt_nobs, pt_nobs)); HIPCHK(c, up(c, B.pt_off, pt_off));
   HIPCHK(c, up(c, B.pt_obs, pt_obs));
   HIPCHK(c, up(c, B.ps_list, ps_list)); HIPCHK(c, up(c, B.ps_cnt, ps_cnt));
+  HIPCHK(c, up(c, B.pu_tab, pu_tab)); HIPCHK(c, up(c, B.pu_cnt, pu_cnt));
   HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
   HIPCHK(c, up(c, B.ln_obs, ln_obs)); HIPCHK(c, up(c, B.ln_tri, ln_tri));
   HIPCHK(c, up(c, B.nLO, nLO)); HIPCHK(c, up(c, B.lo_ln, lo_ln));
@@ -630,21 +648,21 @@ int vpl_ba_solve(vpl_ctx* c) {
   const dim3 grid(c->nW);
   hipStream_t s = c->stream;
   { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(256), PREP_SMEM, s, B); }
-  { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
+  { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
   for (int it = 0; it < c->opt.num_iterations; ++it) {
     { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), SOLVE_SMEM, s, B); }
     { KTimer t(c, "k_cost"); hipLaunchKernelGGL(k_cost, grid, dim3(COST_THREADS), 0, s, B); }
     if (it + 1 < c->opt.num_iterations) {
       KTimer t(c, "k_lin");
-      hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B);
+      hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B);
     }
   }
   { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
   if (c->opt.marginalization_flag == VPL_MARGIN_OLD) {
-    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<1>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
+    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<1>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
     { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   } else if (c->any_second_new) {
-    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<2>, grid, dim3(LIN_THREADS), lin_smem(c->maxL), s, B); }
+    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<2>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
     { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   }
   HIPCHK(c, hipGetLastError());
