@@ -327,18 +327,25 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     const int ls = kind == 1 ? 9 : 6;
     for (int k = 0; k < ls; ++k) dmap[md + idx + k] = base + k;
   }
-  if (tid == 32) {
-    int a = 0, c = 0;
-    if (!second_new) {
-      for (int p = 0; p < nP && a < LOFF; ++p)
-        if (B.pt_start[(size_t)w * B.maxP + p] == 0 && B.Hpp[(size_t)w * B.maxP + p] != 0.0) lst[a++] = p;
-      for (int l = 0; l < nL && c < LOFF; ++l)
-        if (B.ln_start[(size_t)w * B.maxL + l] == 0 && B.ln_nobs[(size_t)w * B.maxL + l] >= 2 &&
-            !B.ln_removed[(size_t)w * B.maxL + l])
-          lst[LOFF + c++] = l;
-    }
-    s_np0 = a;
-    s_nl0 = c;
+  // landmarks that start in frame 0: the points are the first bucket of the start-frame sort (k_lin leaves H_pp = 0 on a
+  // track without factors: its row is staged as zeros), the lines are compacted in order by wave 0
+  if (tid >= 64 && !second_new) {
+    const int np0 = min(LOFF, B.ps_cnt[(size_t)w * (NF + 1) + 1]);
+    for (int a = tid - 64; a < np0; a += T - 64) lst[a] = B.ps_list[(size_t)w * B.maxP + a];
+    if (tid == 64) s_np0 = np0;
+  }
+  if (tid < 64) {
+    int c = 0;
+    if (!second_new)
+      for (int l0 = 0; l0 < nL; l0 += 64) {
+        const int l = l0 + tid;
+        const bool on = l < nL && B.ln_start[(size_t)w * B.maxL + l] == 0 && B.ln_nobs[(size_t)w * B.maxL + l] >= 2 &&
+                        !B.ln_removed[(size_t)w * B.maxL + l];
+        const unsigned long long m = __ballot(on);
+        if (on && c + __popcll(m & ((1ull << tid) - 1ull)) < LOFF) lst[LOFF + c + __popcll(m & ((1ull << tid) - 1ull))] = l;
+        c += __popcll(m);
+      }
+    if (tid == 0) { s_nl0 = min(c, LOFF); if (second_new) s_np0 = 0; }
   }
   __syncthreads();
   VPL_STAMP(B, w, 32);
@@ -362,7 +369,8 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
       for (int it = tid; it < cnt * 73; it += T) {
         const int rr = it / 73, c = it % 73;
         const size_t pi = (size_t)w * B.maxP + lst[base + rr];
-        const double isq = 1.0 / sqrt(B.Hpp[pi]);
+        const double hpp = B.Hpp[pi];
+        const double isq = hpp != 0.0 ? 1.0 / sqrt(hpp) : 0.0;
         tile[rr * 74 + c] = isq * (c < NV ? B.Wp[pi * NV + c] : B.gp[pi]);
       }
       base += cnt;
