@@ -125,17 +125,19 @@ __global__ __launch_bounds__(256) void k_lm_anchors(LmBatch B) {
   int* num = B.kpNum + (size_t)p * B.maxLines;
   int* off = B.kpOff + (size_t)p * B.maxLines;
   const int step = B.prm.step;
-  for (int i = threadIdx.x; i < nr; i += 256) num[i] = int(L[i].length / step) + 2;
+  extern __shared__ int lm_num[];   // maxLines: the counts, then their exclusive prefix (serial over LDS, not over HBM)
+  for (int i = threadIdx.x; i < nr; i += 256) { const int c = int(L[i].length / step) + 2; num[i] = c; lm_num[i] = c; }
   __syncthreads();
   if (threadIdx.x == 0) {
     int s = 0;
-    for (int i = 0; i < nr; ++i) { off[i] = s; s += num[i]; }
+    for (int i = 0; i < nr; ++i) { const int c = lm_num[i]; lm_num[i] = s; s += c; }
     total = s;
     B.nK[p] = s <= B.maxK ? s : 0;
     B.valid[p] = s <= B.maxK ? 1 : -1;
   }
   __syncthreads();
   if (total > B.maxK) return;
+  for (int i = threadIdx.x; i < nr; i += 256) off[i] = lm_num[i];
   float2* kps = B.kpsRef + (size_t)p * B.maxK;
   for (int i = threadIdx.x; i < nr; i += 256) {
     const float x1 = L[i].line_endpoint[0], y1 = L[i].line_endpoint[1], x2 = L[i].line_endpoint[2], y2 = L[i].line_endpoint[3];
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void k_lm_anchors(LmBatch B) {
     const float ddx = step * dirx, ddy = step * diry;
     const int iter = num[i] - 2;
     float px = x1, py = y1;
-    float2* o = kps + off[i];
+    float2* o = kps + lm_num[i];
     for (int j = 0; j <= iter; ++j) {
       o[j] = make_float2(px, py);
       px += ddx;
@@ -219,14 +221,24 @@ __device__ __forceinline__ void lm_norm_params(int sI, long long qI, int sJ, lon
 
 // chunk plan: 64 key points per wave, chunks of all pairs in one list (prefix over the pairs), work counter reset
 __global__ __launch_bounds__(64) void k_lm_plan(LmBatch B) {
-  if (threadIdx.x != 0) return;
-  int s = 0;
-  for (int p = 0; p < B.nPairs; ++p) {
-    B.chunkOff[p] = s;
-    s += (B.nK[p] + 63) >> 6;
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int p0 = 0; p0 < B.nPairs; p0 += 64) {   // 64 pairs per trip: one load latency, inclusive scan by shuffles
+    const int p = p0 + lane;
+    const int c = p < B.nPairs ? (B.nK[p] + 63) >> 6 : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (p < B.nPairs) B.chunkOff[p] = base + incl - c;
+    base += __shfl(incl, 63, 64);
   }
-  B.chunkOff[B.nPairs] = s;
-  *B.workCounter = 0;
+  if (lane == 0) {
+    B.chunkOff[B.nPairs] = base;
+    *B.workCounter = 0;
+  }
 }
 
 // Persistent waves: each takes chunks of 64 key points from the work counter.  Per lane: the I / dIx / dIy window of

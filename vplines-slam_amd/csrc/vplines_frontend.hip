@@ -312,7 +312,7 @@ int vpl_match_run(vpl_fe_ctx* c, const vpl_match_param* p) {
   hipLaunchKernelGGL(k_lm_level0, dim3(blocks(0), c->n), dim3(256), 0, s, M);
   for (int l = 1; l < M.nLevels; ++l) hipLaunchKernelGGL(k_lm_down, dim3(blocks(l), c->n), dim3(256), 0, s, M, l);
   hipLaunchKernelGGL(k_lm_scharr, dim3(blocks(0), c->n, M.nLevels), dim3(256), 0, s, M);
-  hipLaunchKernelGGL(k_lm_anchors, dim3(c->nPairs), dim3(256), 0, s, M);
+  hipLaunchKernelGGL(k_lm_anchors, dim3(c->nPairs), dim3(256), (size_t)M.maxLines * sizeof(int), s, M);
   hipLaunchKernelGGL(k_lm_plan, dim3(1), dim3(64), 0, s, M);
   hipLaunchKernelGGL(k_lm_klt, dim3(LM_KLT_GRID), dim3(64), LM_KLT_SMEM, s, M);
   hipLaunchKernelGGL(k_lm_vote, dim3(c->nPairs), dim3(256), (2 * M.maxLines + 1) * sizeof(int), s, M);
