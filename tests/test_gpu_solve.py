@@ -294,3 +294,19 @@ def test_margin_second_new(gpu_ctx):
     wg = [Bw[0].copy()]
     pri_g, rep_g = gpu_ctx.solve_windows(wg, opt)
     assert pri_g[0].n == 0 and rep_g[0].prior_n == 0
+
+
+@pytest.mark.parametrize("P,L,vp", [(0, 0, False), (1, 0, False), (3, 2, True), (17, 0, False), (256, 128, True)])
+def test_tiny_and_full_capacity_windows(gpu_ctx, P, L, vp):
+    """IMU-only windows, a single track, and the context's full capacity (256 points + 128 lines): no fault, same
+    iteration pattern and poses as the oracle."""
+    ws, opt = make_windows(3, P, L, vp, seed0=900)
+    wg = [w.copy() for w in ws]
+    wc = [w.copy() for w in ws]
+    pri_g, rep_g = gpu_ctx.solve_windows(wg, opt)
+    for i in range(3):
+        pri_c, rep_c = o.solve_window(wc[i], opt)
+        assert rep_g[i].iterations == rep_c.iterations and rep_g[i].termination == rep_c.termination
+        dp, dr = pose_err(wg[i], wc[i])
+        assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)
+        assert pri_g[i].n == pri_c.n
