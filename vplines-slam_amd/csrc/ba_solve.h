@@ -588,25 +588,38 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
     //      that every 72-wide row of W is read as one contiguous 576-byte segment
     {
       const int sub = lane & 7, grp = tid >> 3;   // 64 row groups per pass
-      for (int p0 = 0; p0 < nP; p0 += T / 8) {
-        const int p = p0 + grp;
-        double wy = 0.0;
-        size_t pi = 0;
-        if (p < nP) {
-          pi = (size_t)w * B.maxP + p;
-          const double* Wr = B.Wp + pi * NV + 9 * sub;
+      for (int p0 = 0; p0 < nP; p0 += 2 * (T / 8)) {   // two row groups per trip: their loads are in flight together
+        double wyv[2] = {0.0, 0.0}, sv[2], dv[2], hv[2], gv2[2], grv[2];
+        size_t piv[2];
 #pragma unroll
-          for (int k = 0; k < 9; ++k) wy += Wr[k] * uc[vis2cam(9 * sub + k)];
+        for (int h = 0; h < 2; ++h) {
+          const int p = p0 + h * (T / 8) + grp;
+          piv[h] = (size_t)w * B.maxP + (p < nP ? p : 0);
+          sv[h] = dv[h] = 1.0; hv[h] = gv2[h] = grv[h] = 0.0;
+          if (p < nP) {
+            const double* Wr = B.Wp + piv[h] * NV + 9 * sub;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wyv[h] += Wr[k] * uc[vis2cam(9 * sub + k)];
+            if (sub == 0) {
+              sv[h] = gscale[LP + p]; dv[h] = gdiag[LP + p]; hv[h] = B.Hpp[piv[h]]; gv2[h] = B.gp[piv[h]];
+              grv[h] = ggrad[LP + p];
+            }
+          }
         }
-        wy += __shfl_xor(wy, 1, 64); wy += __shfl_xor(wy, 2, 64); wy += __shfl_xor(wy, 4, 64);
-        if (p < nP && sub == 0) {
-          const double s = gscale[LP + p], d = gdiag[LP + p];
-          const double Al = s * s * B.Hpp[pi] + mu * d * d;
-          const double y = s * (B.gp[pi] - wy) / Al;
-          const double gnv = -d * y;
-          ggn[LP + p] = gnv;
-          a2 += gnv * gnv;
-          a3 += ggrad[LP + p] * gnv;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int p = p0 + h * (T / 8) + grp;
+          double wy = wyv[h];
+          wy += __shfl_xor(wy, 1, 64); wy += __shfl_xor(wy, 2, 64); wy += __shfl_xor(wy, 4, 64);
+          if (p < nP && sub == 0) {
+            const double s = sv[h], d = dv[h];
+            const double Al = s * s * hv[h] + mu * d * d;
+            const double y = s * (gv2[h] - wy) / Al;
+            const double gnv = -d * y;
+            ggn[LP + p] = gnv;
+            a2 += gnv * gnv;
+            a3 += grv[h] * gnv;
+          }
         }
       }
       for (int r0 = 0; r0 < 4 * nL; r0 += T / 8) {
