@@ -226,6 +226,10 @@ int vpl_ba_solve_windows(vpl_ctx* ctx, int n_windows, vpl_window* windows, const
  * from the two observations with the largest plane angle (skipped when cos > 0.998); on success line_plk[i] is written
  * and line_triangulated[i] set.  Synchronous (upload, kernel, download). */
 int vpl_ba_triangulate_lines(vpl_ctx* ctx, int n_windows, vpl_window* windows);
+/* FeatureManager::triangulate (feature_manager.cpp:565-621): tracks whose inv_depth is negative (estimated_depth not set,
+ * -1 in the reference) get the depth of the DLT / SVD over all their observations; a result below 0.1 becomes init_depth
+ * (INIT_DEPTH = 5.0, parameters.cpp:138).  inv_depth is written.  Synchronous. */
+int vpl_ba_triangulate_points(vpl_ctx* ctx, int n_windows, vpl_window* windows, double init_depth);
 /* Estimator::onlyLineOpt (estimator.cpp:950-1039): line-only Levenberg-Marquardt with the poses and the extrinsic
  * constant, CauchyLoss(1.0), at most options.num_iterations iterations, then double2vector + removeLineOutlier.
  * Updates line_plk / line_removed of the triangulated lines; windows with fewer than four such lines are left untouched

@@ -134,4 +134,44 @@ void sym_eigen(const MatX& Ain, VecX& w, MatX& V) {
   V = Vs;
 }
 
+// Right singular vectors of an m x 4 matrix (row-major) by one-sided (Hestenes) Jacobi on its columns: the columns are
+// rotated until mutually orthogonal, V accumulates the rotations.  V (4 x 4, row-major) is returned with its columns
+// sorted by decreasing singular value, as Eigen::JacobiSVD::matrixV() is.
+void svd4_right(const double* A_in, int m, double* V) {
+  std::vector<double> A(A_in, A_in + (size_t)m * 4);
+  for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int r = 0; r < m; ++r) { al += A[r * 4 + p] * A[r * 4 + p]; be += A[r * 4 + q] * A[r * 4 + q]; ga += A[r * 4 + p] * A[r * 4 + q]; }
+        if (ga == 0.0 || std::fabs(ga) <= 1e-15 * std::sqrt(al * be)) continue;
+        rotated = true;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+        for (int r = 0; r < m; ++r) {
+          const double a = A[r * 4 + p], b = A[r * 4 + q];
+          A[r * 4 + p] = c * a - sn * b;
+          A[r * 4 + q] = sn * a + c * b;
+        }
+        for (int r = 0; r < 4; ++r) {
+          const double a = V[r * 4 + p], b = V[r * 4 + q];
+          V[r * 4 + p] = c * a - sn * b;
+          V[r * 4 + q] = sn * a + c * b;
+        }
+      }
+    if (!rotated) break;
+  }
+  double sv[4];
+  for (int c = 0; c < 4; ++c) { double s = 0; for (int r = 0; r < m; ++r) s += A[r * 4 + c] * A[r * 4 + c]; sv[c] = s; }
+  for (int i = 0; i < 3; ++i)           // selection sort of the columns, largest singular value first
+    for (int j = i + 1; j < 4; ++j)
+      if (sv[j] > sv[i]) {
+        std::swap(sv[i], sv[j]);
+        for (int r = 0; r < 4; ++r) std::swap(V[r * 4 + i], V[r * 4 + j]);
+      }
+}
+
 }  // namespace orc

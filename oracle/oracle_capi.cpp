@@ -9,6 +9,7 @@
 
 namespace orc {
 int triangulate_lines(vpl_window* w, const vpl_ba_options* opt);
+int triangulate_points(vpl_window* w, const vpl_ba_options* opt, double init_depth);
 int only_line_opt(vpl_window* w, const vpl_ba_options* opt, vpl_solve_report* rep);
 int solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_out, vpl_solve_report* rep,
                  double* A_final_out, double* b_final_out);
@@ -142,6 +143,7 @@ int orc_solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_
 }
 
 int orc_triangulate_lines(vpl_window* w, const vpl_ba_options* opt) { return triangulate_lines(w, opt); }
+int orc_triangulate_points(vpl_window* w, const vpl_ba_options* opt, double init_depth) { return triangulate_points(w, opt, init_depth); }
 int orc_only_line_opt(vpl_window* w, const vpl_ba_options* opt, vpl_solve_report* rep) { return only_line_opt(w, opt, rep); }
 
 // windows fanned over `threads` host threads (cpu_baseline leg of bench.py)

@@ -181,5 +181,7 @@ void cholesky_solve(const MatX& L, VecX& b);
 bool inverse_lu(const MatX& A, MatX& Ainv);
 // Symmetric eigen-decomposition (cyclic Jacobi): A = V diag(w) V^T, eigenvalues ascending.
 void sym_eigen(const MatX& A, VecX& w, MatX& V);
+// right singular vectors (columns of V, 4 x 4 row-major, decreasing singular value) of an m x 4 row-major matrix
+void svd4_right(const double* A, int m, double* V);
 
 }  // namespace orc

@@ -126,6 +126,47 @@ struct Est {
     }
   }
 
+  // FeatureManager::triangulate, feature_manager.cpp:565-621: DLT over all observations of a track in the start camera
+  // frame; the depth is V(2)/V(3) of the right singular vector of the smallest singular value (Eigen::JacobiSVD in the
+  // reference, third party; restated as a one-sided Jacobi SVD on the four columns).  Returns the number of tracks done.
+  int triangulate(double init_depth) {
+    int done = 0;
+    for (PointTrack& F : feature) {
+      if (F.estimated_depth > 0) continue;
+      const int imu_i = F.start_frame;
+      int imu_j = imu_i - 1;
+      Vec3 t0 = Ps[imu_i] + Rs[imu_i] * tic;
+      Mat3 R0 = Rs[imu_i] * ric;
+      const int m = 2 * (int)F.obs.size();
+      std::vector<double> A((size_t)m * 4);
+      int row = 0;
+      for (auto& ob : F.obs) {
+        imu_j++;
+        Vec3 t1 = Ps[imu_j] + Rs[imu_j] * tic;
+        Mat3 R1 = Rs[imu_j] * ric;
+        Vec3 t = R0.T() * (t1 - t0);
+        Mat3 R = R0.T() * R1;
+        Mat3 Rt = R.T();
+        Vec3 mt = -(Rt * t);
+        double P[3][4];
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) P[r][c] = Rt(r, c); P[r][3] = mt[r]; }
+        Vec3 f = ob / ob.norm();
+        for (int c = 0; c < 4; ++c) A[(size_t)row * 4 + c] = f[0] * P[2][c] - f[2] * P[0][c];
+        ++row;
+        for (int c = 0; c < 4; ++c) A[(size_t)row * 4 + c] = f[1] * P[2][c] - f[2] * P[1][c];
+        ++row;
+      }
+      double V[16];
+      svd4_right(A.data(), m, V);
+      // columns of V sorted by decreasing singular value: the last one belongs to the smallest
+      double depth = V[2 * 4 + 3] / V[3 * 4 + 3];
+      if (depth < 0.1) depth = init_depth;
+      F.estimated_depth = depth;
+      ++done;
+    }
+    return done;
+  }
+
   // FeatureManager::triangulateLine, feature_manager.cpp:413-563; returns the number of lines triangulated now
   int triangulateLine() {
     int done = 0;
@@ -584,6 +625,17 @@ int triangulate_lines(vpl_window* w, const vpl_ba_options* opt) {
     for (int c = 0; c < 6; ++c) w->line_plk[6 * L.index + c] = L.line_plucker[c];
     if (w->line_triangulated) w->line_triangulated[L.index] = 1;
   }
+  return done;
+}
+
+// FeatureManager::triangulate on the tracks of the window whose inv_depth is <= 0 (estimated_depth not set: the reference
+// initialises it to -1); writes inv_depth.  Returns the number of tracks triangulated.
+int triangulate_points(vpl_window* w, const vpl_ba_options* opt, double init_depth) {
+  Est e;
+  load_window(*w, *opt, e, true);
+  const int done = e.triangulate(init_depth);
+  for (size_t i = 0; i < e.feature.size(); ++i)
+    if (w->inv_depth[i] < 0.0) w->inv_depth[i] = 1.0 / e.feature[i].estimated_depth;   // the others were not touched
   return done;
 }
 

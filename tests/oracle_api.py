@@ -286,3 +286,11 @@ def only_line_opt(w, opt):
     rc = lib.orc_only_line_opt(C.byref(cw), C.byref(opt), C.byref(rep))
     assert rc == 0
     return rep
+
+
+def triangulate_points(w, opt, init_depth=5.0):
+    """FeatureManager::triangulate on Window w (tracks with inv_depth < 0). Returns the number done."""
+    lib = load()
+    cw = w.to_c()
+    lib.orc_triangulate_points.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+    return lib.orc_triangulate_points(C.byref(cw), C.byref(opt), init_depth)

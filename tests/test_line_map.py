@@ -9,13 +9,15 @@ import oracle_api as o
 import vplines_slam_amd as v
 
 
-def make(seed, L=40, P=60, sigma_px=0.3, pose_noise=False, t=0.3, orth_sigma=0.0):
+def make(seed, L=40, P=60, sigma_px=0.3, pose_noise=False, t=0.3, orth_sigma=0.0, depth_sigma=None):
     opt = v.default_options()
     cfg = v.workload.config(P, L, True)
     if not pose_noise:
         cfg.pose_sigma_p = cfg.pose_sigma_theta_deg = 0.0
     cfg.pix_sigma = sigma_px / 460.0
     cfg.orth_sigma = orth_sigma                  # 0: line_plk of the generated window is the true line
+    if depth_sigma is not None:
+        cfg.depth_rel_sigma = depth_sigma
     w = v.workload.generate(seed, cfg, t)
     o.preintegrate_windows([w], opt)
     return w, opt
@@ -155,3 +157,63 @@ def test_gpu_only_line_opt_matches_oracle(gpu_ctx):
             assert reps[i].n_lines_removed == rc.n_lines_removed
             scale = np.abs(wc[i].line_plk).max(axis=1, keepdims=True) + 1e-300
             assert (np.abs(wg[i].line_plk - wc[i].line_plk) / scale).max() < 1e-7
+
+
+# ---- FeatureManager::triangulate (points, feature_manager.cpp:565-621) --------------------------------
+def numpy_triangulate_point(w, p):
+    """independent DLT + LAPACK SVD for point track p; returns the depth in the start camera frame"""
+    ric, tic = quat_R(w.ex_pose), w.ex_pose[:3]
+    off = int(np.sum(w.point_nobs[:p]))
+    s, no = int(w.point_start[p]), int(w.point_nobs[p])
+    cams = [(quat_R(w.pose[s + k]) @ ric, w.pose[s + k, :3] + quat_R(w.pose[s + k]) @ tic) for k in range(no)]
+    R0, t0 = cams[0]
+    rows = []
+    for k in range(no):
+        R, t = R0.T @ cams[k][0], R0.T @ (cams[k][1] - t0)
+        P = np.hstack([R.T, (-R.T @ t)[:, None]])
+        f = w.point_obs[off + k] / np.linalg.norm(w.point_obs[off + k])
+        rows += [f[0] * P[2] - f[2] * P[0], f[1] * P[2] - f[2] * P[1]]
+    v4 = np.linalg.svd(np.array(rows))[2][-1]
+    return v4[2] / v4[3]
+
+
+def test_oracle_triangulate_points_matches_numpy_and_truth():
+    w, opt = make(31, sigma_px=0.0, t=0.2, depth_sigma=0.0)
+    truth = w.inv_depth.copy()
+    w.inv_depth[::2] = -1.0
+    n = o.triangulate_points(w, opt)
+    assert n == len(truth[::2])
+    assert np.array_equal(w.inv_depth[1::2], truth[1::2])            # tracks that have a depth are left alone
+    assert np.abs(w.inv_depth / truth - 1).max() < 1e-9              # noise-free: the DLT null vector is the point
+    w2, _ = make(32, sigma_px=0.5, pose_noise=True, t=0.5)
+    w2.inv_depth[:] = -1.0
+    o.triangulate_points(w2, opt, 7.0)
+    for p in range(len(w2.inv_depth)):
+        d = numpy_triangulate_point(w2, p)
+        want = 1.0 / (d if d >= 0.1 else 7.0)
+        assert abs(w2.inv_depth[p] - want) <= 1e-9 * abs(want)
+    # behind the camera / too close -> INIT_DEPTH
+    w3, _ = make(33, sigma_px=0.0)
+    w3.inv_depth[:] = -1.0
+    w3.point_obs[:, :2] *= -1.0                                      # mirrored bearings: no positive-depth intersection
+    o.triangulate_points(w3, opt, 5.0)
+    assert np.mean(w3.inv_depth == 1.0 / 5.0) > 0.5
+
+
+@pytest.mark.gpu
+def test_gpu_triangulate_points_matches_oracle(gpu_ctx):
+    ws = []
+    for i in range(6):
+        w, opt = make(300 + i, P=(5 if i == 4 else 60), sigma_px=0.5, pose_noise=(i % 2 == 1), t=0.2 * i)
+        w.inv_depth[i % 3::3] = -1.0
+        if i == 5:
+            w.inv_depth[:] = -1.0
+            w.point_obs[::2, :2] *= -1.0
+        ws.append(w)
+    wg = [w.copy() for w in ws]
+    gpu_ctx.triangulate_points(wg, 5.0)
+    for g, c in zip(wg, ws):
+        before = c.inv_depth.copy()
+        o.triangulate_points(c, opt, 5.0)
+        assert np.array_equal(g.inv_depth[before > 0], before[before > 0])
+        assert np.abs(g.inv_depth / c.inv_depth - 1).max() < 1e-9

@@ -175,6 +175,7 @@ def load_hip_library():
     lib.vpl_ba_solve_windows.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(Prior),
                                          C.POINTER(SolveReport)]
     lib.vpl_ba_triangulate_lines.argtypes = [vp, C.c_int, C.POINTER(CWindow)]
+    lib.vpl_ba_triangulate_points.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.c_double]
     lib.vpl_ba_only_line_opt.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(SolveReport)]
     lib.vpl_ba_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.vpl_ba_kernel_times.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), _dp, _ip]
@@ -326,6 +327,14 @@ class Context:
         for i, w in enumerate(windows):
             w.to_c(cw[i])
         self._check(self.lib.vpl_ba_triangulate_lines(self.h, n, cw), "vpl_ba_triangulate_lines")
+
+    def triangulate_points(self, windows, init_depth=5.0):
+        """FeatureManager::triangulate on the device; updates inv_depth of the Windows in place"""
+        n = len(windows)
+        cw = (CWindow * n)()
+        for i, w in enumerate(windows):
+            w.to_c(cw[i])
+        self._check(self.lib.vpl_ba_triangulate_points(self.h, n, cw, init_depth), "vpl_ba_triangulate_points")
 
     def only_line_opt(self, windows, opt):
         """Estimator::onlyLineOpt on the device; updates line_plk / line_removed in place, returns the reports"""

@@ -73,6 +73,84 @@ __global__ __launch_bounds__(128) void k_triangulate(DevBatch B) {
   }
 }
 
+// FeatureManager::triangulate (feature_manager.cpp:565-621), one lane per track whose inverse depth is negative (the
+// reference's estimated_depth = -1): DLT rows of every observation in the start camera frame, one-sided Jacobi SVD of
+// the 2m x 4 matrix (kept in per-lane scratch: this runs once per new track, not in the solve loop).
+__global__ __launch_bounds__(128) void k_triangulate_points(DevBatch B, double init_depth) {
+  const int w = blockIdx.x;
+  const int nP = B.nP[w];
+  const double* pose = B.pose + (size_t)w * 77;
+  const double* ex = B.ex + (size_t)w * 7;
+  const M3 ric = qmat(qnormalized(qpose(ex)));
+  const V3 tic{ex[0], ex[1], ex[2]};
+  for (int p = threadIdx.x; p < nP; p += blockDim.x) {
+    const size_t pi = (size_t)w * B.maxP + p;
+    if (!(B.invd[pi] < 0.0)) continue;
+    const int s = B.pt_start[pi], no = B.pt_nobs[pi];
+    const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + B.pt_off[pi]) * 3;
+    const double* x0 = pose + 7 * s;
+    const M3 Rs0 = qmat(qnormalized(qpose(x0)));
+    const V3 t0 = V3{x0[0], x0[1], x0[2]} + mul(Rs0, tic);
+    const M3 R0 = mul(Rs0, ric);
+    double A[2 * NF * 4];
+    const int m = 2 * no;
+    for (int k = 0; k < no; ++k) {
+      const double* xj = pose + 7 * (s + k);
+      const M3 Rsj = qmat(qnormalized(qpose(xj)));
+      const V3 t1 = V3{xj[0], xj[1], xj[2]} + mul(Rsj, tic);
+      const M3 R1 = mul(Rsj, ric);
+      const V3 t = mulT(R0, t1 - t0);
+      const M3 R = mulTA(R0, R1);
+      const M3 Rt = transpose(R);
+      const V3 mt = -mul(Rt, t);
+      const double* ob = o0 + 3 * k;
+      const double rn = sqrt(ob[0] * ob[0] + ob[1] * ob[1] + ob[2] * ob[2]);
+      const double f0 = ob[0] / rn, f1 = ob[1] / rn, f2 = ob[2] / rn;
+      for (int c = 0; c < 4; ++c) {
+        const double P0 = c < 3 ? Rt.m[c] : mt.x, P1 = c < 3 ? Rt.m[3 + c] : mt.y, P2 = c < 3 ? Rt.m[6 + c] : mt.z;
+        A[(2 * k) * 4 + c] = f0 * P2 - f2 * P0;
+        A[(2 * k + 1) * 4 + c] = f1 * P2 - f2 * P1;
+      }
+    }
+    double V[16];
+    for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+      bool rotated = false;
+      for (int pp = 0; pp < 3; ++pp)
+        for (int q = pp + 1; q < 4; ++q) {
+          double al = 0, be = 0, ga = 0;
+          for (int r = 0; r < m; ++r) { al += A[r * 4 + pp] * A[r * 4 + pp]; be += A[r * 4 + q] * A[r * 4 + q]; ga += A[r * 4 + pp] * A[r * 4 + q]; }
+          if (ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be)) continue;
+          rotated = true;
+          const double zeta = (be - al) / (2.0 * ga);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+          for (int r = 0; r < m; ++r) {
+            const double a = A[r * 4 + pp], b = A[r * 4 + q];
+            A[r * 4 + pp] = c * a - sn * b;
+            A[r * 4 + q] = sn * a + c * b;
+          }
+          for (int r = 0; r < 4; ++r) {
+            const double a = V[r * 4 + pp], b = V[r * 4 + q];
+            V[r * 4 + pp] = c * a - sn * b;
+            V[r * 4 + q] = sn * a + c * b;
+          }
+        }
+      if (!rotated) break;
+    }
+    int cmin = 0;
+    double smin = 0;
+    for (int c = 0; c < 4; ++c) {
+      double s2 = 0;
+      for (int r = 0; r < m; ++r) s2 += A[r * 4 + c] * A[r * 4 + c];
+      if (c == 0 || s2 < smin) { smin = s2; cmin = c; }   // (ties resolved to the first column, as the oracle's sort)
+    }
+    double depth = V[2 * 4 + cmin] / V[3 * 4 + cmin];
+    if (depth < 0.1) depth = init_depth;
+    B.invd[pi] = 1.0 / depth;
+  }
+}
+
 // ---- onlyLineOpt ------------------------------------------------------------------------------------------
 constexpr int LOPT_THREADS = 256;
 

@@ -592,6 +592,27 @@ int vpl_ba_triangulate_lines(vpl_ctx* c, int nW, vpl_window* win) {
   return VPL_OK;
 }
 
+// FeatureManager::triangulate for a batch: upload, k_triangulate_points, inverse depths back
+int vpl_ba_triangulate_points(vpl_ctx* c, int nW, vpl_window* win, double init_depth) {
+  if (!c || !win || nW < 1 || !(init_depth > 0.0)) return VPL_E_INVALID;
+  vpl_ba_options opt;
+  vpl_ba_default_options(&opt);
+  opt.marginalization_flag = VPL_MARGIN_NONE;
+  int rc = upload_impl(c, nW, win, &opt, true);
+  if (rc) return rc;
+  DevBatch& B = c->B;
+  hipStream_t s = c->stream;
+  { KTimer t(c, "k_triangulate_points"); hipLaunchKernelGGL(k_triangulate_points, dim3(nW), dim3(128), 0, s, B, init_depth); }
+  HIPCHK(c, hipGetLastError());
+  const size_t W = nW;
+  std::vector<double> invd(W * B.maxP);
+  HIPCHK(c, hipMemcpyAsync(invd.data(), B.invd, invd.size() * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (size_t w = 0; w < W; ++w)
+    for (int p = 0; p < win[w].n_points; ++p) win[w].inv_depth[p] = invd[w * B.maxP + p];
+  return VPL_OK;
+}
+
 // Estimator::onlyLineOpt for a batch: upload (triangulated lines), k_prep (world orth of the lines), k_line_opt (the LM
 // loop), k_gauge (setLineOrth + removeLineOutlier; the gauge transform is the identity, the poses did not move)
 int vpl_ba_only_line_opt(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt_in, vpl_solve_report* reports) {
