@@ -226,6 +226,26 @@ int vpl_ba_solve_windows(vpl_ctx* ctx, int n_windows, vpl_window* windows, const
  * from the two observations with the largest plane angle (skipped when cos > 0.998); on success line_plk[i] is written
  * and line_triangulated[i] set.  Synchronous (upload, kernel, download). */
 int vpl_ba_triangulate_lines(vpl_ctx* ctx, int n_windows, vpl_window* windows);
+/* What Estimator::slideWindow did to the track lists of one window (the lists themselves stay with the caller) */
+typedef struct vpl_slide_tracks {
+  int* point_start; /* [n_points] start_frame after the slide */
+  int* point_nobs;  /* [n_points] observations left; 0 = the track was erased */
+  int* point_drop;  /* [n_points] index (within the track) of the observation that was removed, -1 = none */
+  int* line_start;  /* [n_lines] */
+  int* line_nobs;   /* [n_lines] */
+  int* line_drop;   /* [n_lines] */
+} vpl_slide_tracks;
+/* Estimator::slideWindow (estimator.cpp:1731-1851) of full windows in the NON_LINEAR state.
+ * VPL_MARGIN_OLD: pose / speed_bias move one frame down (frame 10 keeps the newest state), then
+ *   FeatureManager::removeBackShiftDepth (feature_manager.cpp:800-874): tracks that started in frame 0 lose that observation,
+ *   are erased when fewer than two remain, else are re-anchored in the next frame -- inv_depth from the point carried over
+ *   (non-positive depth -> init_depth), line_plk by plk_to_pose; all other tracks start one frame earlier.
+ * VPL_MARGIN_SECOND_NEW: frame 10 is copied over frame 9, then FeatureManager::removeFront (feature_manager.cpp:915-956).
+ * pose, speed_bias, inv_depth, line_plk are updated in place; the new track layout is reported in `tracks`.  The IMU
+ * buffers (preint) are the caller's: the reference re-integrates them sample by sample (estimator.cpp:1786-1797).
+ * Every track of the FeatureManager may be passed (any length >= 1, any start frame).  Synchronous. */
+int vpl_ba_slide_window(vpl_ctx* ctx, int n_windows, vpl_window* windows, int marginalization_flag, double init_depth,
+                        vpl_slide_tracks* tracks);
 /* FeatureManager::triangulate (feature_manager.cpp:565-621): tracks whose inv_depth is negative (estimated_depth not set,
  * -1 in the reference) get the depth of the DLT / SVD over all their observations; a result below 0.1 becomes init_depth
  * (INIT_DEPTH = 5.0, parameters.cpp:138).  inv_depth is written.  Synchronous. */

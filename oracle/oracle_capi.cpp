@@ -10,6 +10,7 @@
 namespace orc {
 int triangulate_lines(vpl_window* w, const vpl_ba_options* opt);
 int triangulate_points(vpl_window* w, const vpl_ba_options* opt, double init_depth);
+int slide_window(vpl_window* w, const vpl_ba_options* opt, int marginalization_flag, double init_depth, vpl_slide_tracks* out);
 int only_line_opt(vpl_window* w, const vpl_ba_options* opt, vpl_solve_report* rep);
 int solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_out, vpl_solve_report* rep,
                  double* A_final_out, double* b_final_out);
@@ -144,6 +145,9 @@ int orc_solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_
 
 int orc_triangulate_lines(vpl_window* w, const vpl_ba_options* opt) { return triangulate_lines(w, opt); }
 int orc_triangulate_points(vpl_window* w, const vpl_ba_options* opt, double init_depth) { return triangulate_points(w, opt, init_depth); }
+int orc_slide_window(vpl_window* w, const vpl_ba_options* opt, int flag, double init_depth, vpl_slide_tracks* out) {
+  return slide_window(w, opt, flag, init_depth, out);
+}
 int orc_only_line_opt(vpl_window* w, const vpl_ba_options* opt, vpl_solve_report* rep) { return only_line_opt(w, opt, rep); }
 
 // windows fanned over `threads` host threads (cpu_baseline leg of bench.py)

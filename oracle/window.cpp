@@ -27,6 +27,7 @@ struct PointTrack {
   std::vector<Vec3> obs;
   double estimated_depth;
   int solve_flag = 0;
+  int index = 0;               // position in the vpl_window arrays
 };
 
 // The slice of Estimator state that optimizationwithLine touches.  Member order
@@ -300,6 +301,7 @@ void load_window(const vpl_window& w, const vpl_ba_options& opt, Est& e, bool al
     for (int k = 0; k < w.point_nobs[i]; ++k, ++off)
       t.obs.push_back(Vec3{w.point_obs[3 * off], w.point_obs[3 * off + 1], w.point_obs[3 * off + 2]});
     t.estimated_depth = 1.0 / w.inv_depth[i];
+    t.index = i;
     e.feature.push_back(t);
   }
   off = 0;
@@ -637,6 +639,97 @@ int triangulate_points(vpl_window* w, const vpl_ba_options* opt, double init_dep
   for (size_t i = 0; i < e.feature.size(); ++i)
     if (w->inv_depth[i] < 0.0) w->inv_depth[i] = 1.0 / e.feature[i].estimated_depth;   // the others were not touched
   return done;
+}
+
+// Estimator::slideWindow (estimator.cpp:1731-1851) for a full window in the NON_LINEAR state, with the FeatureManager
+// calls behind it: MARGIN_OLD -> state swaps + removeBackShiftDepth (feature_manager.cpp:800-874),
+// otherwise -> frame 10 copied over frame 9 + removeFront (feature_manager.cpp:915-956).
+// The IMU buffers / IntegrationBase objects stay with the caller (they are re-integrated sample by sample, :1786-1797).
+int slide_window(vpl_window* w, const vpl_ba_options* opt, int marginalization_flag, double init_depth, vpl_slide_tracks* out) {
+  Est e;
+  load_window(*w, *opt, e, true);
+  constexpr int WINDOW_SIZE = VPL_NFRAMES - 1;
+  const int frame_count = WINDOW_SIZE;
+  for (int i = 0; i < w->n_points; ++i) { out->point_start[i] = w->point_start[i]; out->point_nobs[i] = 0; out->point_drop[i] = -1; }
+  for (int i = 0; i < w->n_lines; ++i) { out->line_start[i] = w->line_start[i]; out->line_nobs[i] = 0; out->line_drop[i] = -1; }
+  if (marginalization_flag == VPL_MARGIN_OLD) {
+    const Mat3 back_R0 = e.Rs[0];
+    const Vec3 back_P0 = e.Ps[0];
+    for (int i = 0; i < WINDOW_SIZE; ++i) {
+      std::swap(e.Rs[i], e.Rs[i + 1]);
+      std::swap(e.Ps[i], e.Ps[i + 1]);
+      for (int c = 0; c < 7; ++c) std::swap(w->pose[i][c], w->pose[i + 1][c]);
+      for (int c = 0; c < 9; ++c) std::swap(w->speed_bias[i][c], w->speed_bias[i + 1][c]);
+    }
+    e.Rs[WINDOW_SIZE] = e.Rs[WINDOW_SIZE - 1];
+    e.Ps[WINDOW_SIZE] = e.Ps[WINDOW_SIZE - 1];
+    for (int c = 0; c < 7; ++c) w->pose[WINDOW_SIZE][c] = w->pose[WINDOW_SIZE - 1][c];
+    for (int c = 0; c < 9; ++c) w->speed_bias[WINDOW_SIZE][c] = w->speed_bias[WINDOW_SIZE - 1][c];
+    // slideWindowOld (:1828-1851), shift_depth = true
+    const Mat3 marg_R = back_R0 * e.ric, new_R = e.Rs[0] * e.ric;
+    const Vec3 marg_P = back_P0 + back_R0 * e.tic, new_P = e.Ps[0] + e.Rs[0] * e.tic;
+    for (size_t k = 0; k < e.feature.size();) {
+      PointTrack& it = e.feature[k];
+      if (it.start_frame != 0) { it.start_frame--; ++k; continue; }
+      const Vec3 uv_i = it.obs[0];
+      it.obs.erase(it.obs.begin());
+      out->point_drop[it.index] = 0;
+      if (it.obs.size() < 2) { e.feature.erase(e.feature.begin() + k); continue; }
+      const Vec3 pts_i = uv_i * it.estimated_depth;
+      const Vec3 w_pts_i = marg_R * pts_i + marg_P;
+      const Vec3 pts_j = new_R.T() * (w_pts_i - new_P);
+      const double dep_j = pts_j[2];
+      it.estimated_depth = dep_j > 0 ? dep_j : init_depth;
+      ++k;
+    }
+    for (size_t k = 0; k < e.linefeature.size();) {
+      LineTrack& it = e.linefeature[k];
+      if (it.start_frame != 0) { it.start_frame--; ++k; continue; }
+      it.obs.erase(it.obs.begin());
+      out->line_drop[it.index] = 0;
+      if (it.obs.size() < 2) { e.linefeature.erase(e.linefeature.begin() + k); continue; }
+      const Mat3 Rji = new_R.T() * marg_R;
+      const Vec3 tji = new_R.T() * (marg_P - new_P);
+      it.line_plucker = plk_to_pose(it.line_plucker, Rji, tji);
+      ++k;
+    }
+  } else {
+    for (int c = 0; c < 7; ++c) w->pose[frame_count - 1][c] = w->pose[frame_count][c];
+    for (int c = 0; c < 9; ++c) w->speed_bias[frame_count - 1][c] = w->speed_bias[frame_count][c];
+    // slideWindowNew -> removeFront(frame_count)
+    for (size_t k = 0; k < e.feature.size();) {
+      PointTrack& it = e.feature[k];
+      if (it.start_frame == frame_count) { it.start_frame--; ++k; continue; }
+      const int j = WINDOW_SIZE - 1 - it.start_frame;
+      if (it.start_frame + (int)it.obs.size() - 1 < frame_count - 1) { ++k; continue; }
+      it.obs.erase(it.obs.begin() + j);
+      out->point_drop[it.index] = j;
+      if (it.obs.empty()) { e.feature.erase(e.feature.begin() + k); continue; }
+      ++k;
+    }
+    for (size_t k = 0; k < e.linefeature.size();) {
+      LineTrack& it = e.linefeature[k];
+      if (it.start_frame == frame_count) { it.start_frame--; ++k; continue; }
+      const int j = WINDOW_SIZE - 1 - it.start_frame;
+      if (it.start_frame + (int)it.obs.size() - 1 < frame_count - 1) { ++k; continue; }
+      it.obs.erase(it.obs.begin() + j);
+      out->line_drop[it.index] = j;
+      if (it.obs.empty()) { e.linefeature.erase(e.linefeature.begin() + k); continue; }
+      ++k;
+    }
+  }
+  for (const PointTrack& t : e.feature) {
+    out->point_start[t.index] = t.start_frame;
+    out->point_nobs[t.index] = (int)t.obs.size();
+    if (marginalization_flag == VPL_MARGIN_OLD && out->point_drop[t.index] == 0) w->inv_depth[t.index] = 1.0 / t.estimated_depth;
+  }
+  for (const LineTrack& t : e.linefeature) {
+    out->line_start[t.index] = t.start_frame;
+    out->line_nobs[t.index] = (int)t.obs.size();
+    if (marginalization_flag == VPL_MARGIN_OLD && out->line_drop[t.index] == 0)
+      for (int c = 0; c < 6; ++c) w->line_plk[6 * t.index + c] = t.line_plucker[c];
+  }
+  return 0;
 }
 
 // Estimator::onlyLineOpt (estimator.cpp:950-1039): poses and extrinsic constant, line factors only (no VP factors),

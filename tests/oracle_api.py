@@ -294,3 +294,17 @@ def triangulate_points(w, opt, init_depth=5.0):
     cw = w.to_c()
     lib.orc_triangulate_points.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
     return lib.orc_triangulate_points(C.byref(cw), C.byref(opt), init_depth)
+
+
+def slide_window(w, opt, marginalization_flag, init_depth=5.0):
+    """Estimator::slideWindow on Window w (in place); returns the SlideTracks"""
+    from vplines_slam_amd.capi import SlideTracks
+    lib = load()
+    cw = w.to_c()
+    st = SlideTracks(len(w.point_start), len(w.line_start))
+    ct = st.to_c()
+    lib.orc_slide_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    rc = lib.orc_slide_window(C.byref(cw), C.byref(opt), marginalization_flag, init_depth, C.byref(ct))
+    assert rc == 0
+    w.from_c(cw)
+    return st

@@ -7,7 +7,8 @@ The HIP library is mandatory -- nothing in this package falls back to a CPU
 implementation."""
 from . import _build  # noqa: F401
 from .capi import (  # noqa: F401
-    BaOptions, Preintegration, Prior, Window, SolveReport, Context, default_options, load_hip_library,
+    BaOptions, Preintegration, Prior, Window, SolveReport, Context, SlideTracks, default_options, load_hip_library,
+    MARGIN_OLD, MARGIN_SECOND_NEW, MARGIN_NONE,
 )
 from . import workload  # noqa: F401
 from . import shard  # noqa: F401

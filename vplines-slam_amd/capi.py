@@ -138,6 +138,25 @@ class Window:
         self.ex_pose[:] = np.ctypeslib.as_array(cw.ex_pose)
 
 
+class CSlideTracks(C.Structure):
+    _fields_ = [("point_start", _ip), ("point_nobs", _ip), ("point_drop", _ip),
+                ("line_start", _ip), ("line_nobs", _ip), ("line_drop", _ip)]
+
+
+class SlideTracks:
+    """vpl_slide_tracks of one window (include/vplines_ba.h)"""
+
+    def __init__(self, n_points, n_lines):
+        self.point_start, self.point_nobs, self.point_drop = (np.zeros(n_points, np.int32) for _ in range(3))
+        self.line_start, self.line_nobs, self.line_drop = (np.zeros(n_lines, np.int32) for _ in range(3))
+
+    def to_c(self, ct=None):
+        ct = ct if ct is not None else CSlideTracks()
+        for f, _ in CSlideTracks._fields_:
+            setattr(ct, f, getattr(self, f).ctypes.data_as(_ip))
+        return ct
+
+
 _hip = None
 
 
@@ -175,6 +194,7 @@ def load_hip_library():
     lib.vpl_ba_solve_windows.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(Prior),
                                          C.POINTER(SolveReport)]
     lib.vpl_ba_triangulate_lines.argtypes = [vp, C.c_int, C.POINTER(CWindow)]
+    lib.vpl_ba_slide_window.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.c_int, C.c_double, C.POINTER(CSlideTracks)]
     lib.vpl_ba_triangulate_points.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.c_double]
     lib.vpl_ba_only_line_opt.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(SolveReport)]
     lib.vpl_ba_enable_kernel_timing.argtypes = [vp, C.c_int]
@@ -327,6 +347,22 @@ class Context:
         for i, w in enumerate(windows):
             w.to_c(cw[i])
         self._check(self.lib.vpl_ba_triangulate_lines(self.h, n, cw), "vpl_ba_triangulate_lines")
+
+    def slide_window(self, windows, marginalization_flag, init_depth=5.0):
+        """Estimator::slideWindow; pose / speed_bias / inv_depth / line_plk of the Windows change in place,
+        returns one SlideTracks (new start / nobs / dropped observation per track) per window"""
+        n = len(windows)
+        cw = (CWindow * n)()
+        ct = (CSlideTracks * n)()
+        res = []
+        for i, w in enumerate(windows):
+            w.to_c(cw[i])
+            res.append(SlideTracks(len(w.point_start), len(w.line_start)))
+            res[-1].to_c(ct[i])
+        self._check(self.lib.vpl_ba_slide_window(self.h, n, cw, marginalization_flag, init_depth, ct), "vpl_ba_slide_window")
+        for i, w in enumerate(windows):
+            w.from_c(cw[i])
+        return res
 
     def triangulate_points(self, windows, init_depth=5.0):
         """FeatureManager::triangulate on the device; updates inv_depth of the Windows in place"""

@@ -151,6 +151,38 @@ __global__ __launch_bounds__(128) void k_triangulate_points(DevBatch B, double i
   }
 }
 
+// FeatureManager::removeBackShiftDepth (feature_manager.cpp:800-874), the arithmetic: one lane per track that started in
+// the marginalised frame and survives.  fr: per window pose[0], pose[1] (before the shift) and ex_pose, 21 doubles.
+// Points pd[i] = {u, v, 1, inv_depth} -> inv_depth in the next frame; lines ld[i] = plk -> plk_to_pose(plk, Rji, tji).
+__global__ __launch_bounds__(256) void k_slide_shift(const double* __restrict__ fr, int nPts, const int* __restrict__ pw,
+                                                     double* __restrict__ pd, int nLns, const int* __restrict__ lw,
+                                                     double* __restrict__ ld, double init_depth) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nPts + nLns) return;
+  const bool is_pt = i < nPts;
+  const int k = is_pt ? i : i - nPts;
+  const double* f = fr + (size_t)(is_pt ? pw[k] : lw[k]) * 21;
+  const M3 ric = qmat(qnormalized(qpose(f + 14)));
+  const V3 tic{f[14], f[15], f[16]};
+  const M3 Rs0 = qmat(qnormalized(qpose(f))), Rs1 = qmat(qnormalized(qpose(f + 7)));
+  const M3 marg_R = mul(Rs0, ric), new_R = mul(Rs1, ric);
+  const V3 marg_P = V3{f[0], f[1], f[2]} + mul(Rs0, tic), new_P = V3{f[7], f[8], f[9]} + mul(Rs1, tic);
+  if (is_pt) {
+    double* d = pd + (size_t)k * 4;
+    const double depth = 1.0 / d[3];
+    const V3 pts_i = V3{d[0], d[1], d[2]} * depth;
+    const V3 w_pts_i = mul(marg_R, pts_i) + marg_P;
+    const V3 pts_j = mulT(new_R, w_pts_i - new_P);
+    d[3] = 1.0 / (pts_j.z > 0 ? pts_j.z : init_depth);
+  } else {
+    double* d = ld + (size_t)k * 6;
+    const M3 Rji = mulTA(new_R, marg_R);
+    const V3 tji = mulT(new_R, marg_P - new_P);
+    const Plk L = plk_to_pose(Plk{V3{d[0], d[1], d[2]}, V3{d[3], d[4], d[5]}}, Rji, tji);
+    d[0] = L.n.x; d[1] = L.n.y; d[2] = L.n.z; d[3] = L.v.x; d[4] = L.v.y; d[5] = L.v.z;
+  }
+}
+
 // ---- onlyLineOpt ------------------------------------------------------------------------------------------
 constexpr int LOPT_THREADS = 256;
 

@@ -592,6 +592,103 @@ int vpl_ba_triangulate_lines(vpl_ctx* c, int nW, vpl_window* win) {
   return VPL_OK;
 }
 
+// Estimator::slideWindow for a batch.  The list bookkeeping (start frames, dropped observations, erased tracks) is integer
+// work on the caller's arrays and is done here on the host; the re-anchoring arithmetic of removeBackShiftDepth runs in
+// k_slide_shift over the gathered start-frame-0 survivors of all windows.
+int vpl_ba_slide_window(vpl_ctx* c, int nW, vpl_window* win, int flag, double init_depth, vpl_slide_tracks* out) {
+  if (!c || !win || !out || nW < 1 || !(init_depth > 0.0)) return VPL_E_INVALID;
+  if (flag != VPL_MARGIN_OLD && flag != VPL_MARGIN_SECOND_NEW) return fail(c, VPL_E_INVALID, "slide_window: marginalization_flag");
+  constexpr int WS = VPL_NFRAMES - 1;
+  for (int w = 0; w < nW; ++w) {
+    const vpl_window& W = win[w];
+    const vpl_slide_tracks& O = out[w];
+    if ((W.n_points && (!O.point_start || !O.point_nobs || !O.point_drop || !W.point_start || !W.point_nobs || !W.point_obs || !W.inv_depth)) ||
+        (W.n_lines && (!O.line_start || !O.line_nobs || !O.line_drop || !W.line_start || !W.line_nobs || !W.line_plk)))
+      return fail(c, VPL_E_INVALID, "slide_window: null track array");
+    for (int i = 0; i < W.n_points; ++i)
+      if (W.point_nobs[i] < 1 || W.point_start[i] < 0 || W.point_start[i] + W.point_nobs[i] > VPL_NFRAMES)
+        return fail(c, VPL_E_INVALID, "slide_window: point track outside the window");
+    for (int i = 0; i < W.n_lines; ++i)
+      if (W.line_nobs[i] < 1 || W.line_start[i] < 0 || W.line_start[i] + W.line_nobs[i] > VPL_NFRAMES)
+        return fail(c, VPL_E_INVALID, "slide_window: line track outside the window");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (flag == VPL_MARGIN_SECOND_NEW) {
+    // removeFront(frame_count = WINDOW_SIZE): no arithmetic
+    auto front = [](int n, const int* start, const int* nobs, int* ostart, int* onobs, int* odrop) {
+      for (int i = 0; i < n; ++i) {
+        ostart[i] = start[i]; onobs[i] = nobs[i]; odrop[i] = -1;
+        if (start[i] == WS) { ostart[i] = WS - 1; continue; }
+        if (start[i] + nobs[i] - 1 < WS - 1) continue;
+        odrop[i] = WS - 1 - start[i];
+        onobs[i] = nobs[i] - 1;
+      }
+    };
+    for (int w = 0; w < nW; ++w) {
+      front(win[w].n_points, win[w].point_start, win[w].point_nobs, out[w].point_start, out[w].point_nobs, out[w].point_drop);
+      front(win[w].n_lines, win[w].line_start, win[w].line_nobs, out[w].line_start, out[w].line_nobs, out[w].line_drop);
+      std::memcpy(win[w].pose[WS - 1], win[w].pose[WS], sizeof(win[w].pose[0]));
+      std::memcpy(win[w].speed_bias[WS - 1], win[w].speed_bias[WS], sizeof(win[w].speed_bias[0]));
+    }
+    return VPL_OK;
+  }
+  std::vector<double> fr((size_t)nW * 21), pd, ld;
+  std::vector<int> pw, lw, pidx, lidx;
+  for (int w = 0; w < nW; ++w) {
+    const vpl_window& W = win[w];
+    std::memcpy(&fr[(size_t)w * 21], W.pose[0], 56);
+    std::memcpy(&fr[(size_t)w * 21 + 7], W.pose[1], 56);
+    std::memcpy(&fr[(size_t)w * 21 + 14], W.ex_pose, 56);
+    size_t off = 0;
+    for (int i = 0; i < W.n_points; off += W.point_nobs[i], ++i) {
+      out[w].point_drop[i] = -1;
+      if (W.point_start[i] != 0) { out[w].point_start[i] = W.point_start[i] - 1; out[w].point_nobs[i] = W.point_nobs[i]; continue; }
+      out[w].point_drop[i] = 0;
+      out[w].point_start[i] = 0;
+      out[w].point_nobs[i] = W.point_nobs[i] - 1 < 2 ? 0 : W.point_nobs[i] - 1;
+      if (!out[w].point_nobs[i]) continue;
+      pw.push_back(w); pidx.push_back(i);
+      pd.insert(pd.end(), {W.point_obs[3 * off], W.point_obs[3 * off + 1], W.point_obs[3 * off + 2], W.inv_depth[i]});
+    }
+    for (int i = 0; i < W.n_lines; ++i) {
+      out[w].line_drop[i] = -1;
+      if (W.line_start[i] != 0) { out[w].line_start[i] = W.line_start[i] - 1; out[w].line_nobs[i] = W.line_nobs[i]; continue; }
+      out[w].line_drop[i] = 0;
+      out[w].line_start[i] = 0;
+      out[w].line_nobs[i] = W.line_nobs[i] - 1 < 2 ? 0 : W.line_nobs[i] - 1;
+      if (!out[w].line_nobs[i]) continue;
+      lw.push_back(w); lidx.push_back(i);
+      ld.insert(ld.end(), W.line_plk + 6 * i, W.line_plk + 6 * i + 6);
+    }
+  }
+  const int nPts = (int)pw.size(), nLns = (int)lw.size();
+  if (nPts + nLns > 0) {
+    DevBuf dfr, dpw, dpd, dlw, dld;
+    hipStream_t s = c->stream;
+    HIPCHK(c, dfr.alloc(fr.size() * 8)); HIPCHK(c, dpw.alloc(pw.size() * 4)); HIPCHK(c, dpd.alloc(pd.size() * 8));
+    HIPCHK(c, dlw.alloc(lw.size() * 4)); HIPCHK(c, dld.alloc(ld.size() * 8));
+    HIPCHK(c, hipMemcpyAsync(dfr.p, fr.data(), fr.size() * 8, hipMemcpyHostToDevice, s));
+    if (nPts) { HIPCHK(c, hipMemcpyAsync(dpw.p, pw.data(), pw.size() * 4, hipMemcpyHostToDevice, s));
+                HIPCHK(c, hipMemcpyAsync(dpd.p, pd.data(), pd.size() * 8, hipMemcpyHostToDevice, s)); }
+    if (nLns) { HIPCHK(c, hipMemcpyAsync(dlw.p, lw.data(), lw.size() * 4, hipMemcpyHostToDevice, s));
+                HIPCHK(c, hipMemcpyAsync(dld.p, ld.data(), ld.size() * 8, hipMemcpyHostToDevice, s)); }
+    { KTimer t(c, "k_slide_shift");
+      hipLaunchKernelGGL(k_slide_shift, dim3((nPts + nLns + 255) / 256), dim3(256), 0, s, dfr.d(), nPts, (const int*)dpw.p, dpd.d(),
+                         nLns, (const int*)dlw.p, dld.d(), init_depth); }
+    HIPCHK(c, hipGetLastError());
+    if (nPts) HIPCHK(c, hipMemcpyAsync(pd.data(), dpd.p, pd.size() * 8, hipMemcpyDeviceToHost, s));
+    if (nLns) HIPCHK(c, hipMemcpyAsync(ld.data(), dld.p, ld.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int k = 0; k < nPts; ++k) win[pw[k]].inv_depth[pidx[k]] = pd[(size_t)k * 4 + 3];
+    for (int k = 0; k < nLns; ++k) std::memcpy(win[lw[k]].line_plk + 6 * lidx[k], &ld[(size_t)k * 6], 48);
+  }
+  for (int w = 0; w < nW; ++w) {
+    std::memmove(win[w].pose[0], win[w].pose[1], sizeof(win[w].pose[0]) * WS);            // frames 1..10 -> 0..9, 10 stays
+    std::memmove(win[w].speed_bias[0], win[w].speed_bias[1], sizeof(win[w].speed_bias[0]) * WS);
+  }
+  return VPL_OK;
+}
+
 // FeatureManager::triangulate for a batch: upload, k_triangulate_points, inverse depths back
 int vpl_ba_triangulate_points(vpl_ctx* c, int nW, vpl_window* win, double init_depth) {
   if (!c || !win || nW < 1 || !(init_depth > 0.0)) return VPL_E_INVALID;
