@@ -51,6 +51,21 @@ int vpl_fe_set_stream(vpl_fe_ctx* ctx, void* hip_stream);
 int vpl_fe_synchronize(vpl_fe_ctx* ctx);
 const char* vpl_fe_last_error(const vpl_fe_ctx* ctx);
 
+/* ---- image preparation of LineFeatureTracker::readImage (feature_tracker/src/line_feature_tracker.cpp:62-68) ----
+ *   cv::remap(_img, img, undist_map1_, undist_map2_, CV_INTER_LINEAR);  createCLAHE(3.0, Size(8,8))->apply(img, img);
+ * vpl_pre_set_maps: the CV_32FC1 maps of PinholeCamera::initUndistortRectifyMap (line_feature_tracker.cpp:32), [H][W]
+ *   each; NULL, NULL = no remap.  vpl_pre_upload: raw 8-bit frames [n][H][W].  vpl_pre_run (asynchronous): remap
+ *   (INTER_LINEAR, BORDER_CONSTANT 0), then CLAHE when `equalize` (reference: clip 3.0, 8 x 8 tiles); the result
+ *   REPLACES the frame batch that vpl_edlines_detect / vpl_match_run work on, so the raw frames never come back to the
+ *   host.  vpl_pre_download copies the prepared frames out (tests, display). */
+int vpl_pre_set_maps(vpl_fe_ctx* ctx, const float* map_x, const float* map_y);
+int vpl_pre_upload(vpl_fe_ctx* ctx, int n_images, const uint8_t* raw_images);
+int vpl_pre_run(vpl_fe_ctx* ctx, int equalize, double clip_limit, int tiles_x, int tiles_y);
+int vpl_pre_download(vpl_fe_ctx* ctx, int n_images, uint8_t* images);
+/* upload + run + (images != NULL ? download : synchronize) */
+int vpl_pre_batch(vpl_fe_ctx* ctx, int n_images, const uint8_t* raw_images, int equalize, double clip_limit, int tiles_x,
+                  int tiles_y, uint8_t* images);
+
 /* three-phase form (inputs resident in HBM while timing) */
 int vpl_edlines_upload(vpl_fe_ctx* ctx, int n_images, const uint8_t* images /* [n][H][W] */);
 int vpl_edlines_detect(vpl_fe_ctx* ctx, const vpl_edline_param* param);   /* enqueue; asynchronous */

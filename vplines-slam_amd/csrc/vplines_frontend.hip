@@ -11,6 +11,7 @@
 #include "vplines_frontend.h"
 #include "ed_kernels.h"
 #include "lm_kernels.h"
+#include "pre_kernels.h"
 
 using namespace vpl;
 
@@ -26,6 +27,11 @@ struct vpl_fe_ctx {
   bool lmReserved = false;
   int *d_refImg = nullptr, *d_curImg = nullptr, *d_nRef = nullptr, *d_nCur = nullptr;
   vpl_line *d_linesRef = nullptr, *d_linesCur = nullptr;
+  // image preparation (remap + CLAHE)
+  uint8_t *d_raw = nullptr, *d_mid = nullptr, *d_lut = nullptr;
+  float *d_mapx = nullptr, *d_mapy = nullptr;
+  bool haveMaps = false;
+  int lutTiles = 0;
   std::vector<void*> allocs;
   std::string err;
 };
@@ -116,6 +122,88 @@ int vpl_edlines_upload(vpl_fe_ctx* c, int n, const uint8_t* images) {
   c->n = n;
   c->B.N = n;
   return VPL_OK;
+}
+
+// ---- image preparation: cv::remap + CLAHE of LineFeatureTracker::readImage (line_feature_tracker.cpp:62-68) ----
+int vpl_pre_set_maps(vpl_fe_ctx* c, const float* map_x, const float* map_y) {
+  if (!c || (map_x == nullptr) != (map_y == nullptr)) return VPL_E_INVALID;
+  FECHK(c, hipSetDevice(c->device));
+  if (!map_x) { c->haveMaps = false; return VPL_OK; }
+  const size_t PX = (size_t)c->W * c->H;
+  if (!c->d_mapx) { FECHK(c, fe_alloc(c, &c->d_mapx, PX)); FECHK(c, fe_alloc(c, &c->d_mapy, PX)); }
+  FECHK(c, hipMemcpyAsync(c->d_mapx, map_x, PX * 4, hipMemcpyHostToDevice, c->stream));
+  FECHK(c, hipMemcpyAsync(c->d_mapy, map_y, PX * 4, hipMemcpyHostToDevice, c->stream));
+  FECHK(c, hipStreamSynchronize(c->stream));   // the caller's maps may go away
+  c->haveMaps = true;
+  return VPL_OK;
+}
+
+int vpl_pre_upload(vpl_fe_ctx* c, int n, const uint8_t* raw) {
+  if (!c || !raw || n < 1) return VPL_E_INVALID;
+  if (n > c->maxN) return fe_fail(c, VPL_E_CAPACITY, "more images than max_images");
+  FECHK(c, hipSetDevice(c->device));
+  const size_t PX = (size_t)c->W * c->H;
+  if (!c->d_raw) { FECHK(c, fe_alloc(c, &c->d_raw, (size_t)c->maxN * PX)); FECHK(c, fe_alloc(c, &c->d_mid, (size_t)c->maxN * PX)); }
+  FECHK(c, hipMemcpyAsync(c->d_raw, raw, (size_t)n * PX, hipMemcpyHostToDevice, c->stream));
+  c->n = n;
+  c->B.N = n;
+  return VPL_OK;
+}
+
+int vpl_pre_run(vpl_fe_ctx* c, int equalize, double clip_limit, int tiles_x, int tiles_y) {
+  if (!c || c->n < 1 || !c->d_raw) return VPL_E_INVALID;
+  if (equalize && (tiles_x < 1 || tiles_y < 1 || tiles_x > c->W || tiles_y > c->H)) return fe_fail(c, VPL_E_INVALID, "bad CLAHE grid");
+  FECHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t PX = (size_t)c->W * c->H;
+  PreBatch P;
+  std::memset(&P, 0, sizeof(P));
+  P.N = c->n; P.W = c->W; P.H = c->H;
+  P.raw = c->d_raw; P.mapx = c->d_mapx; P.mapy = c->d_mapy; P.mid = c->d_mid; P.out = (uint8_t*)c->B.img;
+  const int W4 = (c->W + 3) / 4;
+  const dim3 gpx((W4 * c->H + 255) / 256, c->n);
+  // stage 1: remap into `mid` (or straight into the frame batch when no CLAHE follows)
+  const uint8_t* clahe_in = c->d_raw;
+  if (c->haveMaps) {
+    uint8_t* dst = equalize ? c->d_mid : P.out;
+    hipLaunchKernelGGL(k_pre_remap, gpx, dim3(256), 0, s, P, dst);
+    clahe_in = dst;
+  } else if (!equalize) {
+    FECHK(c, hipMemcpyAsync(P.out, c->d_raw, (size_t)c->n * PX, hipMemcpyDeviceToDevice, s));
+  }
+  if (equalize) {
+    const int tiles = tiles_x * tiles_y;
+    if (tiles > c->lutTiles) { FECHK(c, fe_alloc(c, &c->d_lut, (size_t)c->maxN * tiles * 256)); c->lutTiles = tiles; }
+    P.lut = c->d_lut;
+    int extW = c->W, extH = c->H;
+    if (c->W % tiles_x != 0 || c->H % tiles_y != 0) { extW += tiles_x - c->W % tiles_x; extH += tiles_y - c->H % tiles_y; }
+    P.tilesX = tiles_x; P.tilesY = tiles_y; P.tw = extW / tiles_x; P.th = extH / tiles_y;
+    const int area = P.tw * P.th;
+    P.lutScale = (float)255 / area;
+    P.clipLimit = clip_limit > 0.0 ? std::max((int)(clip_limit * area / 256), 1) : 0;   // clahe.cpp: clipLimit_ * tileSizeTotal / histSize
+    P.inv_tw = 1.0f / P.tw; P.inv_th = 1.0f / P.th;
+    hipLaunchKernelGGL(k_pre_clahe_lut, dim3(tiles, c->n), dim3(256), 0, s, P, clahe_in);
+    hipLaunchKernelGGL(k_pre_clahe_interp, gpx, dim3(256), 0, s, P, clahe_in);
+  }
+  FECHK(c, hipGetLastError());
+  return VPL_OK;
+}
+
+int vpl_pre_download(vpl_fe_ctx* c, int n, uint8_t* images) {
+  if (!c || !images || n < 1 || n > c->n) return VPL_E_INVALID;
+  FECHK(c, hipSetDevice(c->device));
+  FECHK(c, hipMemcpyAsync(images, c->B.img, (size_t)n * c->W * c->H, hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipStreamSynchronize(c->stream));
+  return VPL_OK;
+}
+
+int vpl_pre_batch(vpl_fe_ctx* c, int n, const uint8_t* raw, int equalize, double clip_limit, int tiles_x, int tiles_y,
+                  uint8_t* images) {
+  int rc = vpl_pre_upload(c, n, raw);
+  if (rc) return rc;
+  rc = vpl_pre_run(c, equalize, clip_limit, tiles_x, tiles_y);
+  if (rc) return rc;
+  return images ? vpl_pre_download(c, n, images) : vpl_fe_synchronize(c);
 }
 
 int vpl_edlines_detect(vpl_fe_ctx* c, const vpl_edline_param* p) {

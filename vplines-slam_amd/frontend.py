@@ -82,6 +82,11 @@ def _bind(lib):
     lib.vpl_fe_last_error.argtypes = [vp]
     lib.vpl_fe_last_error.restype = C.c_char_p
     lib.vpl_edlines_upload.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8)]
+    lib.vpl_pre_set_maps.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.vpl_pre_upload.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8)]
+    lib.vpl_pre_run.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_int]
+    lib.vpl_pre_download.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8)]
+    lib.vpl_pre_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     lib.vpl_edlines_detect.argtypes = [vp, C.POINTER(EdlineParam)]
     lib.vpl_edlines_download.argtypes = [vp, C.c_int, C.POINTER(Line), C.POINTER(C.c_int)]
     lib.vpl_edlines_detect_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8), C.POINTER(EdlineParam), C.POINTER(Line),
@@ -136,6 +141,32 @@ class FrontendContext:
         self.n = images.shape[0]
         self._img = images
         self._check(self.lib.vpl_edlines_upload(self.h, self.n, images.ctypes.data_as(C.POINTER(C.c_uint8))), "upload")
+
+    # ---- image preparation (remap + CLAHE), line_feature_tracker.cpp:62-68 ----
+    def set_maps(self, map_x, map_y):
+        """float32 [H][W] undistortion maps; None, None switches the remap off"""
+        fp = C.POINTER(C.c_float)
+        if map_x is None:
+            self._check(self.lib.vpl_pre_set_maps(self.h, None, None), "vpl_pre_set_maps")
+            return
+        mx, my = np.ascontiguousarray(map_x, np.float32), np.ascontiguousarray(map_y, np.float32)
+        assert mx.shape == (self.H, self.W) and my.shape == (self.H, self.W)
+        self._check(self.lib.vpl_pre_set_maps(self.h, mx.ctypes.data_as(fp), my.ctypes.data_as(fp)), "vpl_pre_set_maps")
+
+    def pre_upload(self, raw):
+        raw = np.ascontiguousarray(raw, np.uint8)
+        assert raw.ndim == 3 and raw.shape[1:] == (self.H, self.W)
+        self.n = raw.shape[0]
+        self._img = raw
+        self._check(self.lib.vpl_pre_upload(self.h, self.n, raw.ctypes.data_as(C.POINTER(C.c_uint8))), "vpl_pre_upload")
+
+    def pre_run(self, equalize=True, clip_limit=3.0, tiles=(8, 8)):
+        self._check(self.lib.vpl_pre_run(self.h, int(equalize), clip_limit, tiles[0], tiles[1]), "vpl_pre_run")
+
+    def pre_download(self):
+        out = np.empty((self.n, self.H, self.W), np.uint8)
+        self._check(self.lib.vpl_pre_download(self.h, self.n, out.ctypes.data_as(C.POINTER(C.c_uint8))), "vpl_pre_download")
+        return out
 
     def detect(self, param=None):
         self._param = param or default_param()
