@@ -138,6 +138,21 @@ int vpl_match_debug_kps(vpl_fe_ctx* ctx, int pair, int cap, float* kps_ref, floa
  * VPL_E_INVALID for a level that was not built */
 int vpl_match_debug_level(vpl_fe_ctx* ctx, int img, int level, uint8_t* pixels, int16_t* deriv, int* w, int* h);
 
+/* ---- list handling of LineFeatureTracker::readImage after the match (line_feature_tracker.cpp:96-229) ----
+ * Host-side integer bookkeeping (no device work, no context): id propagation from the previous frame's lines through
+ * line_ref_to_line_cur, fresh ids for the unmatched lines, and the max_h_lines / max_v_lines quota.  The reference's
+ * behaviour is kept as written: a match to detection 0 is ignored (`mt > 0`, :121); t_cnt is read with the NEW frame's
+ * index (:123) from a vector that keeps the previous frame's detection count (n_tcnt_prev; a read past its end, which
+ * the reference leaves undefined, counts as 0); new lines are classed with the 3.14-based angle test of :166.
+ *   ends_new   [n_new][4]  end points of the new frame's detections
+ *   id_prev    [n_prev]    lineID of the previous frame's (kept) lines;  prev_to_new [n_prev] their match, -1 = none
+ *   keep, id_out (capacity n_new): the new frame's kept lines as indices into the detections and their ids;
+ *   tcnt_out   [n_new]     t_cnt in detection order.  *allfeature_cnt is advanced by the number of fresh ids.
+ * Returns the number of kept lines, or a negative VPL_E_* code. */
+int vpl_line_track_ids(int n_new, const float* ends_new, int n_prev, const int* id_prev, const int* tcnt_prev, int n_tcnt_prev,
+                       const int* prev_to_new, int max_h_lines, int max_v_lines, int* allfeature_cnt, int* keep, int* id_out,
+                       int* tcnt_out);
+
 #ifdef __cplusplus
 }
 #endif

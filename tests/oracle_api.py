@@ -308,3 +308,21 @@ def slide_window(w, opt, marginalization_flag, init_depth=5.0):
     assert rc == 0
     w.from_c(cw)
     return st
+
+
+def track_ids(ends_new, id_prev, tcnt_prev, prev_to_new, max_h, max_v, allfeature_cnt, lib=None, fn="orc_track_ids"):
+    """list handling of LineFeatureTracker::readImage (oracle/preproc.cpp); returns keep, ids, tcnt, allfeature_cnt.
+    lib/fn select the same entry point of another library (the product's vpl_line_track_ids has this signature)."""
+    lib = lib or load()
+    ends = np.ascontiguousarray(ends_new, np.float32).reshape(-1, 4)
+    n_new = len(ends)
+    idp, tcp, p2n = (np.ascontiguousarray(a, np.int32) for a in (id_prev, tcnt_prev, prev_to_new))
+    keep, ids, tc = (np.zeros(max(n_new, 1), np.int32) for _ in range(3))
+    cnt = C.c_int(allfeature_cnt)
+    ip = C.POINTER(C.c_int)
+    f = getattr(lib, fn)
+    f.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int, ip, ip, C.c_int, ip, C.c_int, C.c_int, ip, ip, ip, ip]
+    n = f(n_new, ends.ctypes.data_as(C.POINTER(C.c_float)), len(p2n), idp.ctypes.data_as(ip), tcp.ctypes.data_as(ip), len(tcp),
+          p2n.ctypes.data_as(ip), max_h, max_v, C.byref(cnt), keep.ctypes.data_as(ip), ids.ctypes.data_as(ip), tc.ctypes.data_as(ip))
+    assert n >= 0
+    return keep[:n].copy(), ids[:n].copy(), tc[:n_new].copy(), cnt.value

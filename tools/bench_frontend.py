@@ -1,7 +1,8 @@
 """Secondary metric of SURVEY 8(d), config 4: frames/s of the whole line front-end -- EDLines on 64 frames 752x480 plus KLT
 line matching of the 63 consecutive pairs -- with the frames resident in HBM.  The detected lines pass through the host
 between the two stages, as they do in the reference (the tracker owns them); that round trip is inside the timed region.
-Prints one JSON line."""
+With --prep the raw frames first go through the undistortion remap + CLAHE(3.0, 8x8) of LineFeatureTracker::readImage
+(EuRoC cam0 maps) on the device, inside the timed region.  Prints one JSON line."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.dirname(__file__))
@@ -17,11 +18,20 @@ def main():
     imgs = frames(n)
     fe = v.frontend.FrontendContext(device=0, max_images=n, width=752, height=480, max_lines=256,
                                     stream=torch.cuda.current_stream(dev).cuda_stream)
-    fe.match_reserve(n - 1, 4096)
-    fe.upload(imgs)
+    prep = "--prep" in sys.argv
+    fe.match_reserve(n - 1, 8192 if prep else 4096)
+    if prep:
+        from test_preproc import euroc_maps, oracle_clahe, oracle_remap
+        mx, my = euroc_maps()
+        fe.set_maps(mx, my)
+        fe.pre_upload(imgs)
+    else:
+        fe.upload(imgs)
     pairs = [(i, i + 1) for i in range(n - 1)]
 
     def step():
+        if prep:
+            fe.pre_run(True, 3.0, (8, 8))
         fe.detect()
         fe.synchronize()
         lines = fe.download()
@@ -40,9 +50,14 @@ def main():
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
     # device-only share: the kernels of one batch, timed with events
-    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    ep, e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+    ep.record()
+    if prep:
+        fe.pre_run(True, 3.0, (8, 8))
     e0.record(); fe.detect(); e1.record(); fe.match_run(); e2.record()
     torch.cuda.synchronize(dev)
+    if prep:
+        imgs = np.stack([oracle_clahe(oracle_remap(imgs[i], mx, my)) for i in range(5)])
     import oracle_api as o
     tc = time.perf_counter()
     same = 0
@@ -52,8 +67,8 @@ def main():
         same += int(len(la) == len(lines[i]) and np.array_equal(ro, r2c[i]))
     tc = (time.perf_counter() - tc) / 4
     print(json.dumps({"metric": "line front-end frames/s (EDLines + KLT matching, 752x480, batch 64)", "value": n / dt,
-                      "unit": "frames/s", "ms_per_batch": 1e3 * dt, "device_ms_detect": e0.elapsed_time(e1),
-                      "device_ms_match": e1.elapsed_time(e2), "host_round_trip_ms": 1e3 * dt - e0.elapsed_time(e2),
+                      "unit": "frames/s", "prep": prep, "ms_per_batch": 1e3 * dt, "device_ms_prep": ep.elapsed_time(e0), "device_ms_detect": e0.elapsed_time(e1),
+                      "device_ms_match": e1.elapsed_time(e2), "host_round_trip_ms": 1e3 * dt - ep.elapsed_time(e2),
                       "mean_lines_per_frame": float(np.mean([len(l) for l in lines])),
                       "mean_matches_per_pair": float(np.mean([(r >= 0).sum() for r in r2c])),
                       "cpu_oracle_frames_per_s_1thread": 1.0 / tc, "identical_on_4_pairs": same}))

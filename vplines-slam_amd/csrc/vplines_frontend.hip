@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -471,6 +472,46 @@ int vpl_match_debug_level(vpl_fe_ctx* c, int img, int level, uint8_t* pixels, in
   if (pixels) FECHK(c, hipMemcpy2D(pixels, lw, M.pyr + base, S, lw, lh, hipMemcpyDeviceToHost));
   if (deriv) FECHK(c, hipMemcpy2D(deriv, (size_t)lw * 4, M.der + base * 2, (size_t)S * 4, (size_t)lw * 4, lh, hipMemcpyDeviceToHost));
   return VPL_OK;
+}
+
+// LineFeatureTracker::readImage, the lists after the match (line_feature_tracker.cpp:109-229).  Plain host code, as in the
+// reference: a few hundred integers per frame.
+int vpl_line_track_ids(int n_new, const float* ends, int n_prev, const int* id_prev, const int* tcnt_prev, int n_tcnt_prev,
+                       const int* prev_to_new, int max_h, int max_v, int* allfeature_cnt, int* keep, int* id_out,
+                       int* tcnt_out) {
+  if (n_new < 0 || n_prev < 0 || !allfeature_cnt || (n_new && (!ends || !keep || !id_out || !tcnt_out)) ||
+      (n_prev && (!id_prev || !prev_to_new)) || (n_tcnt_prev && !tcnt_prev))
+    return VPL_E_INVALID;
+  std::vector<int> id(n_new, -1);
+  for (int i = 0; i < n_new; ++i) tcnt_out[i] = 0;
+  for (int k = 0; k < n_prev; ++k) {
+    const int mt = prev_to_new[k];
+    if (mt <= 0 || mt >= n_new) continue;                     // `if (mt > 0)`: detection 0 never inherits an id
+    id[mt] = id_prev[k];
+    tcnt_out[mt] = (mt < n_tcnt_prev ? tcnt_prev[mt] : 0) + 1;
+  }
+  // segAngle (:20-25) and the "h" class of :166 / :185
+  auto horizontal_class = [&](int i) {
+    const float* e = ends + 4 * i;
+    const double a = e[2] > e[0] ? std::atan2(e[3] - e[1], e[2] - e[0]) : std::atan2(e[1] - e[3], e[0] - e[2]);
+    return (a >= 3.14 / 4.0 && a <= 3 * 3.14 / 4.0) || (a <= -3.14 / 4.0 && a >= -3 * 3.14 / 4.0);
+  };
+  int n_keep = 0, h_tracked = 0, v_tracked = 0;
+  std::vector<int> fresh_h, fresh_v;
+  for (int i = 0; i < n_new; ++i) {
+    if (id[i] == -1) {
+      id[i] = (*allfeature_cnt)++;
+      (horizontal_class(i) ? fresh_h : fresh_v).push_back(i);
+    } else {
+      keep[n_keep] = i; id_out[n_keep] = id[i]; ++n_keep;
+      (horizontal_class(i) ? h_tracked : v_tracked)++;
+    }
+  }
+  const int take_h = std::min<int>(std::max(max_h - h_tracked, 0), (int)fresh_h.size());
+  const int take_v = std::min<int>(std::max(max_v - v_tracked, 0), (int)fresh_v.size());
+  for (int k = 0; k < take_h; ++k, ++n_keep) { keep[n_keep] = fresh_h[k]; id_out[n_keep] = id[fresh_h[k]]; }
+  for (int k = 0; k < take_v; ++k, ++n_keep) { keep[n_keep] = fresh_v[k]; id_out[n_keep] = id[fresh_v[k]]; }
+  return n_keep;
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 //   line_matching/src/line.h:8-17                    struct Line
 //   line_matching/src/edline_detector.h:32-40,55-84  EDLineParam, EDLineDetector::EDline
 //   line_matching/src/line_matching.h:14-33          LineMatching::LineMatching, LineMatching::Matching
+//   feature_tracker/include/linefeature_tracker.h    FrameLines, LineFeatureTracker::readImage / undistortedLineEndPoints
 // so the tracker code (feature_tracker/src/line_feature_tracker.cpp:87,291-314) keeps its shape.
 // Frames are raw 8-bit single-channel buffers; with -DVPL_USE_OPENCV overloads taking cv::Mat are added
 // (cv::Mat::data of a continuous CV_8UC1 matrix is that buffer).  Nothing computes on the CPU: without a HIP device
@@ -12,6 +13,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -110,6 +112,8 @@ class EDLineDetector {
   }
 #endif
 
+  const vpl_edline_param& param() const { return p_; }
+
  private:
   FrontendDevice& dev_;
   vpl_edline_param p_;
@@ -164,6 +168,134 @@ class LineMatching {
  private:
   FrontendDevice& dev_;
   vpl_match_param p_;
+};
+
+// FrameLines / LineFeatureTracker (feature_tracker/include/linefeature_tracker.h:45-96, src/line_feature_tracker.cpp).
+// readImage = remap + CLAHE (device) -> EDline (device) -> Matching against the previous frame (device) -> id / quota
+// lists (vpl_line_track_ids).  Vanishing points are not detected here: vps holds the zero vector
+// with flag 0 for every line, which the estimator treats as "no VP observation" (estimator.cpp:1181).
+struct FrameLines {
+  std::vector<uint8_t> img;                       // prepared frame (undistorted, equalised)
+  std::vector<Line> vecLine;
+  std::vector<int> lineID;
+  std::vector<int> t_cnt;
+  std::vector<std::array<double, 4>> vps;
+};
+
+class LineFeatureTracker {
+ public:
+  LineFeatureTracker(FrontendDevice& dev, EDLineParam edparam, int max_h_lines, int max_v_lines, bool equalize = true)
+      : dev_(dev), line_detctor(dev, edparam), line_matching(dev), max_h_lines_(max_h_lines), max_v_lines_(max_v_lines),
+        equalize_(equalize) {}
+
+  // readIntrinsicParameter (:26-35): the maps of PinholeCamera::initUndistortRectifyMap and its K_rect
+  void setUndistortMaps(const float* map_x, const float* map_y, float fx, float fy, float cx, float cy) {
+    if (vpl_pre_set_maps(dev_.ctx(), map_x, map_y) != 0)
+      throw std::runtime_error(std::string("vpl_pre_set_maps: ") + vpl_fe_last_error(dev_.ctx()));
+    fx_ = fx; fy_ = fy; cx_ = cx; cy_ = cy;
+  }
+
+  // undistortedLineEndPoints (:37-53): pixel end points of curframe_ to the normalised plane of K_
+  std::vector<Line> undistortedLineEndPoints() const {
+    std::vector<Line> un = curframe_->vecLine;
+    for (Line& l : un) {
+      l.line_endpoint[0] = (l.line_endpoint[0] - cx_) / fx_;
+      l.line_endpoint[1] = (l.line_endpoint[1] - cy_) / fy_;
+      l.line_endpoint[2] = (l.line_endpoint[2] - cx_) / fx_;
+      l.line_endpoint[3] = (l.line_endpoint[3] - cy_) / fy_;
+    }
+    return un;
+  }
+
+  // readImage (:57-286), raw = the 8-bit frame as it arrives from the camera
+  void readImage(const uint8_t* raw) {
+    const size_t px = (size_t)dev_.width() * dev_.height();
+    lines_exit = true;
+    last_match.clear();
+    std::vector<uint8_t> img(px);
+    if (vpl_pre_batch(dev_.ctx(), 1, raw, equalize_ ? 1 : 0, 3.0, 8, 8, img.data()) != 0)
+      throw std::runtime_error(std::string("vpl_pre_batch: ") + vpl_fe_last_error(dev_.ctx()));
+    bool first_img = false;
+    if (!forwframe_) {
+      forwframe_.reset(new FrameLines);
+      curframe_.reset(new FrameLines);
+      forwframe_->img = img;
+      curframe_->img = img;
+      first_img = true;
+    } else {
+      forwframe_.reset(new FrameLines);
+      forwframe_->img = img;
+    }
+    // the prepared frame is still resident: detect without a second upload
+    std::vector<vpl_line> det(dev_.max_lines());
+    int n_det = 0;
+    vpl_edline_param ep = line_detctor.param();
+    if (vpl_edlines_detect(dev_.ctx(), &ep) != 0 || vpl_fe_synchronize(dev_.ctx()) != 0 ||
+        vpl_edlines_download(dev_.ctx(), 1, det.data(), &n_det) != 0)
+      throw std::runtime_error(std::string("vpl_edlines_detect: ") + vpl_fe_last_error(dev_.ctx()));
+    for (int i = 0; i < n_det; ++i) forwframe_->vecLine.push_back(to_line(det[i]));
+    last_detected = forwframe_->vecLine;
+    if (forwframe_->vecLine.empty()) { lines_exit = false; return; }
+    for (size_t i = 0; i < forwframe_->vecLine.size(); ++i) {
+      forwframe_->lineID.push_back(first_img ? allfeature_cnt++ : -1);
+      forwframe_->t_cnt.push_back(0);
+    }
+    if (!curframe_->vecLine.empty()) {
+      std::vector<int> line_prev_to_line_cur;
+      line_matching.Matching(curframe_->img.data(), forwframe_->img.data(), curframe_->vecLine, forwframe_->vecLine,
+                             line_prev_to_line_cur, true, true);
+      last_match = line_prev_to_line_cur;
+      const int n_new = (int)forwframe_->vecLine.size();
+      const int n_prev = (int)line_prev_to_line_cur.size();     // 0 when Matching() returned false
+      std::vector<float> ends(4 * (size_t)n_new);
+      for (int i = 0; i < n_new; ++i)
+        for (int k = 0; k < 4; ++k) ends[4 * i + k] = forwframe_->vecLine[i].line_endpoint[k];
+      std::vector<int> keep(n_new), ids(n_new), tc(n_new);
+      const int n_keep = vpl_line_track_ids(n_new, ends.data(), n_prev, curframe_->lineID.data(), curframe_->t_cnt.data(),
+                                            (int)curframe_->t_cnt.size(), line_prev_to_line_cur.data(), max_h_lines_,
+                                            max_v_lines_, &allfeature_cnt, keep.data(), ids.data(), tc.data());
+      if (n_keep < 0) throw std::runtime_error("vpl_line_track_ids failed");
+      std::vector<Line> kept;
+      for (int k = 0; k < n_keep; ++k) kept.push_back(forwframe_->vecLine[keep[k]]);
+      forwframe_->vecLine.swap(kept);
+      forwframe_->lineID.assign(ids.begin(), ids.begin() + n_keep);
+      forwframe_->t_cnt = tc;                                   // stays in detection order (:227-228 swap only two vectors)
+      forwframe_->vps.assign(forwframe_->vecLine.size(), std::array<double, 4>{0.0, 0.0, 0.0, 0.0});
+    }
+    curframe_.swap(forwframe_);
+  }
+
+  // The wire format of line_feature_tracker_node.cpp:77-153 for one camera: what Estimator::processImage receives
+  // per line id (estimator_node.cpp:375-407): x1, y1, x2, y2 normalised, vp x y z, vp flag.  As at :104-109 every
+  // line carries vps[camera index], not its own entry.
+  struct LineObservation { int id; double v[8]; };
+  std::vector<LineObservation> lineObservations() const {
+    std::vector<LineObservation> out;
+    if (!lines_exit || !curframe_) return out;
+    const std::vector<Line> un = undistortedLineEndPoints();
+    for (size_t j = 0; j < curframe_->lineID.size(); ++j) {
+      LineObservation ob;
+      ob.id = curframe_->lineID[j];
+      for (int k = 0; k < 4; ++k) ob.v[k] = un[j].line_endpoint[k];
+      for (int k = 0; k < 4; ++k) ob.v[4 + k] = curframe_->vps.empty() ? 0.0 : curframe_->vps[0][k];
+      out.push_back(ob);
+    }
+    return out;
+  }
+
+  std::shared_ptr<FrameLines> curframe_, forwframe_;
+  int allfeature_cnt = 0;
+  bool lines_exit = true;
+  std::vector<int> last_match;                    // line_prev_to_line_cur of the last readImage (test access)
+  std::vector<Line> last_detected;                // the last frame's detections before the quota (test access)
+
+ private:
+  FrontendDevice& dev_;
+  EDLineDetector line_detctor;
+  LineMatching line_matching;
+  int max_h_lines_, max_v_lines_;
+  bool equalize_;
+  float fx_ = 1.f, fy_ = 1.f, cx_ = 0.f, cy_ = 0.f;
 };
 
 }  // namespace vplhost
