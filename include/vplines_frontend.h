@@ -138,6 +138,26 @@ int vpl_match_debug_kps(vpl_fe_ctx* ctx, int pair, int cap, float* kps_ref, floa
  * VPL_E_INVALID for a level that was not built */
 int vpl_match_debug_level(vpl_fe_ctx* ctx, int img, int level, uint8_t* pixels, int16_t* deriv, int* w, int* h);
 
+/* ---- vanishing points: vanishing_point_detection::run_vanishing_point_detection
+ * (feature_tracker/src/vanishing_point_detection.cpp:37-66, called at line_feature_tracker.cpp:237-266) for a batch of frames.
+ *   hyp_lines [n][max_lines]  the lines the 2-line hypotheses and the sphere grid are built from (`lines`: verticalLine or
+ *                             all lines, :240-243);  all_lines [n][max_lines]  the lines that are classified
+ *   f, cx, cy                 init(K(0,0), K(0,2), K(1,2), 0.5) (line_feature_tracker.cpp:33)
+ *   seeds [n]                 the reference calls srand(time(NULL)) in every frame (:107); here the caller supplies the
+ *                             seed and the device generates glibc's rand() stream for it
+ *   first_frame [n]           frame_count == 0 (no vps[1]/vps[2] swap, :318-339)
+ *   vps [n][3][3]             the three unit vectors;  vp_ids [n][max_lines]  per line 0..2 = its VP, 3 = none
+ *   status [n]                0, or -1 when no hypothesis can be drawn (fewer than two lines, or only parallel ones -- the
+ *                             reference does not return in that case); vps are 0 and every id is 3 then
+ * Defined where the reference is not: a query index past the end of lx (:411-416, :428-431) means "no query line".
+ * Synchronous. */
+int vpl_vp_detect_batch(vpl_fe_ctx* ctx, int n_frames, const vpl_line* hyp_lines, const int* n_hyp, const vpl_line* all_lines,
+                        const int* n_all, float f, float cx, float cy, const uint32_t* seeds, const int* first_frame,
+                        double* vps, int* vp_ids, int* status);
+/* test access after vpl_vp_detect_batch (any pointer may be NULL): smoothed sphere grid [90][360], the drawn line pairs
+ * [105][2], index of the winning hypothesis, rand() calls made by the hypothesis stage */
+int vpl_vp_debug(vpl_fe_ctx* ctx, int frame, double* grid, int* pairs, int* best_idx, int* drawn);
+
 /* ---- list handling of LineFeatureTracker::readImage after the match (line_feature_tracker.cpp:96-229) ----
  * Host-side integer bookkeeping (no device work, no context): id propagation from the previous frame's lines through
  * line_ref_to_line_cur, fresh ids for the unmatched lines, and the max_h_lines / max_v_lines quota.  The reference's
@@ -148,10 +168,12 @@ int vpl_match_debug_level(vpl_fe_ctx* ctx, int img, int level, uint8_t* pixels, 
  *   id_prev    [n_prev]    lineID of the previous frame's (kept) lines;  prev_to_new [n_prev] their match, -1 = none
  *   keep, id_out (capacity n_new): the new frame's kept lines as indices into the detections and their ids;
  *   tcnt_out   [n_new]     t_cnt in detection order.  *allfeature_cnt is advanced by the number of fresh ids.
+ *   vertical_new (capacity n_new), n_vertical_new: may be NULL; the reference's `verticalLine` (:151-176), i.e. every
+ *              new line of the v class whether the quota keeps it or not (the test on tracked lines at :151 is never true)
  * Returns the number of kept lines, or a negative VPL_E_* code. */
 int vpl_line_track_ids(int n_new, const float* ends_new, int n_prev, const int* id_prev, const int* tcnt_prev, int n_tcnt_prev,
                        const int* prev_to_new, int max_h_lines, int max_v_lines, int* allfeature_cnt, int* keep, int* id_out,
-                       int* tcnt_out);
+                       int* tcnt_out, int* vertical_new, int* n_vertical_new);
 
 #ifdef __cplusplus
 }

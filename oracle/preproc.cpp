@@ -138,7 +138,8 @@ int orc_clahe(const uint8_t* src, int W, int H, double clip_limit, int tilesX, i
 // reference's vector does, so tcnt_out[k] belongs to detection k, not to keep[k]).  Returns the new line count.
 int orc_track_ids(int n_forw, const float* ends_forw, int n_cur, const int* id_cur, const int* tcnt_cur, int n_tcnt_cur,
                   const int* cur_to_forw,
-                  int max_h_lines, int max_v_lines, int* allfeature_cnt, int* keep, int* id_out, int* tcnt_out) {
+                  int max_h_lines, int max_v_lines, int* allfeature_cnt, int* keep, int* id_out, int* tcnt_out, int* vertical_new,
+                  int* n_vertical_new) {
   std::vector<int> lineID(n_forw, -1), t_cnt(n_forw, 0);
   for (int k = 0; k < n_cur; ++k) {
     const int mt = cur_to_forw[k];
@@ -171,6 +172,10 @@ int orc_track_ids(int n_forw, const float* ends_forw, int n_cur, const int* id_c
   }
   for (size_t k = 0; k < tracked.size(); ++k) { keep[k] = tracked[k]; id_out[k] = tracked_id[k]; }
   for (int k = 0; k < n_forw; ++k) tcnt_out[k] = t_cnt[k];
+  if (vertical_new && n_vertical_new) {   // verticalLine (:151-176): the tracked-line test there can never hold, so new v lines only
+    for (size_t k = 0; k < v_new.size(); ++k) vertical_new[k] = v_new[k];
+    *n_vertical_new = (int)v_new.size();
+  }
   return (int)tracked.size();
 }
 

@@ -28,6 +28,8 @@ int main(int argc, char** argv) {
   FrontendDevice dev(W, H, 1024, 16384);
   EDLineParam param = {5, 1.0f, 30.f, 5.f, 2, 35, 1.8};
   LineFeatureTracker tracker(dev, param, std::atoi(argv[7]), std::atoi(argv[8]), true);
+  uint32_t next_seed = 1000;
+  tracker.vp_seed = [&next_seed] { return next_seed++; };
   tracker.setUndistortMaps(mx.data(), my.data(), 458.654f, 457.296f, (float)(W / 2), (float)(H / 2));
   for (int f = 0; f < n; ++f) {
     tracker.readImage(frames.data() + f * px);
@@ -52,6 +54,12 @@ int main(int argc, char** argv) {
       std::printf(" %d", ob.id);
       for (int k = 0; k < 8; ++k) std::printf(" %.9g", ob.v[k]);
     }
+    std::printf("\nframe%d_vpids", f);
+    for (int v : tracker.last_vp_ids) std::printf(" %d", v);
+    std::printf("\nframe%d_vps %u", f, tracker.last_vp_seed);
+    for (int k = 0; k < 9; ++k) std::printf(" %.17g", tracker.last_vps[k]);
+    std::printf("\nframe%d_vp4", f);
+    for (const auto& a : F.vps) std::printf(" %.17g %.17g %.17g %.17g", a[0], a[1], a[2], a[3]);
     std::printf("\nframe%d_cnt %d %d\n", f, tracker.allfeature_cnt, tracker.lines_exit ? 1 : 0);
   }
   return 0;

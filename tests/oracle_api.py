@@ -310,7 +310,8 @@ def slide_window(w, opt, marginalization_flag, init_depth=5.0):
     return st
 
 
-def track_ids(ends_new, id_prev, tcnt_prev, prev_to_new, max_h, max_v, allfeature_cnt, lib=None, fn="orc_track_ids"):
+def track_ids(ends_new, id_prev, tcnt_prev, prev_to_new, max_h, max_v, allfeature_cnt, lib=None, fn="orc_track_ids",
+              with_vertical=False):
     """list handling of LineFeatureTracker::readImage (oracle/preproc.cpp); returns keep, ids, tcnt, allfeature_cnt.
     lib/fn select the same entry point of another library (the product's vpl_line_track_ids has this signature)."""
     lib = lib or load()
@@ -321,8 +322,37 @@ def track_ids(ends_new, id_prev, tcnt_prev, prev_to_new, max_h, max_v, allfeatur
     cnt = C.c_int(allfeature_cnt)
     ip = C.POINTER(C.c_int)
     f = getattr(lib, fn)
-    f.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int, ip, ip, C.c_int, ip, C.c_int, C.c_int, ip, ip, ip, ip]
+    f.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int, ip, ip, C.c_int, ip, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip]
+    vert = np.zeros(max(n_new, 1), np.int32)
+    nvert = C.c_int(0)
     n = f(n_new, ends.ctypes.data_as(C.POINTER(C.c_float)), len(p2n), idp.ctypes.data_as(ip), tcp.ctypes.data_as(ip), len(tcp),
-          p2n.ctypes.data_as(ip), max_h, max_v, C.byref(cnt), keep.ctypes.data_as(ip), ids.ctypes.data_as(ip), tc.ctypes.data_as(ip))
+          p2n.ctypes.data_as(ip), max_h, max_v, C.byref(cnt), keep.ctypes.data_as(ip), ids.ctypes.data_as(ip), tc.ctypes.data_as(ip),
+          vert.ctypes.data_as(ip), C.byref(nvert))
     assert n >= 0
+    if with_vertical:
+        return keep[:n].copy(), ids[:n].copy(), tc[:n_new].copy(), cnt.value, vert[:nvert.value].copy()
     return keep[:n].copy(), ids[:n].copy(), tc[:n_new].copy(), cnt.value
+
+
+def vp_detect(hyp_ends, all_ends, f, cx, cy, seed, first_frame, full=False):
+    """run_vanishing_point_detection (oracle/vpdetect.cpp).  Returns vps [3][3], ids, it (or -1); with full=True also a dict
+    with hyp, grid, scores, best_idx, pairs, drawn."""
+    lib = load()
+    he = np.ascontiguousarray(np.asarray(hyp_ends, np.float32).reshape(-1, 4))
+    ae = np.ascontiguousarray(np.asarray(all_ends, np.float32).reshape(-1, 4))
+    vps = np.zeros((3, 3))
+    ids = np.zeros(max(len(ae), 1), np.int32)
+    hyp, grid, scores = np.zeros((105 * 360, 3, 3)), np.zeros((90, 360)), np.zeros(105 * 360)
+    best = C.c_int(-1)
+    pairs = np.zeros((105, 2), np.int32)
+    drawn = np.zeros(2, np.int32)
+    fp = C.POINTER(C.c_float)
+    lib.orc_vp_detect.argtypes = [fp, C.c_int, fp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_int] + \
+                                 [C.c_void_p] * 5 + [C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    it = lib.orc_vp_detect(he.ctypes.data_as(fp), len(he), ae.ctypes.data_as(fp), len(ae), f, cx, cy, seed, int(first_frame),
+                           vps.ctypes.data, ids.ctypes.data, hyp.ctypes.data, grid.ctypes.data, scores.ctypes.data,
+                           C.byref(best), pairs.ctypes.data, drawn.ctypes.data)
+    ids = ids[:len(ae)]
+    if full:
+        return vps, ids, it, dict(hyp=hyp, grid=grid, scores=scores, best_idx=best.value, pairs=pairs, drawn=drawn)
+    return vps, ids, it

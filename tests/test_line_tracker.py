@@ -38,7 +38,7 @@ def py_track_ids(ends, id_prev, tcnt_prev, p2n, max_h, max_v, cnt):
     h = sum(is_h(ends[i]) for i in tracked)
     vv = len(tracked) - h
     keep = tracked + new_h[:max(max_h - h, 0)] + new_v[:max(max_v - vv, 0)]
-    return np.array(keep, np.int32), np.array([ids[i] for i in keep], np.int32), np.array(tc, np.int32), cnt
+    return np.array(keep, np.int32), np.array([ids[i] for i in keep], np.int32), np.array(tc, np.int32), cnt, np.array(new_v, np.int32)
 
 
 def test_track_ids_oracle_product_and_python_agree():
@@ -54,8 +54,8 @@ def test_track_ids_oracle_product_and_python_agree():
         tcnt_prev = rng.integers(0, 9, int(rng.integers(0, 70))).astype(np.int32)
         p2n = rng.integers(-1, max(n_new, 1) + 3, n_prev).astype(np.int32)      # includes 0 (ignored) and out-of-range
         max_h, max_v = int(rng.integers(0, 40)), int(rng.integers(0, 40))
-        a = o.track_ids(ends, id_prev, tcnt_prev, p2n, max_h, max_v, 500 + trial)
-        b = o.track_ids(ends, id_prev, tcnt_prev, p2n, max_h, max_v, 500 + trial, lib=hip, fn="vpl_line_track_ids")
+        a = o.track_ids(ends, id_prev, tcnt_prev, p2n, max_h, max_v, 500 + trial, with_vertical=True)
+        b = o.track_ids(ends, id_prev, tcnt_prev, p2n, max_h, max_v, 500 + trial, lib=hip, fn="vpl_line_track_ids", with_vertical=True)
         c = py_track_ids(ends, id_prev, tcnt_prev, p2n, max_h, max_v, 500 + trial)
         for x, y, z in zip(a, b, c):
             assert np.array_equal(x, y) and np.array_equal(x, z)
@@ -99,7 +99,7 @@ def test_line_feature_tracker_mirror_replays_with_oracle(tmp_path):
     prev = None
     cnt = 0
     fx, fy, cx, cy = np.float32(458.654), np.float32(457.296), np.float32(W // 2), np.float32(H // 2)
-    n_tracked_total = 0
+    n_tracked_total = n_vp = n_classified = 0
     for f in range(len(frames)):
         img = oracle_clahe(oracle_remap(frames[f], mx, my))
         assert int(vals["frame%d_img" % f][0]) == poly_hash(img)                       # prepared frame, bit for bit
@@ -120,15 +120,33 @@ def test_line_feature_tracker_mirror_replays_with_oracle(tmp_path):
             # the matcher is replayed on the device's own line records (as test_gpu_host_adapter does)
             ok, r2c, _ = o.line_match(prev["img"], img, prev["full"], det_full)
             assert ok and np.array_equal(match, r2c)
-            keep, want_ids, want_tc, cnt = o.track_ids(det, prev["ids"], prev["tcnt"], r2c, MAXH, MAXV, cnt)
+            keep, want_ids, want_tc, cnt, vert = o.track_ids(det, prev["ids"], prev["tcnt"], r2c, MAXH, MAXV, cnt, with_vertical=True)
             assert np.array_equal(ids, want_ids) and np.array_equal(tcnt, want_tc)
             assert np.array_equal(lines, det[keep])
+            # vanishing points: hypotheses from the new v-class lines when there are more than two, else from the kept lines
+            hyp = det[vert] if len(vert) > 2 else lines
+            seed = int(vals["frame%d_vps" % f][0])
+            assert seed == 1000 + n_vp
+            wv, wi, it = o.vp_detect(hyp, lines, fx, cx, cy, seed, n_vp == 0)
+            n_vp += 1
+            assert it == 105
+            assert np.array_equal(np.array(vals["frame%d_vps" % f][1:], np.float64).reshape(3, 3), wv)
+            assert np.array_equal(np.array(vals["frame%d_vpids" % f], np.int64), wi)
+            vp4 = np.array(vals["frame%d_vp4" % f], np.float64).reshape(-1, 4)
+            want4 = np.array([[0, 0, 0, 0] if k == 3 else list(wv[k]) + [1.0] for k in wi])
+            assert np.array_equal(vp4, want4)
+            n_classified += int((wi < 3).sum())
             n_tracked_total += int(np.isin(ids, prev["ids"]).sum())
         assert [int(x) for x in vals["frame%d_cnt" % f]] == [cnt, 1]
         obs = np.array(vals["frame%d_obs" % f], np.float64).reshape(-1, 9)
-        assert np.array_equal(obs[:, 0].astype(int), ids) and not obs[:, 5:].any()      # no VP observations (rank 4)
+        assert np.array_equal(obs[:, 0].astype(int), ids)
+        if prev is None:
+            assert not obs[:, 5:].any()                                                 # first frame: no VP stage ran
+        else:
+            assert np.allclose(obs[:, 5:], vp4[0], rtol=1e-8)                           # every line carries vps[0] (node.cpp:104)
         l32 = lines.astype(np.float32)
         want = np.stack([(l32[:, 0] - cx) / fx, (l32[:, 1] - cy) / fy, (l32[:, 2] - cx) / fx, (l32[:, 3] - cy) / fy], 1)
         assert np.abs(obs[:, 1:5] - want).max() < 1e-6
         prev = dict(img=img, full=det_full[keep], ids=ids, tcnt=tcnt)
     assert n_tracked_total > 30                                                         # ids really propagate
+    assert n_vp == len(frames) - 1 and n_classified > 10

@@ -13,6 +13,7 @@
 #include "ed_kernels.h"
 #include "lm_kernels.h"
 #include "pre_kernels.h"
+#include "vp_kernels.h"
 
 using namespace vpl;
 
@@ -33,6 +34,13 @@ struct vpl_fe_ctx {
   float *d_mapx = nullptr, *d_mapy = nullptr;
   bool haveMaps = false;
   int lutTiles = 0;
+  // vanishing points
+  VpBatch V;
+  bool vpReserved = false;
+  float *d_vpHyp = nullptr, *d_vpAll = nullptr;
+  int *d_vpNHyp = nullptr, *d_vpNAll = nullptr, *d_vpFirst = nullptr;
+  uint32_t* d_vpSeed = nullptr;
+  int vpN = 0;
   std::vector<void*> allocs;
   std::string err;
 };
@@ -474,11 +482,87 @@ int vpl_match_debug_level(vpl_fe_ctx* c, int img, int level, uint8_t* pixels, in
   return VPL_OK;
 }
 
+// ---- vanishing points (vanishing_point_detection.cpp) ----
+static int vp_reserve(vpl_fe_ctx* c) {
+  if (c->vpReserved) return VPL_OK;
+  if (c->maxLines > 1024) return fe_fail(c, VPL_E_CAPACITY, "vanishing points: max_lines_per_image above 1024");
+  const size_t N = c->maxN, ML = c->maxLines;
+  VpBatch& V = c->V;
+  std::memset(&V, 0, sizeof(V));
+  FECHK(c, fe_alloc(c, &c->d_vpHyp, N * ML * 4)); FECHK(c, fe_alloc(c, &c->d_vpAll, N * ML * 4));
+  FECHK(c, fe_alloc(c, &c->d_vpNHyp, N)); FECHK(c, fe_alloc(c, &c->d_vpNAll, N)); FECHK(c, fe_alloc(c, &c->d_vpFirst, N));
+  FECHK(c, fe_alloc(c, &c->d_vpSeed, N));
+  FECHK(c, fe_alloc(c, &V.g, N * VP_CELLS)); FECHK(c, fe_alloc(c, &V.grid, N * VP_CELLS));
+  FECHK(c, fe_alloc(c, &V.pairs, N * VP_IT * 2)); FECHK(c, fe_alloc(c, &V.rng, N * 36)); FECHK(c, fe_alloc(c, &V.status, N));
+  FECHK(c, fe_alloc(c, &V.partScore, N * VP_SCORE_BLOCKS)); FECHK(c, fe_alloc(c, &V.partIdx, N * VP_SCORE_BLOCKS));
+  FECHK(c, fe_alloc(c, &V.vps, N * 9)); FECHK(c, fe_alloc(c, &V.ids, N * ML)); FECHK(c, fe_alloc(c, &V.bestIdx, N));
+  V.maxL = (int)ML;
+  V.hypEnds = c->d_vpHyp; V.allEnds = c->d_vpAll; V.nHyp = c->d_vpNHyp; V.nAll = c->d_vpNAll; V.seed = c->d_vpSeed;
+  V.firstFrame = c->d_vpFirst;
+  c->vpReserved = true;
+  return VPL_OK;
+}
+
+int vpl_vp_detect_batch(vpl_fe_ctx* c, int n, const vpl_line* hyp_lines, const int* n_hyp, const vpl_line* all_lines,
+                        const int* n_all, float f, float cx, float cy, const uint32_t* seeds, const int* first_frame, double* vps,
+                        int* vp_ids, int* status) {
+  if (!c || n < 1 || !hyp_lines || !n_hyp || !all_lines || !n_all || !seeds || !first_frame || !vps || !vp_ids || !status)
+    return VPL_E_INVALID;
+  if (n > c->maxN) return fe_fail(c, VPL_E_CAPACITY, "more frames than max_images");
+  FECHK(c, hipSetDevice(c->device));
+  int rc = vp_reserve(c);
+  if (rc) return rc;
+  const size_t ML = c->maxLines;
+  for (int i = 0; i < n; ++i)
+    if (n_hyp[i] < 0 || n_all[i] < 0 || n_hyp[i] > (int)ML || n_all[i] > (int)ML) return fe_fail(c, VPL_E_CAPACITY, "more lines than max_lines");
+  std::vector<float> eh((size_t)n * ML * 4, 0.f), ea((size_t)n * ML * 4, 0.f);
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < n_hyp[i]; ++k) std::memcpy(&eh[((size_t)i * ML + k) * 4], hyp_lines[(size_t)i * ML + k].line_endpoint, 16);
+    for (int k = 0; k < n_all[i]; ++k) std::memcpy(&ea[((size_t)i * ML + k) * 4], all_lines[(size_t)i * ML + k].line_endpoint, 16);
+  }
+  hipStream_t s = c->stream;
+  VpBatch& V = c->V;
+  V.N = n; V.f = f; V.ppx = cx; V.ppy = cy;
+  FECHK(c, hipMemcpyAsync(c->d_vpHyp, eh.data(), eh.size() * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_vpAll, ea.data(), ea.size() * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_vpNHyp, n_hyp, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_vpNAll, n_all, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_vpSeed, seeds, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_vpFirst, first_frame, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemsetAsync(V.g, 0, (size_t)n * VP_CELLS * 8, s));
+  hipLaunchKernelGGL(k_vp_grid, dim3(n, 2), dim3(64), 0, s, V);
+  hipLaunchKernelGGL(k_vp_smooth, dim3((VP_CELLS + 255) / 256, n), dim3(256), 0, s, V);
+  hipLaunchKernelGGL(k_vp_score, dim3(VP_SCORE_BLOCKS, n), dim3(256), 0, s, V);
+  const size_t pickSmem = ML * (3 * 8 + 4 + 3 * 4);
+  hipLaunchKernelGGL(k_vp_pick, dim3(n), dim3(64), pickSmem, s, V);
+  FECHK(c, hipGetLastError());
+  FECHK(c, hipMemcpyAsync(vps, V.vps, (size_t)n * 72, hipMemcpyDeviceToHost, s));
+  FECHK(c, hipMemcpyAsync(status, V.status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  std::vector<int> ids((size_t)n * ML);
+  FECHK(c, hipMemcpyAsync(ids.data(), V.ids, ids.size() * 4, hipMemcpyDeviceToHost, s));
+  FECHK(c, hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) std::memcpy(vp_ids + (size_t)i * ML, &ids[(size_t)i * ML], (size_t)n_all[i] * 4);
+  c->vpN = n;
+  return VPL_OK;
+}
+
+int vpl_vp_debug(vpl_fe_ctx* c, int frame, double* grid, int* pairs, int* best_idx, int* drawn) {
+  if (!c || !c->vpReserved || frame < 0 || frame >= c->vpN) return VPL_E_INVALID;
+  FECHK(c, hipSetDevice(c->device));
+  FECHK(c, hipStreamSynchronize(c->stream));
+  const VpBatch& V = c->V;
+  if (grid) FECHK(c, hipMemcpy(grid, V.grid + (size_t)frame * VP_CELLS, VP_CELLS * 8, hipMemcpyDeviceToHost));
+  if (pairs) FECHK(c, hipMemcpy(pairs, V.pairs + (size_t)frame * VP_IT * 2, VP_IT * 2 * 4, hipMemcpyDeviceToHost));
+  if (best_idx) FECHK(c, hipMemcpy(best_idx, V.bestIdx + frame, 4, hipMemcpyDeviceToHost));
+  if (drawn) FECHK(c, hipMemcpy(drawn, V.rng + (size_t)frame * 36 + 35, 4, hipMemcpyDeviceToHost));
+  return VPL_OK;
+}
+
 // LineFeatureTracker::readImage, the lists after the match (line_feature_tracker.cpp:109-229).  Plain host code, as in the
 // reference: a few hundred integers per frame.
 int vpl_line_track_ids(int n_new, const float* ends, int n_prev, const int* id_prev, const int* tcnt_prev, int n_tcnt_prev,
                        const int* prev_to_new, int max_h, int max_v, int* allfeature_cnt, int* keep, int* id_out,
-                       int* tcnt_out) {
+                       int* tcnt_out, int* vertical_new, int* n_vertical_new) {
   if (n_new < 0 || n_prev < 0 || !allfeature_cnt || (n_new && (!ends || !keep || !id_out || !tcnt_out)) ||
       (n_prev && (!id_prev || !prev_to_new)) || (n_tcnt_prev && !tcnt_prev))
     return VPL_E_INVALID;
@@ -511,6 +595,10 @@ int vpl_line_track_ids(int n_new, const float* ends, int n_prev, const int* id_p
   const int take_v = std::min<int>(std::max(max_v - v_tracked, 0), (int)fresh_v.size());
   for (int k = 0; k < take_h; ++k, ++n_keep) { keep[n_keep] = fresh_h[k]; id_out[n_keep] = id[fresh_h[k]]; }
   for (int k = 0; k < take_v; ++k, ++n_keep) { keep[n_keep] = fresh_v[k]; id_out[n_keep] = id[fresh_v[k]]; }
+  if (vertical_new && n_vertical_new) {                       // verticalLine of :151-176: every new line of the v class
+    for (size_t k = 0; k < fresh_v.size(); ++k) vertical_new[k] = fresh_v[k];
+    *n_vertical_new = (int)fresh_v.size();
+  }
   return n_keep;
 }
 

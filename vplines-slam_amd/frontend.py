@@ -82,6 +82,10 @@ def _bind(lib):
     lib.vpl_fe_last_error.argtypes = [vp]
     lib.vpl_fe_last_error.restype = C.c_char_p
     lib.vpl_edlines_upload.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8)]
+    lib.vpl_vp_detect_batch.argtypes = [vp, C.c_int, C.POINTER(Line), C.POINTER(C.c_int), C.POINTER(Line), C.POINTER(C.c_int),
+                                        C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.vpl_vp_debug.argtypes = [vp, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.vpl_pre_set_maps.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.vpl_pre_upload.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8)]
     lib.vpl_pre_run.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_int]
@@ -167,6 +171,44 @@ class FrontendContext:
         out = np.empty((self.n, self.H, self.W), np.uint8)
         self._check(self.lib.vpl_pre_download(self.h, self.n, out.ctypes.data_as(C.POINTER(C.c_uint8))), "vpl_pre_download")
         return out
+
+    # ---- vanishing points (vanishing_point_detection.cpp) ----
+    def vp_detect(self, hyp_lines, all_lines, f, cx, cy, seeds, first_frame):
+        """hyp_lines / all_lines: per frame an [k][>=4] array whose first 4 columns are the end points.
+        Returns vps [n][3][3], ids (list of int arrays), status [n]."""
+        n = len(hyp_lines)
+        ML = self.max_lines
+
+        def pack(lists):
+            rec = np.zeros(n * ML, LINE_DTYPE)
+            cnt = np.zeros(n, np.int32)
+            for i, l in enumerate(lists):
+                l = np.asarray(l, np.float64).reshape(-1, np.asarray(l).shape[-1] if len(l) else 4)
+                cnt[i] = len(l)
+                rec["line_endpoint"][i * ML:i * ML + len(l)] = l[:, :4]
+            return rec, cnt
+        rh, nh = pack(hyp_lines)
+        ra, na = pack(all_lines)
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        first = np.ascontiguousarray(first_frame, np.int32)
+        vps = np.zeros((n, 3, 3))
+        ids = np.zeros((n, ML), np.int32)
+        status = np.zeros(n, np.int32)
+        ip = C.POINTER(C.c_int)
+        self._check(self.lib.vpl_vp_detect_batch(self.h, n, rh.ctypes.data_as(C.POINTER(Line)), nh.ctypes.data_as(ip),
+                                                 ra.ctypes.data_as(C.POINTER(Line)), na.ctypes.data_as(ip), f, cx, cy,
+                                                 seeds.ctypes.data_as(C.POINTER(C.c_uint32)), first.ctypes.data_as(ip),
+                                                 vps.ctypes.data_as(C.POINTER(C.c_double)), ids.ctypes.data_as(ip),
+                                                 status.ctypes.data_as(ip)), "vpl_vp_detect_batch")
+        return vps, [ids[i, :na[i]].copy() for i in range(n)], status
+
+    def vp_debug(self, frame):
+        grid = np.zeros((90, 360))
+        pairs = np.zeros((105, 2), np.int32)
+        best, drawn = C.c_int(), C.c_int()
+        self._check(self.lib.vpl_vp_debug(self.h, frame, grid.ctypes.data, pairs.ctypes.data, C.byref(best), C.byref(drawn)),
+                    "vpl_vp_debug")
+        return grid, pairs, best.value, drawn.value
 
     def detect(self, param=None):
         self._param = param or default_param()

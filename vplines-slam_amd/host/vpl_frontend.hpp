@@ -13,6 +13,8 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <ctime>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -172,8 +174,8 @@ class LineMatching {
 
 // FrameLines / LineFeatureTracker (feature_tracker/include/linefeature_tracker.h:45-96, src/line_feature_tracker.cpp).
 // readImage = remap + CLAHE (device) -> EDline (device) -> Matching against the previous frame (device) -> id / quota
-// lists (vpl_line_track_ids).  Vanishing points are not detected here: vps holds the zero vector
-// with flag 0 for every line, which the estimator treats as "no VP observation" (estimator.cpp:1181).
+// lists (vpl_line_track_ids) -> vanishing points (device, vpl_vp_detect_batch).  The reference seeds rand() with
+// time(NULL) inside the VP stage; here the seed comes from vp_seed() (default: time(NULL), settable for reproducible runs).
 struct FrameLines {
   std::vector<uint8_t> img;                       // prepared frame (undistorted, equalised)
   std::vector<Line> vecLine;
@@ -250,17 +252,51 @@ class LineFeatureTracker {
       std::vector<float> ends(4 * (size_t)n_new);
       for (int i = 0; i < n_new; ++i)
         for (int k = 0; k < 4; ++k) ends[4 * i + k] = forwframe_->vecLine[i].line_endpoint[k];
-      std::vector<int> keep(n_new), ids(n_new), tc(n_new);
+      std::vector<int> keep(n_new), ids(n_new), tc(n_new), vert(n_new);
+      int n_vert = 0;
       const int n_keep = vpl_line_track_ids(n_new, ends.data(), n_prev, curframe_->lineID.data(), curframe_->t_cnt.data(),
                                             (int)curframe_->t_cnt.size(), line_prev_to_line_cur.data(), max_h_lines_,
-                                            max_v_lines_, &allfeature_cnt, keep.data(), ids.data(), tc.data());
+                                            max_v_lines_, &allfeature_cnt, keep.data(), ids.data(), tc.data(), vert.data(),
+                                            &n_vert);
       if (n_keep < 0) throw std::runtime_error("vpl_line_track_ids failed");
-      std::vector<Line> kept;
+      std::vector<Line> kept, verticalLine;
       for (int k = 0; k < n_keep; ++k) kept.push_back(forwframe_->vecLine[keep[k]]);
+      for (int k = 0; k < n_vert; ++k) verticalLine.push_back(forwframe_->vecLine[vert[k]]);
       forwframe_->vecLine.swap(kept);
       forwframe_->lineID.assign(ids.begin(), ids.begin() + n_keep);
       forwframe_->t_cnt = tc;                                   // stays in detection order (:227-228 swap only two vectors)
-      forwframe_->vps.assign(forwframe_->vecLine.size(), std::array<double, 4>{0.0, 0.0, 0.0, 0.0});
+      // vanishing points (:233-279)
+      const std::array<double, 4> none{0.0, 0.0, 0.0, 0.0};
+      forwframe_->vps.clear();
+      last_vp_ids.clear();
+      if (forwframe_->vecLine.size() > 2) {
+        const std::vector<Line>& hyp = verticalLine.size() > 2 ? verticalLine : forwframe_->vecLine;
+        const int ML = dev_.max_lines();
+        std::vector<vpl_line> lh(ML), la(ML);
+        for (size_t i = 0; i < hyp.size(); ++i) lh[i] = from_line(hyp[i]);
+        for (size_t i = 0; i < forwframe_->vecLine.size(); ++i) la[i] = from_line(forwframe_->vecLine[i]);
+        const int nh = (int)hyp.size(), na = (int)forwframe_->vecLine.size();
+        const uint32_t seed = vp_seed();
+        const int first = vp_frame_count_ == 0 ? 1 : 0;
+        double vps[9];
+        int status = 0;
+        std::vector<int> local_vp_ids(ML, 3);
+        if (vpl_vp_detect_batch(dev_.ctx(), 1, lh.data(), &nh, la.data(), &na, fx_, cx_, cy_, &seed, &first, vps,
+                                local_vp_ids.data(), &status) != 0)
+          throw std::runtime_error(std::string("vpl_vp_detect_batch: ") + vpl_fe_last_error(dev_.ctx()));
+        ++vp_frame_count_;
+        last_vp_seed = seed;
+        std::memcpy(last_vps, vps, sizeof(vps));
+        for (int i = 0; i < na; ++i) {
+          const int id = status == 0 ? local_vp_ids[i] : 3;
+          last_vp_ids.push_back(id);
+          if (id == 3) { forwframe_->vps.push_back(none); continue; }
+          const double* v = vps + 3 * id;
+          forwframe_->vps.push_back(std::array<double, 4>{v[0], v[1], v[2], v[2] / v[2]});      // (:256)
+        }
+      } else {
+        forwframe_->vps.assign(forwframe_->vecLine.size(), none);
+      }
     }
     curframe_.swap(forwframe_);
   }
@@ -286,6 +322,10 @@ class LineFeatureTracker {
   std::shared_ptr<FrameLines> curframe_, forwframe_;
   int allfeature_cnt = 0;
   bool lines_exit = true;
+  std::function<uint32_t()> vp_seed = [] { return (uint32_t)std::time(nullptr); };   // srand((unsigned)time(NULL)), :107
+  std::vector<int> last_vp_ids;                   // local_vp_ids of the last readImage (test access)
+  double last_vps[9] = {0};
+  uint32_t last_vp_seed = 0;
   std::vector<int> last_match;                    // line_prev_to_line_cur of the last readImage (test access)
   std::vector<Line> last_detected;                // the last frame's detections before the quota (test access)
 
@@ -296,6 +336,7 @@ class LineFeatureTracker {
   int max_h_lines_, max_v_lines_;
   bool equalize_;
   float fx_ = 1.f, fy_ = 1.f, cx_ = 0.f, cy_ = 0.f;
+  int vp_frame_count_ = 0;
 };
 
 }  // namespace vplhost
