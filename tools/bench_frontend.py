@@ -2,7 +2,8 @@
 line matching of the 63 consecutive pairs -- with the frames resident in HBM.  The detected lines pass through the host
 between the two stages, as they do in the reference (the tracker owns them); that round trip is inside the timed region.
 With --prep the raw frames first go through the undistortion remap + CLAHE(3.0, 8x8) of LineFeatureTracker::readImage
-(EuRoC cam0 maps) on the device, inside the timed region.  Prints one JSON line."""
+(EuRoC cam0 maps) on the device, inside the timed region.  With --vp the vanishing-point stage runs on the lines of every
+frame after the match (hypotheses from all lines of the frame), also inside the timed region.  Prints one JSON line."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.dirname(__file__))
@@ -19,6 +20,8 @@ def main():
     fe = v.frontend.FrontendContext(device=0, max_images=n, width=752, height=480, max_lines=256,
                                     stream=torch.cuda.current_stream(dev).cuda_stream)
     prep = "--prep" in sys.argv
+    vp = "--vp" in sys.argv
+    vp_out, vp_ms = [], []
     fe.match_reserve(n - 1, 8192 if prep else 4096)
     if prep:
         from test_preproc import euroc_maps, oracle_clahe, oracle_remap
@@ -39,7 +42,12 @@ def main():
         fe.match_upload(pairs, [lines[a] for a, _ in pairs], [lines[b] for _, b in pairs])
         fe.match_run()
         fe.synchronize()
-        return lines, fe.match_download()
+        out = fe.match_download()
+        if vp:
+            t = time.perf_counter()
+            vp_out.append(fe.vp_detect(lines, lines, 458.654, 376.0, 240.0, np.arange(n) + 7, np.zeros(n, np.int32)))
+            vp_ms.append(1e3 * (time.perf_counter() - t))
+        return lines, out
 
     for _ in range(warm):
         step()
@@ -67,7 +75,8 @@ def main():
         same += int(len(la) == len(lines[i]) and np.array_equal(ro, r2c[i]))
     tc = (time.perf_counter() - tc) / 4
     print(json.dumps({"metric": "line front-end frames/s (EDLines + KLT matching, 752x480, batch 64)", "value": n / dt,
-                      "unit": "frames/s", "prep": prep, "ms_per_batch": 1e3 * dt, "device_ms_prep": ep.elapsed_time(e0), "device_ms_detect": e0.elapsed_time(e1),
+                      "unit": "frames/s", "prep": prep, "vp": vp, "vp_stage_ms_per_batch_incl_transfers": float(np.mean(vp_ms[2:])) if vp else None,
+                      "vp_classified_lines_per_frame": float(np.mean([(i < 3).sum() for i in vp_out[-1][1]])) if vp else None, "ms_per_batch": 1e3 * dt, "device_ms_prep": ep.elapsed_time(e0), "device_ms_detect": e0.elapsed_time(e1),
                       "device_ms_match": e1.elapsed_time(e2), "host_round_trip_ms": 1e3 * dt - ep.elapsed_time(e2),
                       "mean_lines_per_frame": float(np.mean([len(l) for l in lines])),
                       "mean_matches_per_pair": float(np.mean([(r >= 0).sum() for r in r2c])),
