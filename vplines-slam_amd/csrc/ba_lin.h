@@ -247,12 +247,17 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   const double* xe = xp + 77;
   const double hub = B.opt.huber_delta;
   const int lane = tid & 63;
-  // zero the dense W rows first (frames a track does not observe must read as zero)
-  {
-    double* Wp0 = B.Wp + (size_t)w * B.maxP * NV;
-    for (int i = tid; i < nP * NV; i += T) Wp0[i] = 0.0;
-    double* Wl0 = B.Wl + (size_t)w * B.maxL * 4 * NV;
-    for (int i = tid; i < nL * 4 * NV; i += T) Wl0[i] = 0.0;
+  // zero the W rows first where some slot is not written by a factor (shorter tracks, erased lines, the start-frame
+  // slot of the lines in the marginalisation pass); uniform track lengths need no fill in the solve
+  const int WS = B.WS;
+  if (MARG || B.wfill) {
+    // (the marginalisation pass only ever reads the rows of the tracks that start in frame 0)
+    double* Wp0 = B.Wp + (size_t)w * B.maxP * WS;
+    for (int i = tid; i < nP * WS; i += T)
+      if (!MARG || B.pt_start[(size_t)w * B.maxP + i / WS] == 0) Wp0[i] = 0.0;
+    double* Wl0 = B.Wl + (size_t)w * B.maxL * 4 * WS;
+    for (int i = tid; i < nL * 4 * WS; i += T)
+      if (!MARG || B.ln_start[(size_t)w * B.maxL + i / (4 * WS)] == 0) Wl0[i] = 0.0;
   }
   __syncthreads();
 
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
       const int no = live ? B.pt_nobs[pi] : 0, off = live ? B.pt_off[pi] : 0;
       const bool act = live && k < no;
       const int j = s + k;
-      double* Wrow = B.Wp + pi * NV;
+      double* Wrow = B.Wp + pi * WS;
       double r[2] = {0, 0}, Ji[12], Jj[12], Je[12];
 #pragma unroll
       for (int q = 0; q < 12; ++q) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
         for (int a = 0; a < 6; ++a) {
           lds_add(&pa[2 + a], Jl[0] * Ji[a] + Jl[1] * Ji[6 + a]);
           lds_add(&pa[8 + a], Jl[0] * Je[a] + Jl[1] * Je[6 + a]);
-          Wrow[6 * j + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];   // this (track, frame) entry has one writer
+          Wrow[6 * k + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];   // this (track, frame) entry has one writer
         }
       }
       // ---- per quarter: reduction of [Js Jj Je r]^T [Js Jj Je r] over its 16 lanes on the matrix cores ----
@@ -373,12 +378,11 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   for (int p = tid; p < nP; p += T) {   // per-track sums out of LDS
     const size_t pi = (size_t)w * B.maxP + p;
     const double* pa = pacc + 14 * p;
-    double* Wrow = B.Wp + pi * NV;
-    const int s0 = B.pt_start[pi];
+    double* Wrow = B.Wp + pi * WS;
     B.Hpp[pi] = pa[0];
     B.gp[pi] = pa[1];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) { Wrow[6 * s0 + a] = pa[2 + a]; Wrow[66 + a] = pa[8 + a]; }
+    for (int a = 0; a < 6; ++a) { Wrow[a] = pa[2 + a]; Wrow[WS - 6 + a] = pa[8 + a]; }
   }
   __syncthreads();   // staging space is handed over to the IMU / line phases
   VPL_STAMP(B, w, 24);
@@ -529,11 +533,11 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
       if (tid == 0) { B.dbg[(size_t)w * 64 + 44] = lt_ctx; B.dbg[(size_t)w * 64 + 45] = lt_math; B.dbg[(size_t)w * 64 + 46] = lt_atom; B.dbg[(size_t)w * 64 + 47] = lt_ext; }
 #endif
       if (act) {
-        double* Wl = B.Wl + li * 4 * NV;
+        double* Wl = B.Wl + li * 4 * WS;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int c2 = 0; c2 < 6; ++c2) Wl[a * NV + 6 * j + c2] = Wj[6 * a + c2];
+          for (int c2 = 0; c2 < 6; ++c2) Wl[a * WS + 6 * k + c2] = Wj[6 * a + c2];
       }
     }
   }
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
 #pragma unroll
       for (int c2 = 0; c2 <= a; ++c2, ++t) { Hl[4 * a + c2] = la[t]; Hl[4 * c2 + a] = la[t]; }
 #pragma unroll
-      for (int c2 = 0; c2 < 6; ++c2) B.Wl[(li * 4 + a) * NV + 66 + c2] = la[14 + 6 * a + c2];
+      for (int c2 = 0; c2 < 6; ++c2) B.Wl[(li * 4 + a) * WS + WS - 6 + c2] = la[14 + 6 * a + c2];
     }
   }
   __syncthreads();

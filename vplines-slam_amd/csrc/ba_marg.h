@@ -371,7 +371,8 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
         const size_t pi = (size_t)w * B.maxP + lst[base + rr];
         const double hpp = B.Hpp[pi];
         const double isq = hpp != 0.0 ? 1.0 / sqrt(hpp) : 0.0;
-        tile[rr * 74 + c] = isq * (c < NV ? B.Wp[pi * NV + c] : B.gp[pi]);
+        const int cc = c < NV ? wcol(c, B.pt_start[pi], B.WS) : 0;
+        tile[rr * 74 + c] = cc < 0 ? 0.0 : isq * (c < NV ? B.Wp[pi * B.WS + cc] : B.gp[pi]);
       }
       base += cnt;
     } else {
@@ -397,8 +398,9 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
             Cc[tri(ii, jj)] = s2 / d;
           }
         }
+        const int cc = c < NV ? wcol(c, B.ln_start[li], B.WS) : 0;
         for (int a = 0; a < 4; ++a) {
-          double s2 = c < NV ? B.Wl[(li * 4 + a) * NV + c] : B.gl[li * 4 + a];
+          double s2 = cc < 0 ? 0.0 : (c < NV ? B.Wl[(li * 4 + a) * B.WS + cc] : B.gl[li * 4 + a]);
           for (int k = 0; k < a; ++k) s2 -= Cc[tri(a, k)] * x[k];
           x[a] = s2 / Cc[tri(a, a)];
           tile[(4 * ll + a) * 74 + c] = x[a];

@@ -116,8 +116,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
   double* isd = yv + 176;         // 176 1/L_jj
   double* red = isd + 176;        // 24
   int* flag = (int*)(red + 24);   // 4
+  int* pSt = flag + 4;            // maxP  start frame of every point track (column map of the compact W rows)
+  int* lSt = pSt + B.maxP;        // maxL  same for the lines
 
   const int nP = B.nP[w], nL = B.nL[w];
+  const int WS = B.WS;
+  for (int p = tid; p < nP; p += T) pSt[p] = B.pt_start[(size_t)w * B.maxP + p];
+  for (int l = tid; l < nL; l += T) lSt[l] = B.ln_start[(size_t)w * B.maxL + l];
   const size_t fb = (size_t)w * B.nfull;
   double* gscale = B.scale + fb;
   double* gdiag = B.diag + fb;
@@ -282,7 +287,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
               raw[k] = 0.0;
               if (rr < cnt && c <= NV) {
                 const size_t pi = (size_t)w * B.maxP + r0 + rr;
-                raw[k] = c < NV ? B.Wp[pi * NV + c] : B.gp[pi];
+                const int cc = c < NV ? wcol(c, pSt[r0 + rr], WS) : 0;
+                if (cc >= 0) raw[k] = c < NV ? B.Wp[pi * WS + cc] : B.gp[pi];
               }
             }
 #pragma unroll
@@ -304,10 +310,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
             const int ll = it / CW, c = it - ll * CW;
             const bool on = it < (CROWS / 4) * CW && ll < cnt && c <= NV;
             const size_t li = (size_t)w * B.maxL + l0 + (on ? ll : 0);
+            const int cc = (on && c < NV) ? wcol(c, lSt[l0 + ll], WS) : 0;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
               wv4[k][a] = 0.0;
-              if (on) wv4[k][a] = c < NV ? B.Wl[(li * 4 + a) * NV + c] : B.gl[li * 4 + a];
+              if (on && cc >= 0) wv4[k][a] = c < NV ? B.Wl[(li * 4 + a) * WS + cc] : B.gl[li * 4 + a];
             }
           }
 #pragma unroll
@@ -588,6 +595,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
     //      that every 72-wide row of W is read as one contiguous 576-byte segment
     {
       const int sub = lane & 7, grp = tid >> 3;   // 64 row groups per pass
+      const int nblk = WS / 6;
       for (int p0 = 0; p0 < nP; p0 += 2 * (T / 8)) {   // two row groups per trip: their loads are in flight together
         double wyv[2] = {0.0, 0.0}, sv[2], dv[2], hv[2], gv2[2], grv[2];
         size_t piv[2];
@@ -597,9 +605,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
           piv[h] = (size_t)w * B.maxP + (p < nP ? p : 0);
           sv[h] = dv[h] = 1.0; hv[h] = gv2[h] = grv[h] = 0.0;
           if (p < nP) {
-            const double* Wr = B.Wp + piv[h] * NV + 9 * sub;
+            // compact row: 6-blocks of the frames start .. start + maxTrack - 1, then the extrinsic block
+            const int s0 = pSt[p];
+            for (int blk = sub; blk < nblk; blk += 8) {
+              const bool exb = blk == nblk - 1;
+              const int vb = exb ? 66 : 6 * (s0 + blk);
+              if (!exb && vb >= 66) continue;               // slot of a frame past the window
+              const double* Wr = B.Wp + piv[h] * WS + 6 * blk;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wyv[h] += Wr[k] * uc[vis2cam(9 * sub + k)];
+              for (int k = 0; k < 6; ++k) wyv[h] += Wr[k] * uc[vis2cam(vb + k)];
+            }
             if (sub == 0) {
               sv[h] = gscale[LP + p]; dv[h] = gdiag[LP + p]; hv[h] = B.Hpp[piv[h]]; gv2[h] = B.gp[piv[h]];
               grv[h] = ggrad[LP + p];
@@ -628,9 +643,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
         size_t li = 0;
         if (l < nL) {
           li = (size_t)w * B.maxL + l;
-          const double* Wr = B.Wl + (li * 4 + a) * NV + 9 * sub;
+          const int s0 = lSt[l];
+          for (int blk = sub; blk < nblk; blk += 8) {
+            const bool exb = blk == nblk - 1;
+            const int vb = exb ? 66 : 6 * (s0 + blk);
+            if (!exb && vb >= 66) continue;
+            const double* Wr = B.Wl + (li * 4 + a) * WS + 6 * blk;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) wy += Wr[k] * uc[vis2cam(9 * sub + k)];
+            for (int k = 0; k < 6; ++k) wy += Wr[k] * uc[vis2cam(vb + k)];
+          }
         }
         wy += __shfl_xor(wy, 1, 64); wy += __shfl_xor(wy, 2, 64); wy += __shfl_xor(wy, 4, 64);
         // the 4 rows of a line sit in 4 adjacent 8-lane groups of the same wave: gather on the first
@@ -776,7 +797,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
   }
 }
 
-constexpr size_t SOLVE_SMEM = (size_t)(NAP + 5 * 176 + 24) * sizeof(double) + 4 * sizeof(int);
+constexpr size_t SOLVE_SMEM = (size_t)(NAP + 5 * 176 + 24) * sizeof(double) + 4 * sizeof(int);   // + (maxP + maxL) ints, see solve_smem
+inline size_t solve_smem(int maxP, int maxL) { return SOLVE_SMEM + (size_t)(maxP + maxL) * sizeof(int); }
 static_assert(2 * CROWS * CW <= NAP, "the two staging buffers alias the reduced-system storage");
 
 // ---------------------------------------------------------------------------------------------------

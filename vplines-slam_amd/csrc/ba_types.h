@@ -14,6 +14,12 @@ namespace vpl {
 constexpr int NF = 11;                 // WINDOW_SIZE + 1 frames
 constexpr int NC = 171;                // cam dims
 constexpr int NV = 72;                 // vis dims
+// column of vis dim c (0..71) in the compact W row of a track that starts in frame s; -1: structurally zero
+__host__ __device__ inline int wcol(int c, int s, int WS) {
+  if (c >= 66) return WS - 72 + c;
+  const int cc = c - 6 * s;
+  return (cc >= 0 && cc < WS - 6) ? cc : -1;
+}
 constexpr int NCP = NC * (NC + 1) / 2; // packed lower triangle of the cam Hessian (14706)
 constexpr int MAXPB = 23;              // prior blocks
 constexpr int MAXPN = 171;             // prior dim
@@ -88,8 +94,12 @@ struct DevBatch {
 
   // ---- linearisation (one buffer set; written by k_lin at the current x) ----
   double *Hcc, *gc;                              // [W][NCP] [W][NC]
-  double *Hpp, *gp, *Wp;                         // [W][maxP] [W][maxP] [W][maxP][NV]
-  double *Hll, *gl, *Wl;                         // [W][maxL][16] [W][maxL][4] [W][maxL][4][NV]
+  double *Hpp, *gp, *Wp;                         // [W][maxP] [W][maxP] [W][maxP][WS]
+  double *Hll, *gl, *Wl;                         // [W][maxL][16] [W][maxL][4] [W][maxL][4][WS]
+  // W rows are stored compact: the 6 x 6 blocks of the frames start .. start + maxTrack - 1 of the track, then the 6
+  // extrinsic columns: WS = 6 * maxTrack + 6 doubles (42 for 6-frame tracks, 72 = NV at most).  wfill: rows have slots no
+  // factor writes (shorter tracks, erased lines) and must be zeroed before the factors are accumulated.
+  int WS, wfill;
   double *lchol;                                 // [W][maxL][10] Cholesky factors of the regularised line blocks
 
   // ---- trust region vectors over the full index ----

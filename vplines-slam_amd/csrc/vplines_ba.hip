@@ -165,6 +165,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   c->maxLO = max_line_obs > 0 ? max_line_obs : 1;
   // k_solve keeps 2 doubles per point and 18 per line in the LDS space behind its two staging buffers
   if (2 * c->maxP + 18 * c->maxL > NAP - 2 * CROWS * CW) { delete c; return VPL_E_CAPACITY; }
+  if (solve_smem(c->maxP, c->maxL) > 159 * 1024) { delete c; return VPL_E_CAPACITY; }
   DevBatch& B = c->B;
   std::memset(&B, 0, sizeof(B));
   B.maxP = c->maxP; B.maxPO = c->maxPO; B.maxL = c->maxL; B.maxLO = c->maxLO;
@@ -203,7 +204,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   hipFuncSetAttribute((const void*)k_lin<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxP, c->maxL));
   hipFuncSetAttribute((const void*)k_lin<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxP, c->maxL));
   hipFuncSetAttribute((const void*)k_lin<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxP, c->maxL));
-  hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
+  hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(c->maxP, c->maxL));
   hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SMEM);
   hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
   (void)hipGetLastError();
@@ -401,6 +402,18 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   c->h_nP.assign(W, 0);
   c->h_nL.assign(W, 0);
   c->h_lmap.resize(W);
+
+  // compact W rows: stride from the longest track of the batch; zero fill only where some slot has no writer
+  {
+    int maxTrack = 2, minTrack = NF;
+    for (size_t w = 0; w < W; ++w) {
+      for (int p = 0; p < win[w].n_points; ++p) { maxTrack = std::max(maxTrack, win[w].point_nobs[p]); minTrack = std::min(minTrack, win[w].point_nobs[p]); }
+      for (int l = 0; l < win[w].n_lines; ++l) { maxTrack = std::max(maxTrack, win[w].line_nobs[l]); minTrack = std::min(minTrack, win[w].line_nobs[l]); }
+    }
+    maxTrack = std::min(maxTrack, (int)NF);
+    B.WS = 6 * maxTrack + 6;
+    B.wfill = (minTrack != maxTrack || opt->remove_line_outliers) ? 1 : 0;
+  }
 
   for (size_t w = 0; w < W; ++w) {
     const vpl_window& v = win[w];
@@ -768,7 +781,7 @@ int vpl_ba_solve(vpl_ctx* c) {
   { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(256), PREP_SMEM, s, B); }
   { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
   for (int it = 0; it < c->opt.num_iterations; ++it) {
-    { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), SOLVE_SMEM, s, B); }
+    { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), solve_smem(B.maxP, B.maxL), s, B); }
     { KTimer t(c, "k_cost"); hipLaunchKernelGGL(k_cost, grid, dim3(COST_THREADS), 0, s, B); }
     if (it + 1 < c->opt.num_iterations) {
       KTimer t(c, "k_lin");
