@@ -79,9 +79,12 @@ __device__ __forceinline__ double swizzle_row_f64(double v) {   // value of lane
   return __hiloint2double(hi, lo);
 }
 
-// one column step of the right-looking factorisation of the 16x16 diagonal tile held in registers
+// one column step of the right-looking factorisation of the 16x16 diagonal tile held in registers.  The same row
+// operations are applied to an identity matrix m (same lane layout): after the 16 steps m = L~^-1 with L~ the unit lower
+// factor, so L^-1 = diag(1 / sqrt(pivot)) m comes out of the factorisation for the price of one more bpermute per step
+// (independent of the first) -- and the rows below the tile become a matrix product instead of 16-step substitutions.
 template <int J>
-__device__ __forceinline__ void diag_tile_step(double (&d)[4], int r4, int cc, int ncol, double& pivc, bool& bad) {
+__device__ __forceinline__ void diag_tile_step(double (&d)[4], double (&m)[4], int r4, int cc, int ncol, double& pivc, bool& bad) {
   if (J < ncol && !bad) {
     const double ajj = readlane_f64(d[J >> 2], ((J & 3) << 4) | J);
     if (!(ajj > 0.0)) {
@@ -93,10 +96,14 @@ __device__ __forceinline__ void diag_tile_step(double (&d)[4], int r4, int cc, i
       rinv = fma(rinv, fma(-ajj, rinv, 1.0), rinv);
       rinv = fma(rinv, fma(-ajj, rinv, 1.0), rinv);
       const double f = __shfl(d[J >> 2], ((J & 3) << 4) | cc, 64) * rinv;            // D[J][cc] / a_JJ
+      const double f2 = __shfl(m[J >> 2], ((J & 3) << 4) | cc, 64) * rinv;           // M[J][cc] / a_JJ
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const double cv = swizzle_row_f64<J>(d[v]);                                 // D[r4 + 4v][J]
-        if (r4 + 4 * v > J && cc > J) d[v] -= cv * f;
+        if (r4 + 4 * v > J) {
+          if (cc > J) d[v] -= cv * f;
+          m[v] -= cv * f2;
+        }
       }
     }
   }
@@ -114,7 +121,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
   double* uc = dg + 176;          // 176 work vector (u for the Cauchy point, later S_c y_c)
   double* yv = uc + 176;          // 176 solution of the reduced system / z
   double* isd = yv + 176;         // 176 1/L_jj
-  double* red = isd + 176;        // 24
+  double* Linv = isd + 176;       // 256  inverse of the current diagonal tile's factor (swizzled tile)
+  double* red = Linv + 256;       // 24
   int* flag = (int*)(red + 24);   // 4
   int* pSt = flag + 4;            // maxP  start frame of every point track (column map of the compact W rows)
   int* lSt = pSt + B.maxP;        // maxL  same for the lines
@@ -465,7 +473,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
           const int ncol = min(16, NC - 16 * K);
           double pivc = 1.0;
           bool bad = false;
-#define VPL_DSTEP(J) diag_tile_step<J>(d, r4, cc, ncol, pivc, bad);
+          double m[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) m[v] = (r4 + 4 * v == cc) ? 1.0 : 0.0;
+#define VPL_DSTEP(J) diag_tile_step<J>(d, m, r4, cc, ncol, pivc, bad);
           VPL_DSTEP(0) VPL_DSTEP(1) VPL_DSTEP(2) VPL_DSTEP(3) VPL_DSTEP(4) VPL_DSTEP(5) VPL_DSTEP(6) VPL_DSTEP(7)
           VPL_DSTEP(8) VPL_DSTEP(9) VPL_DSTEP(10) VPL_DSTEP(11) VPL_DSTEP(12) VPL_DSTEP(13) VPL_DSTEP(14) VPL_DSTEP(15)
 #undef VPL_DSTEP
@@ -482,6 +493,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
                 else if (r == cc) { const double id = 1.0 / sq; isd[16 * K + cc] = id; D[tsw(r, cc)] = 1.0 / id; }
               }
             }
+            if (K < NT16 - 1) {
+              // L^-1 = diag(1 / sqrt(pivot)) m for the tiles below (ncol == 16 here); 1/sqrt(pivot of row r) sits in lane r
+              const double isq = 1.0 / sq;
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const int r = r4 + 4 * v;
+                const double ir = __shfl(isq, r, 64);
+                Linv[tsw(r, cc)] = cc <= r ? m[v] * ir : 0.0;
+              }
+            }
           }
         }
         __syncthreads();
@@ -489,26 +510,18 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
         { const long long t1 = __builtin_readcyclecounter(); tb += t1 - t0; t0 = t1; }
 #endif
         if (flag[0]) break;
-        {   // rows below the diagonal tile (including the rest of the rhs row's tile row)
-          const int nrow = 16 * (NT16 - 1 - K);
-          const double* D = S + ((K * (K + 1) / 2 + K) << 8);
-          const int ncol = min(16, NC - 16 * K);
-          for (int rr = tid; rr < nrow; rr += T) {
-            const int r = 16 * (K + 1) + rr;
-            if (r > NC) continue;
-            double* Ar = S + (((r >> 4) * ((r >> 4) + 1) / 2 + K) << 8) + (r & 15) * 16;   // row r of tile (r/16, K)
-            const int rx = r & 15;                                                          // its swizzle key
-            double x[16];
+        // tiles below the diagonal tile (the rhs row is in tile row 10): X = A(I,K) L(K,K)^-T = A(I,K) Linv^T on the
+        // matrix cores, X[m][n] = sum_k A[m][k] Linv[n][k]
+        for (int I = K + 1 + wv; I < NT16; I += SOLVE_THREADS / 64) {
+          const int m = lane & 15, kk = lane >> 4;
+          double* At = S + ((I * (I + 1) / 2 + K) << 8);
+          v4d c = {0.0, 0.0, 0.0, 0.0};
+          double av[4], bv[4];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-              double s2 = Ar[j ^ rx];
+          for (int ks = 0; ks < 4; ++ks) { av[ks] = At[tsw(m, 4 * ks + kk)]; bv[ks] = Linv[tsw(m, 4 * ks + kk)]; }
 #pragma unroll
-              for (int k = 0; k < 16; ++k) if (k < j) s2 -= x[k] * D[tsw(j, k)];
-              x[j] = j < ncol ? s2 * isd[16 * K + j] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) if (j < ncol) Ar[j ^ rx] = x[j];
-          }
+          for (int ks = 0; ks < 4; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c, 0, 0, 0);
+          At[tsw(kk, m)] = c.x; At[tsw(kk + 4, m)] = c.y; At[tsw(kk + 8, m)] = c.z; At[tsw(kk + 12, m)] = c.w;
         }
         __syncthreads();
 #ifdef VPL_STAMPS
@@ -797,7 +810,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
   }
 }
 
-constexpr size_t SOLVE_SMEM = (size_t)(NAP + 5 * 176 + 24) * sizeof(double) + 4 * sizeof(int);   // + (maxP + maxL) ints, see solve_smem
+constexpr size_t SOLVE_SMEM = (size_t)(NAP + 5 * 176 + 256 + 24) * sizeof(double) + 4 * sizeof(int);   // + (maxP + maxL) ints, see solve_smem
 inline size_t solve_smem(int maxP, int maxL) { return SOLVE_SMEM + (size_t)(maxP + maxL) * sizeof(int); }
 static_assert(2 * CROWS * CW <= NAP, "the two staging buffers alias the reduced-system storage");
 
