@@ -438,24 +438,28 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
       long long ta = 0, tb = 0, tc = 0, t0 = __builtin_readcyclecounter();
 #endif
       for (int K = 0; K < NT16; ++K) {
-        if (K > 0) {
-          for (int I = K + wv; I < NT16; I += SOLVE_THREADS / 64) {
-            const int m = lane & 15, kk = lane >> 4;
-            double* Ct = S + ((I * (I + 1) / 2 + K) << 8);
-            v4d c;
-            c.x = Ct[tsw(kk, m)]; c.y = Ct[tsw(kk + 4, m)]; c.z = Ct[tsw(kk + 8, m)]; c.w = Ct[tsw(kk + 12, m)];
-            for (int J = 0; J < K; ++J) {
-              const double* Ai = S + ((I * (I + 1) / 2 + J) << 8);
-              const double* Bk = S + ((K * (K + 1) / 2 + J) << 8);
+        // C(I,K) -= sum_{J<K} L(I,J) L(K,J)^T is applied in two parts: the terms J < K-1 were already subtracted by the
+        // idle waves while wave 0 factored the previous diagonal tile (look-ahead, below); only J = K-1 is left here.
+        // The order of the terms, and therefore every bit of the result, is the one of a single pass.
+        auto rank_update = [&](int col, int I, int J0, int J1) {
+          const int m = lane & 15, kk = lane >> 4;
+          double* Ct = S + ((I * (I + 1) / 2 + col) << 8);
+          v4d c;
+          c.x = Ct[tsw(kk, m)]; c.y = Ct[tsw(kk + 4, m)]; c.z = Ct[tsw(kk + 8, m)]; c.w = Ct[tsw(kk + 12, m)];
+          for (int J = J0; J < J1; ++J) {
+            const double* Ai = S + ((I * (I + 1) / 2 + J) << 8);
+            const double* Bk = S + ((col * (col + 1) / 2 + J) << 8);
 #pragma unroll
-              for (int ks = 0; ks < 4; ++ks) {
-                const double av = -Ai[tsw(m, 4 * ks + kk)];
-                const double bv = Bk[tsw(m, 4 * ks + kk)];
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
-              }
+            for (int ks = 0; ks < 4; ++ks) {
+              const double av = -Ai[tsw(m, 4 * ks + kk)];
+              const double bv = Bk[tsw(m, 4 * ks + kk)];
+              c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
             }
-            Ct[tsw(kk, m)] = c.x; Ct[tsw(kk + 4, m)] = c.y; Ct[tsw(kk + 8, m)] = c.z; Ct[tsw(kk + 12, m)] = c.w;
           }
+          Ct[tsw(kk, m)] = c.x; Ct[tsw(kk + 4, m)] = c.y; Ct[tsw(kk + 8, m)] = c.z; Ct[tsw(kk + 12, m)] = c.w;
+        };
+        if (K > 0) {
+          for (int I = K + wv; I < NT16; I += SOLVE_THREADS / 64) rank_update(K, I, K - 1, K);
           __syncthreads();
         }
 #ifdef VPL_STAMPS
@@ -504,6 +508,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
               }
             }
           }
+        } else if (K >= 1 && K + 1 < NT16) {
+          // look-ahead: the other waves subtract the finished columns J < K from tile column K+1 meanwhile
+          for (int I = K + 1 + (wv - 1); I < NT16; I += SOLVE_THREADS / 64 - 1) rank_update(K + 1, I, 0, K);
         }
         __syncthreads();
 #ifdef VPL_STAMPS
