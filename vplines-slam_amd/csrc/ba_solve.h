@@ -72,10 +72,9 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {   // src
   return __hiloint2double(hi, lo);
 }
 template <int J>
-__device__ __forceinline__ double swizzle_row_f64(double v) {   // value of lane (lane & 48) | J: ds_swizzle, bit-mask mode
-  constexpr int pat = (J << 5) | 0x10;                           // and_mask 0x10 keeps the row group inside the 32-lane half
-  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
-  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+__device__ __forceinline__ double swizzle_row_f64(double v) {   // value of lane (lane & 48) | J: DPP row_newbcast:J (gfx90a+),
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);   // VALU speed, no LDS path
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 
