@@ -44,6 +44,8 @@ def build_hip(force=False, verbose=False):
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_LIB] + srcs
     if os.environ.get("VPL_STAMPS"):
         cmd.insert(1, "-DVPL_STAMPS")
+    for d in os.environ.get("VPL_EXTRA_DEFS", "").split():   # A/B experiments: -DNAME[=value] switches of the kernels
+        cmd.insert(1, d)
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     out = _run(cmd)

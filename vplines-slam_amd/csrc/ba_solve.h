@@ -73,8 +73,8 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {   // src
 }
 template <int J>
 __device__ __forceinline__ double swizzle_row_f64(double v) {   // value of lane (lane & 48) | J: DPP row_newbcast:J (gfx90a+),
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);   // VALU speed, no LDS path
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + J, 0xf, 0xf, false);   // VALU speed, no LDS path
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + J, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 
@@ -90,7 +90,9 @@ __device__ __forceinline__ void diag_tile_step(double (&d)[4], double (&m)[4], i
       bad = true;
     } else {
       if (cc == J) pivc = ajj;
-      // 1 / a_JJ by v_rcp_f64 + two Newton steps (5 dependent instructions; an IEEE divide is ~10 on this chain)
+      // 1 / a_JJ by v_rcp_f64 + two Newton steps (5 dependent instructions; an IEEE divide is ~10 on this chain).
+      // Measured alternatives, all slower on this lone wave: branch-free steps with the products formed ahead of the
+      // reciprocal, v_permlane swaps instead of ds_bpermute, a column-per-lane layout with v_readlane / DPP broadcasts.
       double rinv = __builtin_amdgcn_rcp(ajj);
       rinv = fma(rinv, fma(-ajj, rinv, 1.0), rinv);
       rinv = fma(rinv, fma(-ajj, rinv, 1.0), rinv);
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
       //   (c) rows below: x = a L(K,K)^-T, one lane per row
       // The rhs row (row NC, inside tile row 10) rides along: forward substitution for free.
 #ifdef VPL_STAMPS
-      long long ta = 0, tb = 0, tc = 0, t0 = __builtin_readcyclecounter();
+      long long ta = 0, tb = 0, tc = 0, td = 0, t0 = __builtin_readcyclecounter();
 #endif
       for (int K = 0; K < NT16; ++K) {
         // C(I,K) -= sum_{J<K} L(I,J) L(K,J)^T is applied in two parts: the terms J < K-1 were already subtracted by the
@@ -479,10 +481,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
           double m[4];
 #pragma unroll
           for (int v = 0; v < 4; ++v) m[v] = (r4 + 4 * v == cc) ? 1.0 : 0.0;
+#ifdef VPL_STAMPS
+          const long long td0 = __builtin_readcyclecounter();
+#endif
 #define VPL_DSTEP(J) diag_tile_step<J>(d, m, r4, cc, ncol, pivc, bad);
           VPL_DSTEP(0) VPL_DSTEP(1) VPL_DSTEP(2) VPL_DSTEP(3) VPL_DSTEP(4) VPL_DSTEP(5) VPL_DSTEP(6) VPL_DSTEP(7)
           VPL_DSTEP(8) VPL_DSTEP(9) VPL_DSTEP(10) VPL_DSTEP(11) VPL_DSTEP(12) VPL_DSTEP(13) VPL_DSTEP(14) VPL_DSTEP(15)
 #undef VPL_DSTEP
+#ifdef VPL_STAMPS
+          td += __builtin_readcyclecounter() - td0;
+#endif
           if (bad) {
             if (lane == 0) flag[0] = 1;
           } else {
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
 #endif
       }
 #ifdef VPL_STAMPS
-      if (tid == 0) { B.dbg[(size_t)w * 64 + 40] = ta; B.dbg[(size_t)w * 64 + 41] = tb; B.dbg[(size_t)w * 64 + 42] = tc; }
+      if (tid == 0) { B.dbg[(size_t)w * 64 + 40] = ta; B.dbg[(size_t)w * 64 + 41] = tb; B.dbg[(size_t)w * 64 + 42] = tc; B.dbg[(size_t)w * 64 + 43] = td; }
 #endif
       __syncthreads();
       if (flag[0]) {   // LINEAR_SOLVER_FAILURE: raise mu and retry from the stored linearisation
