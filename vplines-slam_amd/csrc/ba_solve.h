@@ -831,7 +831,9 @@ static_assert(2 * CROWS * CW <= NAP, "the two staging buffers alias the reduced-
 // ---------------------------------------------------------------------------------------------------
 constexpr int COST_THREADS = 512;
 
-__global__ __launch_bounds__(COST_THREADS) void k_cost(DevBatch B) {
+// two workgroups per CU (4 waves per SIMD, <= 128 VGPRs): the kernel is a latency chain per lane, occupancy is what helps
+// (0.327 -> 0.283 ms per step against one workgroup per CU at 136 VGPRs)
+__global__ __launch_bounds__(COST_THREADS, 4) void k_cost(DevBatch B) {
   const int w = blockIdx.x, tid = threadIdx.x, T = COST_THREADS;
   TrState* tr = &B.tr[w];
   if (tr->status != 0 || !tr->step_valid) return;
