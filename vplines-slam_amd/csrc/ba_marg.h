@@ -144,7 +144,7 @@ __global__ __launch_bounds__(128) void k_gauge(DevBatch B) {
 // step) rides along: on exit c[k] = y_k for k < rank, where L(0:rank,0:rank) y = (P c)(0:rank).
 // Stops at the first pivot <= max(abs_tol, max(n eps, rel_tol) * max_i a_ii); the trailing block is then treated as zero.
 __device__ int psd_pivoted_cholesky(double* A, int n, int ld, int* perm, double* red, int* iflag, double rel_tol,
-                                    double abs_tol, double* c) {
+                                    double abs_tol, double* c, double* col /* n doubles of scratch */) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
   for (int i = tid; i < n; i += T) perm[i] = i;
   __syncthreads();
@@ -186,22 +186,28 @@ __device__ int psd_pivoted_cholesky(double* A, int n, int ld, int* perm, double*
     }
     const double lkk = sqrt(piv);
     const double inv = 1.0 / lkk;
-    // trailing update with the unscaled column, then scale the column
-    for (int it = tid; it < (n - k - 1) * (n - k - 1); it += T) {
-      const int i = k + 1 + it / (n - k - 1), j = k + 1 + it % (n - k - 1);
-      A[i * ld + j] -= A[i * ld + k] * A[j * ld + k] / piv;
-    }
-    if (c) {   // forward substitution rides along: c_i -= a_ik c_k / piv, then y_k = c_k / sqrt(piv)
-      const double ck = c[k];
-      for (int i = k + 1 + tid; i < n; i += T) c[i] -= A[i * ld + k] * ck / piv;
-    }
+    // The scaled column goes to a side vector first (one barrier); the trailing update reads only that vector, so the
+    // column of L, the zeros of row k and the rhs entry can be written in the same phase: two barriers per pivot step
+    // instead of three, and no division inside the update.
+    for (int i = k + tid; i < n; i += T) col[i] = (i == k) ? lkk : A[i * ld + k] * inv;
     __syncthreads();
-    if (c && tid == 0) c[k] *= inv;
+    const int m = n - k - 1;
+    for (int it = tid; it < m * m; it += T) {
+      const int ii = it / m, i = k + 1 + ii, j = k + 1 + (it - ii * m);
+      A[i * ld + j] -= col[i] * col[j];
+    }
     for (int i = k + tid; i < n; i += T) {
-      A[i * ld + k] = (i == k) ? lkk : A[i * ld + k] * inv;
-      if (i > k) A[k * ld + i] = 0.0;   // upper part of row k is not part of L
+      A[i * ld + k] = col[i];
+      if (i > k) A[k * ld + i] = 0.0;           // upper part of row k is not part of L
     }
-    __syncthreads();
+    if (c) {   // forward substitution rides along: y_k = c_k / l_kk, c_i -= l_ik y_k
+      const double yk = c[k] * inv;
+      for (int i = k + 1 + tid; i < n; i += T) c[i] -= col[i] * yk;
+      __syncthreads();                          // every thread has read c[k]
+      if (tid == 0) c[k] = yk;
+    } else {
+      __syncthreads();
+    }
   }
   __syncthreads();
   // columns rank..n-1 do not exist
@@ -213,7 +219,7 @@ __device__ int psd_pivoted_cholesky(double* A, int n, int ld, int* perm, double*
 __device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* lam, double* red, int* iflag,
                                    double rel_tol) {
   const int tid = threadIdx.x, T = blockDim.x;
-  const int rank = psd_pivoted_cholesky(A, n, ld, perm, red, iflag, rel_tol, 0.0, nullptr);
+  const int rank = psd_pivoted_cholesky(A, n, ld, perm, red, iflag, rel_tol, 0.0, nullptr, lam);
   // ---- one-sided Jacobi on the rank columns ----
   const int m = (rank + 1) & ~1, half = m / 2;
   const int P = tid >> 3, sub = tid & 7;
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   double* Y = tile;   // n x 16 scratch (tile is free now)
   for (int it = tid; it < md * md; it += T) Y[it] = E15[(it / md) * 17 + it % md];   // keep a copy for the fallback
   __syncthreads();
-  const int rank_mm = psd_pivoted_cholesky(E15, md, 17, perm, red, s_flag, 0.0, kMargEps, nullptr);
+  const int rank_mm = psd_pivoted_cholesky(E15, md, 17, perm, red, s_flag, 0.0, kMargEps, nullptr, lam);
   if (rank_mm == md) {
     VPL_STAMP(B, w, 34);
     for (int i = tid; i < n; i += T) {   // tmp(i, :) = Arm(i, :) Amm^-1 :  L L^T x = P a
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   // sign (it keeps the positive part above 1e-8 with a negligible weight).  Pivots below max(1e-8, 1e-9 max diagonal)
   // end the factorisation; the trailing block is treated as zero.
   VPL_STAMP(B, w, 35);
-  const int rank = psd_pivoted_cholesky(G, n, ldm, perm, red, s_flag, kMargNoiseRel, kMargEps, bv);
+  const int rank = psd_pivoted_cholesky(G, n, ldm, perm, red, s_flag, kMargNoiseRel, kMargEps, bv, lam);
   VPL_STAMP(B, w, 36);
   double* J0 = B.mg_J0 + (size_t)w * MAXKEEP * MAXKEEP;
   double* r0 = B.mg_r0 + (size_t)w * MAXKEEP;
