@@ -201,10 +201,14 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
     return VPL_E_HIP;
   }
   if (lin_smem(c->maxP, c->maxL) > 158 * 1024) { for (void* p : c->allocs) hipFree(p); delete c; return VPL_E_CAPACITY; }
-  hipFuncSetAttribute((const void*)k_lin<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxP, c->maxL));
-  hipFuncSetAttribute((const void*)k_lin<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxP, c->maxL));
-  hipFuncSetAttribute((const void*)k_lin<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_smem(c->maxP, c->maxL));
-  hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(c->maxP, c->maxL));
+  // the attribute is per kernel, not per context: never lower what a larger context of this process has asked for
+  static size_t lin_max = 0, solve_max = 0;
+  lin_max = std::max(lin_max, lin_smem(c->maxP, c->maxL));
+  solve_max = std::max(solve_max, solve_smem(c->maxP, c->maxL));
+  hipFuncSetAttribute((const void*)k_lin<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_max);
+  hipFuncSetAttribute((const void*)k_lin<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_max);
+  hipFuncSetAttribute((const void*)k_lin<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_max);
+  hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_max);
   hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SMEM);
   hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
   (void)hipGetLastError();

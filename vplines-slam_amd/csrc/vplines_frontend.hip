@@ -101,8 +101,11 @@ int vpl_fe_create(vpl_fe_ctx** out, int device, int max_images, int width, int h
   // k_ed_route keeps the frame's edge bitmap and one tile of routing codes in LDS
   c->routeSmem = (size_t)(((((size_t)width * height + 31) >> 5) + 3) & ~(size_t)3) * 4 + ED_TILE * ED_TILE * 2 + 64 * 4;
   if (e == hipSuccess && c->routeSmem > 159 * 1024) e = hipErrorInvalidValue;   // frames above ~1.2 Mpixel
-  if (e == hipSuccess && c->routeSmem > 48 * 1024)
+  static size_t route_max = 0;   // per kernel, not per context: never lowered by a later, smaller context
+  if (e == hipSuccess && c->routeSmem > 48 * 1024 && c->routeSmem > route_max) {
     e = hipFuncSetAttribute((const void*)k_ed_route, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->routeSmem);
+    if (e == hipSuccess) route_max = c->routeSmem;
+  }
   if (e != hipSuccess) {
     for (void* p : c->allocs) hipFree(p);
     delete c;
