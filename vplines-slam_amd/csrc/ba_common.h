@@ -101,4 +101,82 @@ __device__ __forceinline__ void prior_block_dx(int kind, const double* x, const 
   }
 }
 
+// cross-lane helpers of the register-resident diagonal-tile factorisation
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {   // srclane uniform (compile-time after unrolling)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+template <int J>
+__device__ __forceinline__ double swizzle_row_f64(double v) {   // value of lane (lane & 48) | J: DPP row_newbcast:J (gfx90a+),
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + J, 0xf, 0xf, false);   // VALU speed, no LDS path
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// one column step of the right-looking factorisation of the 16x16 diagonal tile held in registers.  The same row
+// operations are applied to an identity matrix m (same lane layout): after the 16 steps m = L~^-1 with L~ the unit lower
+// factor, so L^-1 = diag(1 / sqrt(pivot)) m comes out of the factorisation for the price of one more bpermute per step
+// (independent of the first) -- and the rows below the tile become a matrix product instead of 16-step substitutions.
+template <int J>
+__device__ __forceinline__ void diag_tile_step(double (&d)[4], double (&m)[4], int r4, int cc, int ncol, double& pivc, bool& bad) {
+  if (J < ncol && !bad) {
+    const double ajj = readlane_f64(d[J >> 2], ((J & 3) << 4) | J);
+    if (!(ajj > 0.0)) {
+      bad = true;
+    } else {
+      if (cc == J) pivc = ajj;
+      // 1 / a_JJ by v_rcp_f64 + two Newton steps (5 dependent instructions; an IEEE divide is ~10 on this chain).
+      // Measured alternatives, all slower on this lone wave: branch-free steps with the products formed ahead of the
+      // reciprocal, v_permlane swaps instead of ds_bpermute, a column-per-lane layout with v_readlane / DPP broadcasts.
+      double rinv = __builtin_amdgcn_rcp(ajj);
+      rinv = fma(rinv, fma(-ajj, rinv, 1.0), rinv);
+      rinv = fma(rinv, fma(-ajj, rinv, 1.0), rinv);
+      const double f = __shfl(d[J >> 2], ((J & 3) << 4) | cc, 64) * rinv;            // D[J][cc] / a_JJ
+      const double f2 = __shfl(m[J >> 2], ((J & 3) << 4) | cc, 64) * rinv;           // M[J][cc] / a_JJ
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double cv = swizzle_row_f64<J>(d[v]);                                 // D[r4 + 4v][J]
+        if (r4 + 4 * v > J) {
+          if (cc > J) d[v] -= cv * f;
+          m[v] -= cv * f2;
+        }
+      }
+    }
+  }
+}
+
+
+// Cholesky of a small SPD matrix (n <= 16, row-major, leading dimension ld, in LDS) by ONE wave with the register tile
+// algorithm above: A = L L^T.  Writes L (lower, zeros above the diagonal) back into A and, if Xinv != nullptr, L^-1 (lower)
+// into Xinv (same shape).  All 64 lanes of the wave must call it.  Returns false on a non-positive pivot.
+__device__ __forceinline__ bool wave_chol16(double* A, int n, int ld, double* Xinv, int lane) {
+  const int r4 = lane >> 4, cc = lane & 15;
+  double d[4], m[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int r = r4 + 4 * v;
+    d[v] = (r < n && cc < n) ? A[r * ld + cc] : (r == cc ? 1.0 : 0.0);     // identity padding
+    m[v] = r == cc ? 1.0 : 0.0;
+  }
+  double pivc = 1.0;
+  bool bad = false;
+#define VPL_DSTEP(J) diag_tile_step<J>(d, m, r4, cc, 16, pivc, bad);
+  VPL_DSTEP(0) VPL_DSTEP(1) VPL_DSTEP(2) VPL_DSTEP(3) VPL_DSTEP(4) VPL_DSTEP(5) VPL_DSTEP(6) VPL_DSTEP(7)
+  VPL_DSTEP(8) VPL_DSTEP(9) VPL_DSTEP(10) VPL_DSTEP(11) VPL_DSTEP(12) VPL_DSTEP(13) VPL_DSTEP(14) VPL_DSTEP(15)
+#undef VPL_DSTEP
+  if (bad) return false;
+  const double sq = sqrt(pivc), isq = 1.0 / sq;       // pivot of column cc
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int r = r4 + 4 * v;
+    const double ir = __shfl(isq, r, 64);             // 1 / sqrt(pivot of row r) sits in lane r
+    if (r < n && cc < n) {
+      A[r * ld + cc] = r > cc ? d[v] / sq : (r == cc ? sq : 0.0);
+      if (Xinv) Xinv[r * ld + cc] = r >= cc ? m[v] * ir : 0.0;
+    }
+  }
+  return true;
+}
+
 }  // namespace vpl

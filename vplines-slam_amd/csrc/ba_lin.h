@@ -14,50 +14,33 @@ typedef double v4d_lin __attribute__((ext_vector_type(4)));
 constexpr int LIN_THREADS = 512;
 constexpr int STG_LD = 21;                // row stride of the MFMA staging tiles (odd: the 16 writer lanes spread over the banks)
 constexpr int LIN_STAGE = 8 * 32 * STG_LD;   // MFMA staging of the point phase (doubles)
-constexpr int PREP_NMAX = 120;            // prior dims staged in LDS by k_prep (larger priors read HBM/L2)
-constexpr size_t PREP_SMEM = (size_t)(4 * 675 + PREP_NMAX * PREP_NMAX) * sizeof(double);
-
-// ---------------------------------------------------------------------------------------
-// wave-cooperative 15x15 helpers on LDS matrices (row-major, ld 15); one wave, no block barriers
-__device__ __forceinline__ void wave_chol15(double* A, int lane) {   // lower Cholesky in place
-  for (int j = 0; j < 15; ++j) {
-    double d = A[j * 15 + j];
-    for (int k = 0; k < j; ++k) d -= A[j * 15 + k] * A[j * 15 + k];
-    d = sqrt(d);
-    if (lane > j && lane < 15) {
-      double s2 = A[lane * 15 + j];
-      for (int k = 0; k < j; ++k) s2 -= A[lane * 15 + k] * A[j * 15 + k];
-      A[lane * 15 + j] = s2 / d;
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) A[j * 15 + j] = d;
-    __builtin_amdgcn_wave_barrier();
-  }
+constexpr int PREP_NMAX = 112;            // prior dims staged in LDS by k_prep (larger priors read HBM/L2); 10 x 675 + 112^2 doubles = 151 KB
+constexpr int PREP_THREADS = 640;         // ten waves: one IMU factor each, all ten in one round
+// per-wave scratch of the whitening (3 x 225) + the staged prior J0 of the batch's largest prior (capped at PREP_NMAX)
+inline size_t prep_smem(int max_prior_n) {
+  const int ns = max_prior_n < PREP_NMAX ? max_prior_n : PREP_NMAX;
+  return (size_t)((PREP_THREADS / 64) * 675 + ns * ns) * sizeof(double);
 }
+constexpr size_t PREP_SMEM = (size_t)((PREP_THREADS / 64) * 675 + PREP_NMAX * PREP_NMAX) * sizeof(double);
 
-__global__ __launch_bounds__(256) void k_prep(DevBatch B) {
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(DevBatch B, int nstage) {
   const int w = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
+  constexpr int NWV = PREP_THREADS / 64;
   extern __shared__ double psm[];
   double* wsc = psm + wv * 675;          // per-wave scratch: G (225) | X = G^-1 (225) | P = cov^-1 (225)
-  double* Jl = psm + 4 * 675;            // prior J0 staged (n * n)
+  double* Jl = psm + NWV * 675;          // prior J0 staged (n * n), room for nstage x nstage
   // (a) IMU: sqrt_info = LLT(cov^-1).matrixL().transpose()  (imu_factor.h:68).  cov is SPD: its inverse
   //     is formed from its Cholesky factor (cov = G G^T, cov^-1 = G^-T G^-1), then factored again.
-  for (int j = 1 + wv; j < NF; j += 4) {
+  for (int j = 1 + wv; j < NF; j += NWV) {
     DevPreint& P = B.pre[(size_t)w * NF + j];
     double* G = wsc;
     double* X = wsc + 225;
     double* Pm = wsc + 450;
     for (int k = lane; k < 225; k += 64) G[k] = P.cov[k];
     __builtin_amdgcn_wave_barrier();
-    wave_chol15(G, lane);
-    if (lane < 15) {   // column `lane` of X = G^-1 by forward substitution
-      for (int i = 0; i < 15; ++i) {
-        double s2 = (i == lane) ? 1.0 : 0.0;
-        for (int k = lane; k < i; ++k) s2 -= G[i * 15 + k] * X[k * 15 + lane];
-        X[i * 15 + lane] = i >= lane ? s2 / G[i * 15 + i] : 0.0;
-      }
-    }
+    // cov = G G^T and X = G^-1 in one pass: the register tile factorisation carries an identity along (ba_common.h)
+    wave_chol16(G, 15, 15, X, lane);
     __builtin_amdgcn_wave_barrier();
     for (int e = lane; e < 225; e += 64) {   // P = X^T X
       const int a = e / 15, b2 = e % 15;
@@ -66,7 +49,8 @@ __global__ __launch_bounds__(256) void k_prep(DevBatch B) {
       Pm[e] = s2;
     }
     __builtin_amdgcn_wave_barrier();
-    wave_chol15(Pm, lane);
+    wave_chol16(Pm, 15, 15, nullptr, lane);
+    __builtin_amdgcn_wave_barrier();
     for (int e = lane; e < 225; e += 64) {
       const int i = e / 15, jj = e % 15;
       P.sqrt_info[e] = (jj >= i) ? Pm[jj * 15 + i] : 0.0;   // L^T
@@ -106,7 +90,7 @@ __global__ __launch_bounds__(256) void k_prep(DevBatch B) {
   if (n > 0) {
     const double* J0 = B.pr_J0 + (size_t)w * MAXPN * MAXPN;
     double* H = B.pr_H + (size_t)w * MAXPN * MAXPN;
-    const bool fits = n <= PREP_NMAX;
+    const bool fits = n <= nstage;
     if (fits) {
       for (int idx = tid; idx < n * n; idx += blockDim.x) Jl[idx] = J0[idx];
       __syncthreads();

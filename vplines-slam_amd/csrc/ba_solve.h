@@ -65,51 +65,6 @@ __device__ __forceinline__ void chol4(double* A, bool& ok) {   // packed lower 4
   }
 }
 
-// cross-lane helpers of the register-resident diagonal-tile factorisation
-__device__ __forceinline__ double readlane_f64(double v, int srclane) {   // srclane uniform (compile-time after unrolling)
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-  return __hiloint2double(hi, lo);
-}
-template <int J>
-__device__ __forceinline__ double swizzle_row_f64(double v) {   // value of lane (lane & 48) | J: DPP row_newbcast:J (gfx90a+),
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + J, 0xf, 0xf, false);   // VALU speed, no LDS path
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + J, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-
-// one column step of the right-looking factorisation of the 16x16 diagonal tile held in registers.  The same row
-// operations are applied to an identity matrix m (same lane layout): after the 16 steps m = L~^-1 with L~ the unit lower
-// factor, so L^-1 = diag(1 / sqrt(pivot)) m comes out of the factorisation for the price of one more bpermute per step
-// (independent of the first) -- and the rows below the tile become a matrix product instead of 16-step substitutions.
-template <int J>
-__device__ __forceinline__ void diag_tile_step(double (&d)[4], double (&m)[4], int r4, int cc, int ncol, double& pivc, bool& bad) {
-  if (J < ncol && !bad) {
-    const double ajj = readlane_f64(d[J >> 2], ((J & 3) << 4) | J);
-    if (!(ajj > 0.0)) {
-      bad = true;
-    } else {
-      if (cc == J) pivc = ajj;
-      // 1 / a_JJ by v_rcp_f64 + two Newton steps (5 dependent instructions; an IEEE divide is ~10 on this chain).
-      // Measured alternatives, all slower on this lone wave: branch-free steps with the products formed ahead of the
-      // reciprocal, v_permlane swaps instead of ds_bpermute, a column-per-lane layout with v_readlane / DPP broadcasts.
-      double rinv = __builtin_amdgcn_rcp(ajj);
-      rinv = fma(rinv, fma(-ajj, rinv, 1.0), rinv);
-      rinv = fma(rinv, fma(-ajj, rinv, 1.0), rinv);
-      const double f = __shfl(d[J >> 2], ((J & 3) << 4) | cc, 64) * rinv;            // D[J][cc] / a_JJ
-      const double f2 = __shfl(m[J >> 2], ((J & 3) << 4) | cc, 64) * rinv;           // M[J][cc] / a_JJ
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const double cv = swizzle_row_f64<J>(d[v]);                                 // D[r4 + 4v][J]
-        if (r4 + 4 * v > J) {
-          if (cc > J) d[v] -= cv * f;
-          m[v] -= cv * f2;
-        }
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
   const int w = blockIdx.x, tid = threadIdx.x, T = SOLVE_THREADS;
   const int lane = tid & 63, wv = tid >> 6;

@@ -42,6 +42,7 @@ struct vpl_ctx {
   std::vector<int> h_nP, h_nL;
   std::vector<std::vector<int>> h_lmap;          // per window: device line index -> index in the vpl_window arrays
   size_t marg_smem = 0;
+  int maxPriorN = 0;                             // largest prior of the uploaded batch (k_prep stages J0 in LDS)
 };
 
 static int fail(vpl_ctx* c, int code, const std::string& msg) {
@@ -400,6 +401,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   std::vector<int> mg_n(W, 0), mg_nb(W, 0), mg_kind(W * MAXPB, 0), mg_frame(W * MAXPB, 0), mg_idx(W * MAXPB, 0),
       mg_cam(W * MAXPB, 0);
   c->h_mg_m.assign(W, 0);
+  c->maxPriorN = 0;
   c->h_passthrough.assign(W, -1);
   c->h_pass_priors.clear();
   c->any_second_new = false;
@@ -491,6 +493,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       const vpl_prior& pr = *v.prior;
       if (pr.n < 0 || pr.n > MAXPN || pr.n_blocks < 0 || pr.n_blocks > MAXPB) return fail(c, VPL_E_INVALID, "bad prior");
       pr_n[w] = pr.n; pr_nb[w] = pr.n_blocks;
+      c->maxPriorN = std::max(c->maxPriorN, pr.n);
       for (int b = 0; b < pr.n_blocks; ++b) {
         pr_kind[w * MAXPB + b] = pr.block_kind[b];
         pr_frame[w * MAXPB + b] = pr.block_frame[b];
@@ -740,7 +743,7 @@ int vpl_ba_only_line_opt(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_optio
   DevBatch& B = c->B;
   const dim3 grid(nW);
   hipStream_t s = c->stream;
-  { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(256), PREP_SMEM, s, B); }
+  { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(PREP_THREADS), prep_smem(c->maxPriorN), s, B, std::min(c->maxPriorN, PREP_NMAX)); }
   { KTimer t(c, "k_line_opt"); hipLaunchKernelGGL(k_line_opt, grid, dim3(LOPT_THREADS), 0, s, B); }
   { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
   HIPCHK(c, hipGetLastError());
@@ -782,7 +785,7 @@ int vpl_ba_solve(vpl_ctx* c) {
   DevBatch& B = c->B;
   const dim3 grid(c->nW);
   hipStream_t s = c->stream;
-  { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(256), PREP_SMEM, s, B); }
+  { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(PREP_THREADS), prep_smem(c->maxPriorN), s, B, std::min(c->maxPriorN, PREP_NMAX)); }
   { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
   for (int it = 0; it < c->opt.num_iterations; ++it) {
     { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), solve_smem(B.maxP, B.maxL), s, B); }
