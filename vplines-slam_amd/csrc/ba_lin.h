@@ -102,6 +102,13 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(DevBatch B, int nstage) {
       for (int k = 0; k < n; ++k) s += Js[(size_t)k * n + a] * Js[(size_t)k * n + b];
       H[idx] = s;
     }
+    // g0 = J0^T r0: with H it turns the gradient of the prior, J0^T (r0 + J0 dx), into g0 + H dx -- a mat-vec that does not
+    // wait for the residual
+    for (int c2 = tid; c2 < n; c2 += blockDim.x) {
+      double s = 0;
+      for (int k = 0; k < n; ++k) s += Js[(size_t)k * n + c2] * B.pr_r0[(size_t)w * MAXPN + k];
+      B.pr_g0[(size_t)w * MAXPN + c2] = s;
+    }
     if (tid < B.pr_nb[w]) {
       int kind = B.pr_kind[(size_t)w * MAXPB + tid], fr = B.pr_frame[(size_t)w * MAXPB + tid];
       int idx = B.pr_idx[(size_t)w * MAXPB + tid];
@@ -200,25 +207,27 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     for (int i = tid; i < n; i += T) invmap[B.pr_map[(size_t)w * MAXPN + i]] = i;
     __syncthreads();
     const double* J0 = B.pr_J0 + (size_t)w * MAXPN * MAXPN;
-    // r = r0 + J0 dx: eight lanes per row (coalesced along the row), g = J0^T r: one lane per column, loads unrolled
+    // r = r0 + J0 dx and g = J0^T r = g0 + H dx (H = J0^T J0, g0 = J0^T r0 from k_prep) in ONE pass: eight lanes per row,
+    // both rows' loads in flight together -- the second mat-vec used to start after the first (and a barrier) and paid
+    // the global latency of its column reads all over again
+    const double* Hp = B.pr_H + (size_t)w * MAXPN * MAXPN;
     for (int r = tid >> 3; r < n; r += T >> 3) {
       const int sub = tid & 7;
-      double s = 0;
+      double s = 0, sg = 0;
 #pragma unroll 4
-      for (int c = sub; c < n; c += 8) s += J0[(size_t)r * n + c] * prdx[c];
+      for (int c = sub; c < n; c += 8) {
+        const double dxc = prdx[c];
+        s += J0[(size_t)r * n + c] * dxc;
+        sg += Hp[(size_t)r * n + c] * dxc;
+      }
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      sg += __shfl_xor(sg, 1, 64); sg += __shfl_xor(sg, 2, 64); sg += __shfl_xor(sg, 4, 64);
       if (sub == 0) {
         s += B.pr_r0[(size_t)w * MAXPN + r];
         prr[r] = s;
+        prg[r] = sg + B.pr_g0[(size_t)w * MAXPN + r];
         cost += 0.5 * s * s;
       }
-    }
-    __syncthreads();
-    for (int c = tid; c < n; c += T) {
-      double s = 0;
-#pragma unroll 8
-      for (int r = 0; r < n; ++r) s += J0[(size_t)r * n + c] * prr[r];
-      prg[c] = s;
     }
   }
 

@@ -90,6 +90,7 @@ struct DevBatch {
   double *pr_x0;                                 // [W][23][9]
   double *pr_J0, *pr_r0;                         // [W][171*171] [W][171]
   double *pr_H;                                  // [W][171*171]  J0^T J0 (prior-local indexing)
+  double *pr_g0;                                 // [W][171]      J0^T r0
   int *pr_map;                                   // [W][171] prior-local column -> cam index
 
   // ---- linearisation (one buffer set; written by k_lin at the current x) ----

@@ -186,7 +186,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(nLO, W); AL(lo_ln, W * B.maxLO);
   AL(pre, W * NF);
   AL(pr_n, W); AL(pr_nb, W); AL(pr_kind, W * MAXPB); AL(pr_frame, W * MAXPB); AL(pr_idx, W * MAXPB);
-  AL(pr_x0, W * MAXPB * 9); AL(pr_J0, W * MAXPN * MAXPN); AL(pr_r0, W * MAXPN); AL(pr_H, W * MAXPN * MAXPN);
+  AL(pr_x0, W * MAXPB * 9); AL(pr_J0, W * MAXPN * MAXPN); AL(pr_r0, W * MAXPN); AL(pr_H, W * MAXPN * MAXPN); AL(pr_g0, W * MAXPN);
   AL(pr_map, W * MAXPN);
   AL(Hcc, W * NCP); AL(gc, W * NC); AL(Hpp, W * B.maxP); AL(gp, W * B.maxP); AL(Wp, W * B.maxP * NV);
   AL(Hll, W * B.maxL * 16); AL(gl, W * B.maxL * 4); AL(Wl, W * B.maxL * 4 * NV); AL(lchol, W * B.maxL * 10);
