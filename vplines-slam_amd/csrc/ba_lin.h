@@ -23,11 +23,12 @@ inline size_t prep_smem(int max_prior_n) {
 }
 constexpr size_t PREP_SMEM = (size_t)((PREP_THREADS / 64) * 675 + PREP_NMAX * PREP_NMAX) * sizeof(double);
 
-__global__ __launch_bounds__(PREP_THREADS) void k_prep(DevBatch B, int nstage) {
-  const int w = blockIdx.x, tid = threadIdx.x;
+// Every kernel of the solve is a `*_body` device function of (batch, window, dynamic LDS) plus a thin __global__ wrapper:
+// the bodies are also called back to back by the one-kernel-per-solve k_window (ba_window.h).
+__device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double* psm, int nstage) {
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
-  constexpr int NWV = PREP_THREADS / 64;
-  extern __shared__ double psm[];
+  const int NWV = blockDim.x >> 6;       // 10 waves stand-alone (one IMU factor each), 8 inside k_window
   double* wsc = psm + wv * 675;          // per-wave scratch: G (225) | X = G^-1 (225) | P = cov^-1 (225)
   double* Jl = psm + NWV * 675;          // prior J0 staged (n * n), room for nstage x nstage
   // (a) IMU: sqrt_info = LLT(cov^-1).matrixL().transpose()  (imu_factor.h:68).  cov is SPD: its inverse
@@ -127,6 +128,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(DevBatch B, int nstage) {
     B.tr[w] = t;
   }
 }
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(DevBatch B, int nstage) {
+  extern __shared__ double psm[];
+  prep_body(B, blockIdx.x + B.w0, psm, nstage);
+}
 
 // ---------------------------------------------------------------------------------------
 // helpers accumulating J_a^T J_b (2 residual rows, 6-wide blocks) into the LDS vis Hessian
@@ -151,16 +156,15 @@ __device__ __forceinline__ void acc_g(double* gv, int ba, const double* Ja, cons
 // MODE 0: solve linearisation; 1: MARGIN_OLD assembly (prior + IMU(0,1) + landmarks that start in frame 0);
 // 2: MARGIN_SECOND_NEW assembly (the prior alone, estimator.cpp:1387-1405)
 template <int MODE>
-__global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
+__device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double* sm) {
   constexpr bool MARG = MODE != 0;
   constexpr bool PRIOR_ONLY = MODE == 2;
-  const int w = blockIdx.x, tid = threadIdx.x, T = LIN_THREADS;
+  const int tid = threadIdx.x, T = LIN_THREADS;
   TrState* tr = &B.tr[w];
   if (!MARG) {
     if (tr->status != 0 || tr->fresh_lin) return;
   }
   if (PRIOR_ONLY && B.mg_n[w] == 0) return;
-  extern __shared__ double sm[];
   double* Hv = sm;                 // NV*NV, lower triangle used
   double* gv = Hv + NV * NV;       // NV
   double* xp = gv + NV;            // 12*7 poses + ex
@@ -642,6 +646,11 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
     if (tr->iter == 0) tr->initial_cost = cost;
     tr->fresh_lin = 1;
   }
+}
+template <int MODE>
+__global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
+  extern __shared__ double sm[];
+  lin_body<MODE>(B, blockIdx.x + B.w0, sm);
 }
 
 inline size_t lin_smem(int maxP, int maxL) {

@@ -9,8 +9,8 @@
 
 namespace vpl {
 
-__global__ __launch_bounds__(128) void k_gauge(DevBatch B) {
-  const int w = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void gauge_body(const DevBatch& B, const int w) {
+  const int tid = threadIdx.x;
   __shared__ double rd[9], p0a[3], p0b[3], newpose[NF * 7], newex[7];
   const double* gz = B.gauge + (size_t)w * 4;
   double* pose = B.pose + (size_t)w * 77;
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(128) void k_gauge(DevBatch B) {
                     B.mg_cam + (size_t)w * MAXPB, B.mg_n + w, B.mg_nb + w, B.mg_m + w);
   }
 }
+__global__ __launch_bounds__(128) void k_gauge(DevBatch B) { gauge_body(B, blockIdx.x + B.w0); }
 
 // ---------------------------------------------------------------------------------------------------
 // Spectral factor of a symmetric positive semi-definite matrix held in LDS (full storage, row stride ld):
@@ -298,9 +299,8 @@ __host__ __device__ inline MargLayout marg_layout(int n) {
   return L;
 }
 
-__global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
-  const int w = blockIdx.x, tid = threadIdx.x, T = MARG_THREADS;
-  extern __shared__ double sm[];
+__device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double* sm) {
+  const int tid = threadIdx.x, T = MARG_THREADS;
   const int nP = B.nP[w], nL = B.nL[w];
   const int nb = B.mg_nb[w];
   const int n = B.mg_n[w];
@@ -546,6 +546,10 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
     for (int k = 0; k < 9; ++k) B.mg_x0[((size_t)w * MAXPB + tid) * 9 + k] = k < gs ? x[k] : 0.0;
   }
   VPL_STAMP(B, w, 37);
+}
+__global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
+  extern __shared__ double sm[];
+  marg_body(B, blockIdx.x + B.w0, sm);
 }
 
 }  // namespace vpl

@@ -65,12 +65,11 @@ __device__ __forceinline__ void chol4(double* A, bool& ok) {   // packed lower 4
   }
 }
 
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
-  const int w = blockIdx.x, tid = threadIdx.x, T = SOLVE_THREADS;
+__device__ __forceinline__ void solve_body(const DevBatch& B, const int w, double* sm) {
+  const int tid = threadIdx.x, T = SOLVE_THREADS;
   const int lane = tid & 63, wv = tid >> 6;
   TrState* tr = &B.tr[w];
   if (tr->status != 0) return;
-  extern __shared__ double sm[];
   double* S = sm;                 // NAP tile-major lower (row NC = rhs); first used as 2 staging buffers
   double* sc = S + NAP;           // 176 jacobi scale of cam dims
   double* dg = sc + 176;          // 176 dogleg diagonal of cam dims
@@ -778,6 +777,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
     tr->num_invalid = 0;
   }
 }
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
+  extern __shared__ double sm[];
+  solve_body(B, blockIdx.x + B.w0, sm);
+}
 
 constexpr size_t SOLVE_SMEM = (size_t)(NAP + 5 * 176 + 256 + 24) * sizeof(double) + 4 * sizeof(int);   // + (maxP + maxL) ints, see solve_smem
 inline size_t solve_smem(int maxP, int maxL) { return SOLVE_SMEM + (size_t)(maxP + maxL) * sizeof(int); }
@@ -788,8 +791,8 @@ constexpr int COST_THREADS = 512;
 
 // two workgroups per CU (4 waves per SIMD, <= 128 VGPRs): the kernel is a latency chain per lane, occupancy is what helps
 // (0.327 -> 0.283 ms per step against one workgroup per CU at 136 VGPRs)
-__global__ __launch_bounds__(COST_THREADS, 4) void k_cost(DevBatch B) {
-  const int w = blockIdx.x, tid = threadIdx.x, T = COST_THREADS;
+__device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
+  const int tid = threadIdx.x, T = COST_THREADS;
   TrState* tr = &B.tr[w];
   if (tr->status != 0 || !tr->step_valid) return;
   __shared__ double xp[84], xs[99], prdx[MAXPN], red[20];
@@ -920,5 +923,8 @@ __global__ __launch_bounds__(COST_THREADS, 4) void k_cost(DevBatch B) {
     for (int i = tid; i < 4 * nL; i += T) B.orth[(size_t)w * B.maxL * 4 + i] = B.orth_c[(size_t)w * B.maxL * 4 + i];
   }
 }
+// two workgroups per CU (4 waves per SIMD, <= 128 VGPRs): the kernel is a latency chain per lane, occupancy is what helps
+// (0.327 -> 0.283 ms per step against one workgroup per CU at 136 VGPRs)
+__global__ __launch_bounds__(COST_THREADS, 4) void k_cost(DevBatch B) { cost_body(B, blockIdx.x + B.w0); }
 
 }  // namespace vpl

@@ -101,6 +101,7 @@ struct DevBatch {
   // extrinsic columns: WS = 6 * maxTrack + 6 doubles (42 for 6-frame tracks, 72 = NV at most).  wfill: rows have slots no
   // factor writes (shorter tracks, erased lines) and must be zeroed before the factors are accumulated.
   int WS, wfill;
+  int w0;                                        // first window of this launch (the solve is launched per window group)
   double *lchol;                                 // [W][maxL][10] Cholesky factors of the regularised line blocks
 
   // ---- trust region vectors over the full index ----

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -17,6 +18,7 @@
 #include "ba_lin.h"
 #include "ba_solve.h"
 #include "ba_marg.h"
+#include "ba_window.h"
 #include "ba_lineopt.h"
 #include "ba_factors.h"
 
@@ -43,6 +45,13 @@ struct vpl_ctx {
   std::vector<std::vector<int>> h_lmap;          // per window: device line index -> index in the vpl_window arrays
   size_t marg_smem = 0;
   int maxPriorN = 0;                             // largest prior of the uploaded batch (k_prep stages J0 in LDS)
+  int groups = 1;                                // window groups of the kernel-per-phase path (VPL_BA_GROUPS, experiments)
+  bool fused = false;                            // one k_window launch per solve: measured slower (see ba_window.h); VPL_BA_FUSED=1 enables it
+  DevBatch hB;                                   // host copy of the descriptor of the running k_window launch
+  int slot = -1;                                 // this context's entry of c_window_batch (-1: none left, no k_window)
+  std::vector<hipStream_t> gstreams;
+  std::vector<hipEvent_t> gevents;
+  hipEvent_t fork_ev = nullptr;
 };
 
 static int fail(vpl_ctx* c, int code, const std::string& msg) {
@@ -214,6 +223,12 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
   (void)hipGetLastError();
   vpl_ba_default_options(&c->opt);
+  if (const char* gv = std::getenv("VPL_BA_GROUPS")) c->groups = std::max(1, std::atoi(gv));
+  if (const char* fv = std::getenv("VPL_BA_FUSED")) c->fused = std::atoi(fv) != 0;
+  {
+    static int next_slot = 0;                    // contexts beyond WINDOW_SLOTS use the kernel-per-phase path
+    c->slot = next_slot < WINDOW_SLOTS ? next_slot++ : -1;
+  }
   *out = c;
   return VPL_OK;
 }
@@ -223,6 +238,9 @@ void vpl_ctx_destroy(vpl_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (void* p : c->allocs) hipFree(p);
+  for (hipStream_t st : c->gstreams) hipStreamDestroy(st);
+  for (hipEvent_t ev : c->gevents) hipEventDestroy(ev);
+  if (c->fork_ev) hipEventDestroy(c->fork_ev);
   delete c;
 }
 
@@ -779,12 +797,11 @@ int vpl_ba_only_line_opt(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_optio
   return VPL_OK;
 }
 
-int vpl_ba_solve(vpl_ctx* c) {
-  if (!c || c->nW < 1) return VPL_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->device));
-  DevBatch& B = c->B;
-  const dim3 grid(c->nW);
-  hipStream_t s = c->stream;
+// The whole solve of the windows [w0, w0 + nw) on stream s
+static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
+  DevBatch B = c->B;
+  B.w0 = w0;
+  const dim3 grid(nw);
   { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(PREP_THREADS), prep_smem(c->maxPriorN), s, B, std::min(c->maxPriorN, PREP_NMAX)); }
   { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
   for (int it = 0; it < c->opt.num_iterations; ++it) {
@@ -802,6 +819,59 @@ int vpl_ba_solve(vpl_ctx* c) {
   } else if (c->any_second_new) {
     { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<2>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
     { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
+  }
+}
+
+// vpl_ba_solve: the kernel-per-phase sequence over the whole batch.  Two alternatives are kept behind environment switches
+// because they were measured and lost: VPL_BA_FUSED=1 runs the solve as one k_window launch
+// (ba_window.h; 138 k against 150 k solves/s), VPL_BA_GROUPS=n cuts the batch into n window groups on streams of their own
+// (the group kernels do not overlap on this GPU: 4 groups cost 30 %).
+int vpl_ba_solve(vpl_ctx* c) {
+  if (!c || c->nW < 1) return VPL_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int nstage = std::min(c->maxPriorN, PREP_NMAX);
+  const size_t prep8 = (size_t)((WINDOW_THREADS / 64) * 675 + nstage * nstage) * sizeof(double);
+  const size_t dyn = std::max(std::max(prep8, lin_smem(c->maxP, c->maxL)), std::max(solve_smem(c->maxP, c->maxL), c->marg_smem));
+  const bool fused = c->fused && c->slot >= 0 && !c->timing && dyn + WINDOW_STATIC_LDS <= 160 * 1024;
+  if (fused) {
+    static size_t window_max = 0;
+    if (dyn > window_max) {
+      HIPCHK(c, hipFuncSetAttribute((const void*)k_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+      window_max = dyn;
+    }
+    const int mode = c->opt.marginalization_flag == VPL_MARGIN_OLD ? 1 : c->any_second_new ? 2 : 0;
+    c->hB = c->B;
+    c->hB.w0 = 0;
+    HIPCHK(c, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_window_batch), &c->hB, sizeof(DevBatch), (size_t)c->slot * sizeof(DevBatch),
+                                     hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_window, dim3(c->nW), dim3(WINDOW_THREADS), dyn, c->stream, c->slot, nstage, c->opt.num_iterations, mode);
+    HIPCHK(c, hipGetLastError());
+    return VPL_OK;
+  }
+  const int G = c->timing ? 1 : std::min(c->groups, std::max(1, c->nW / 32));
+  if (G <= 1) {
+    launch_solve(c, 0, c->nW, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return VPL_OK;
+  }
+  while ((int)c->gstreams.size() < G) {
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->gstreams.push_back(st);
+    c->gevents.push_back(ev);
+  }
+  if (!c->fork_ev) HIPCHK(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->fork_ev, c->stream));
+  const int per = (c->nW + G - 1) / G;
+  for (int g = 0; g < G; ++g) {
+    const int w0 = g * per, nw = std::min(per, c->nW - w0);
+    if (nw <= 0) break;
+    HIPCHK(c, hipStreamWaitEvent(c->gstreams[g], c->fork_ev, 0));
+    launch_solve(c, w0, nw, c->gstreams[g]);
+    HIPCHK(c, hipEventRecord(c->gevents[g], c->gstreams[g]));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->gevents[g], 0));
   }
   HIPCHK(c, hipGetLastError());
   return VPL_OK;
