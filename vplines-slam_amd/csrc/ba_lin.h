@@ -560,54 +560,84 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   // ---- assemble the packed cam Hessian and gradient in HBM -----------------------------------
   double* Hout = B.Hcc + (size_t)w * NCP;
   const double* pH = B.pr_H + (size_t)w * MAXPN * MAXPN;
-  for (int base = 0; base < NCP; base += 8 * T) {   // the prior's share first (8 global loads in flight), then the rest
-    double ph[8];
-    int rr[8], cc[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * T + tid;
-      ph[u] = 0.0;
-      rr[u] = 0; cc[u] = 0;
-      if (idx < NCP) {
-        tri_decode(idx, rr[u], cc[u]);
-        if (n > 0) {
-          const int pr = invmap[rr[u]], pc = invmap[cc[u]];
-          if (pr >= 0 && pc >= 0) ph[u] = pH[(size_t)pr * n + pc];
+  // Three passes over the packed lower triangle instead of one that decodes every index and asks every entry for all
+  // three sources: (A) rows to waves, columns to lanes -- the visual block, coalesced stores, no index decoding;
+  // (B) the 3570 entries the IMU factors touch (11 diagonal 15x15 blocks, 10 sub-diagonal ones), each summing its one or
+  // two J^T J terms; (C) the n (n + 1) / 2 entries of the prior, all of its loads in one batch.  (B) and (C) add to what
+  // (A) stored: same workgroup, a barrier in between.
+  {
+    const int lane2 = tid & 63, wv2 = tid >> 6;
+    for (int r = wv2; r < NC; r += T >> 6) {
+      const int vr = cam2vis(r);
+      const bool dead = !ex_free && r >= 165;
+      double* row = Hout + (size_t)r * (r + 1) / 2;
+      for (int c = lane2; c <= r; c += 64) {
+        double v = 0.0;
+        if (vr >= 0 && !dead) {
+          const int vc = cam2vis(c);
+          if (vc >= 0) v = Hv[vr * NV + vc];
         }
+        row[c] = v;
       }
     }
+  }
+  __syncthreads();
+  for (int item = tid; item < 11 * 120 + 10 * 225; item += T) {
+    int fr, a, b;   // entry (15 fr + a, 15 fc + b)
+    bool diag;
+    if (item < 11 * 120) {
+      fr = item / 120;
+      tri_decode(item - 120 * fr, a, b);
+      diag = true;
+    } else {
+      const int e = item - 11 * 120;
+      fr = 1 + e / 225;
+      const int q = e - 225 * (fr - 1);
+      a = q / 15; b = q - 15 * a;
+      diag = false;
+    }
+    double v = 0.0;
+    const int t0 = fr - 1;
+    if (t0 >= 0 && imuact[t0]) {           // factor (fr-1, fr): rows 15..29 of its 30 columns are frame fr
+      const double* J = imuJ + 450 * t0;
+      const int ja = 15 + a, jb = diag ? 15 + b : b;
+      double s2 = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * T + tid;
-      if (idx >= NCP) continue;
-      const int r = rr[u], c = cc[u];
-      double v = ph[u];
-      const int vr = cam2vis(r), vc = cam2vis(c);
-      if (vr >= 0 && vc >= 0) v += Hv[vr * NV + vc];
-      if (r < 165) {
-        const int fr = r / 15, fc = c / 15;
-        if (fc == fr || fc == fr - 1) {
-          const int t0 = fr - 1;
-          if (t0 >= 0 && imuact[t0]) {
-            const double* J = imuJ + 450 * t0;
-            const int a = r - 15 * t0, b = c - 15 * t0;
-            double s = 0;
+      for (int k = 0; k < 15; ++k) s2 += J[k * 30 + ja] * J[k * 30 + jb];
+      v += s2;
+    }
+    if (diag && fr < 10 && imuact[fr]) {   // factor (fr, fr+1): columns 0..14 are frame fr
+      const double* J = imuJ + 450 * fr;
+      double s2 = 0;
 #pragma unroll
-            for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b];
-            v += s;
-          }
-          if (fc == fr && fr < 10 && imuact[fr]) {
-            const double* J = imuJ + 450 * fr;
-            const int a = r - 15 * fr, b = c - 15 * fr;
-            double s = 0;
+      for (int k = 0; k < 15; ++k) s2 += J[k * 30 + a] * J[k * 30 + b];
+      v += s2;
+    }
+    const int r = 15 * fr + a, c = diag ? 15 * fr + b : 15 * (fr - 1) + b;
+    if (v != 0.0) Hout[(size_t)r * (r + 1) / 2 + c] += v;
+  }
+  if (n > 0) {
+    const int np = n * (n + 1) / 2;
+    for (int base = 0; base < np; base += 4 * T) {
+      double ph[4];
+      int tr_[4], tc_[4];
 #pragma unroll
-            for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b];
-            v += s;
-          }
+      for (int u = 0; u < 4; ++u) {
+        const int e = base + u * T + tid;
+        ph[u] = 0.0; tr_[u] = -1; tc_[u] = 0;
+        if (e < np) {
+          int i, j;
+          tri_decode(e, i, j);
+          ph[u] = pH[(size_t)i * n + j];
+          const int ri = B.pr_map[(size_t)w * MAXPN + i], rj = B.pr_map[(size_t)w * MAXPN + j];
+          tr_[u] = ri > rj ? ri : rj;
+          tc_[u] = ri > rj ? rj : ri;
         }
       }
-      if (!ex_free && r >= 165) v = 0.0;
-      Hout[idx] = v;
+      __syncthreads();   // (uniform trip count) the IMU pass has finished with the entries the prior shares
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (tr_[u] >= 0 && (ex_free || tr_[u] < 165)) Hout[(size_t)tr_[u] * (tr_[u] + 1) / 2 + tc_[u]] += ph[u];
     }
   }
   for (int r = tid; r < NC; r += T) {
