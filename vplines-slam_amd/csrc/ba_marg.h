@@ -359,13 +359,36 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   const double* gc = B.gc + (size_t)w * NC;
   // ---- landmark elimination (plain inverse of the block-diagonal landmark part, :316-326) --------
   // rows X = C^-1 [W | g] per start-frame-0 landmark (C C^T = H_ll); A = Hcc - X^T X, b = gc - X^T z
-  for (int it = tid; it < nd * nd; it += T) {
-    const int i = it / nd, j = it % nd;
-    const int ci = dmap[i], cj = dmap[j];
-    Ad[i * ldd + j] = ci >= cj ? Hcc[tri(ci, cj)] : Hcc[tri(cj, ci)];
+  for (int base = 0; base < nd * nd; base += 8 * T) {   // eight global loads in flight per lane, then the LDS stores
+    double hv[8];
+    int dst[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int it = base + u * T + tid;
+      dst[u] = -1;
+      hv[u] = 0.0;
+      if (it < nd * nd) {
+        const int i = it / nd, j = it - i * nd;
+        const int ci = dmap[i], cj = dmap[j];
+        dst[u] = i * ldd + j;
+        hv[u] = ci >= cj ? Hcc[tri(ci, cj)] : Hcc[tri(cj, ci)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (dst[u] >= 0) Ad[dst[u]] = hv[u];
   }
   for (int i = tid; i < nd; i += T) bv[i] = gc[dmap[i]];
+  // list of the dense dims with a visual index (tmp is free until the Schur complement of the marginalised block)
+  int* vlist = (int*)tmp;
+  if (tid == 0) {
+    int k = 0;
+    for (int i = 0; i < nd; ++i)
+      if (cam2vis(dmap[i]) >= 0) vlist[k++] = i;
+    s_flag[2] = k;
+  }
   __syncthreads();
+  const int nv = s_flag[2];
   const int np0 = s_np0, nl0 = s_nl0;
   for (int base = 0; base < np0 + nl0; ) {
     int nrows;
@@ -415,14 +438,14 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
       base += cnt;
     }
     __syncthreads();
-    for (int it = tid; it < nd * nd; it += T) {
-      const int i = it / nd, j = it % nd;
+    // only the dense dims that are visual (pose / extrinsic) dims couple to the landmarks: nv x nv entries, not nd x nd
+    for (int it = tid; it < nv * nv; it += T) {
+      const int a = it / nv, b2 = it - a * nv;
+      const int i = vlist[a], j = vlist[b2];
       const int vi = cam2vis(dmap[i]), vj = cam2vis(dmap[j]);
-      if (vi >= 0 && vj >= 0) {
-        double s = 0.0;
-        for (int r = 0; r < nrows; ++r) s += tile[r * 74 + vi] * tile[r * 74 + vj];
-        Ad[i * ldd + j] -= s;
-      }
+      double s = 0.0;
+      for (int r = 0; r < nrows; ++r) s += tile[r * 74 + vi] * tile[r * 74 + vj];
+      Ad[i * ldd + j] -= s;
     }
     for (int i = tid; i < nd; i += T) {
       const int vi = cam2vis(dmap[i]);
