@@ -392,27 +392,57 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   const int np0 = s_np0, nl0 = s_nl0;
   for (int base = 0; base < np0 + nl0; ) {
     int nrows;
+    // Per-row constants first (one lane per landmark: its scale or 4x4 factor, its start frame), then the elements with
+    // one global load each, four in flight per lane.  Loading them per element put two dependent global latencies into
+    // every trip of the element loop and repeated the 4x4 Cholesky of a line 73 times.
+    double* rs = tmp + 128;              // MTROWS point scales
+    double* lineC = tmp + 160;           // (MTROWS / 4) x 10 line factors
+    int* rstart = (int*)(tmp + 240);     // MTROWS start frames
+    int* rland = rstart + MTROWS;        // MTROWS landmark indices
     if (base < np0) {
       const int cnt = min(MTROWS, np0 - base);
       nrows = cnt;
-      for (int it = tid; it < cnt * 73; it += T) {
-        const int rr = it / 73, c = it % 73;
-        const size_t pi = (size_t)w * B.maxP + lst[base + rr];
+      if (tid < cnt) {
+        const int p = lst[base + tid];
+        const size_t pi = (size_t)w * B.maxP + p;
         const double hpp = B.Hpp[pi];
-        const double isq = hpp != 0.0 ? 1.0 / sqrt(hpp) : 0.0;
-        const int cc = c < NV ? wcol(c, B.pt_start[pi], B.WS) : 0;
-        tile[rr * 74 + c] = cc < 0 ? 0.0 : isq * (c < NV ? B.Wp[pi * B.WS + cc] : B.gp[pi]);
+        rs[tid] = hpp != 0.0 ? 1.0 / sqrt(hpp) : 0.0;
+        rstart[tid] = B.pt_start[pi];
+        rland[tid] = p;
+      }
+      __syncthreads();
+      for (int it0 = tid; it0 < cnt * 73; it0 += 4 * T) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int it = it0 + u * T;
+          v[u] = 0.0;
+          if (it < cnt * 73) {
+            const int rr = it / 73, c = it - rr * 73;
+            const size_t pi = (size_t)w * B.maxP + rland[rr];
+            const int cc = c < NV ? wcol(c, rstart[rr], B.WS) : 0;
+            if (cc >= 0) v[u] = c < NV ? B.Wp[pi * B.WS + cc] : B.gp[pi];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int it = it0 + u * T;
+          if (it < cnt * 73) {
+            const int rr = it / 73, c = it - rr * 73;
+            tile[rr * 74 + c] = rs[rr] * v[u];
+          }
+        }
       }
       base += cnt;
     } else {
       const int l0 = base - np0;
       const int cnt = min(MTROWS / 4, nl0 - l0);
       nrows = 4 * cnt;
-      for (int it = tid; it < cnt * 73; it += T) {
-        const int ll = it / 73, c = it % 73;
-        const size_t li = (size_t)w * B.maxL + lst[LOFF + l0 + ll];
+      if (tid < cnt) {
+        const int l = lst[LOFF + l0 + tid];
+        const size_t li = (size_t)w * B.maxL + l;
         const double* Hl = B.Hll + li * 16;
-        double Cc[10], x[4];
+        double Cc[10];
         int t = 0;
         for (int a = 0; a < 4; ++a)
           for (int cc = 0; cc <= a; ++cc, ++t) Cc[t] = Hl[4 * a + cc];
@@ -427,10 +457,24 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
             Cc[tri(ii, jj)] = s2 / d;
           }
         }
-        const int cc = c < NV ? wcol(c, B.ln_start[li], B.WS) : 0;
+        for (int q = 0; q < 10; ++q) lineC[10 * tid + q] = Cc[q];
+        rstart[tid] = B.ln_start[li];
+        rland[tid] = l;
+      }
+      __syncthreads();
+      for (int it = tid; it < cnt * 73; it += T) {
+        const int ll = it / 73, c = it - ll * 73;
+        const size_t li = (size_t)w * B.maxL + rland[ll];
+        const double* Cc = lineC + 10 * ll;
+        const int cc = c < NV ? wcol(c, rstart[ll], B.WS) : 0;
+        double wv4[4], x[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wv4[a] = cc < 0 ? 0.0 : (c < NV ? B.Wl[(li * 4 + a) * B.WS + cc] : B.gl[li * 4 + a]);
+#pragma unroll
         for (int a = 0; a < 4; ++a) {
-          double s2 = cc < 0 ? 0.0 : (c < NV ? B.Wl[(li * 4 + a) * B.WS + cc] : B.gl[li * 4 + a]);
-          for (int k = 0; k < a; ++k) s2 -= Cc[tri(a, k)] * x[k];
+          double s2 = wv4[a];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (k < a) s2 -= Cc[tri(a, k)] * x[k];
           x[a] = s2 / Cc[tri(a, a)];
           tile[(4 * ll + a) * 74 + c] = x[a];
         }
