@@ -89,8 +89,8 @@ __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double
   // (d) prior: H = J0^T J0 (J0 staged in LDS) and the column map
   const int n = B.pr_n[w];
   if (n > 0) {
-    const double* J0 = B.pr_J0 + (size_t)w * MAXPN * MAXPN;
-    double* H = B.pr_H + (size_t)w * MAXPN * MAXPN;
+    const double* J0 = B.pr_J0 + (size_t)w * B.prS;
+    double* H = B.pr_H + (size_t)w * B.prS;
     const bool fits = n <= nstage;
     if (fits) {
       for (int idx = tid; idx < n * n; idx += blockDim.x) Jl[idx] = J0[idx];
@@ -210,11 +210,11 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     }
     for (int i = tid; i < n; i += T) invmap[B.pr_map[(size_t)w * MAXPN + i]] = i;
     __syncthreads();
-    const double* J0 = B.pr_J0 + (size_t)w * MAXPN * MAXPN;
+    const double* J0 = B.pr_J0 + (size_t)w * B.prS;
     // r = r0 + J0 dx and g = J0^T r = g0 + H dx (H = J0^T J0, g0 = J0^T r0 from k_prep) in ONE pass: eight lanes per row,
     // both rows' loads in flight together -- the second mat-vec used to start after the first (and a barrier) and paid
     // the global latency of its column reads all over again
-    const double* Hp = B.pr_H + (size_t)w * MAXPN * MAXPN;
+    const double* Hp = B.pr_H + (size_t)w * B.prS;
     for (int r = tid >> 3; r < n; r += T >> 3) {
       const int sub = tid & 7;
       double s = 0, sg = 0;
@@ -559,7 +559,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   VPL_STAMP(B, w, 20);
   // ---- assemble the packed cam Hessian and gradient in HBM -----------------------------------
   double* Hout = B.Hcc + (size_t)w * NCP;
-  const double* pH = B.pr_H + (size_t)w * MAXPN * MAXPN;
+  const double* pH = B.pr_H + (size_t)w * B.prS;
   // Three passes over the packed lower triangle instead of one that decodes every index and asks every entry for all
   // three sources: (A) rows to waves, columns to lanes -- the visual block, coalesced stores, no index decoding;
   // (B) the 3570 entries the IMU factors touch (11 diagonal 15x15 blocks, 10 sub-diagonal ones), each summing its one or

@@ -815,7 +815,7 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
       for (int k = 0; k < ls; ++k) prdx[idx + k] = dx[k];
     }
     __syncthreads();
-    const double* J0 = B.pr_J0 + (size_t)w * MAXPN * MAXPN;
+    const double* J0 = B.pr_J0 + (size_t)w * B.prS;
     for (int r = tid >> 3; r < n; r += T >> 3) {   // eight lanes per row of J0 (coalesced), loads unrolled
       const int sub = tid & 7;
       double s = 0;

@@ -91,6 +91,8 @@ struct DevBatch {
   double *pr_J0, *pr_r0;                         // [W][171*171] [W][171]
   double *pr_H;                                  // [W][171*171]  J0^T J0 (prior-local indexing)
   double *pr_g0;                                 // [W][171]      J0^T r0
+  int prS;                                       // stride (doubles) of one window's J0 / H: the batch's largest prior squared,
+                                                 // not 171^2 -- the priors of a batch stay within a few MB instead of 120 MB
   int *pr_map;                                   // [W][171] prior-local column -> cam index
 
   // ---- linearisation (one buffer set; written by k_lin at the current x) ----

@@ -427,6 +427,13 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   c->h_nL.assign(W, 0);
   c->h_lmap.resize(W);
 
+  {   // stride of the per-window prior matrices: the largest prior of the batch
+    int nmax = 1;
+    for (size_t w = 0; w < W; ++w)
+      if (win[w].has_prior && win[w].prior) nmax = std::max(nmax, win[w].prior->n);
+    if (nmax > MAXPN) return fail(c, VPL_E_CAPACITY, "prior larger than MAXPN");
+    B.prS = (nmax * nmax + 7) & ~7;
+  }
   // compact W rows: stride from the longest track of the batch; zero fill only where some slot has no writer
   {
     int maxTrack = 2, minTrack = NF;
@@ -521,7 +528,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
           return fail(c, VPL_E_INVALID, "bad prior block");
       }
       std::memcpy(&pr_r0[w * MAXPN], pr.r0, (size_t)pr.n * 8);
-      HIPCHK(c, hipMemcpyAsync(B.pr_J0 + w * MAXPN * MAXPN, pr.J0, (size_t)pr.n * pr.n * 8, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(B.pr_J0 + w * (size_t)B.prS, pr.J0, (size_t)pr.n * pr.n * 8, hipMemcpyHostToDevice, c->stream));
     }
     // kept blocks of the next prior in the canonical (address) order of the reference's para_* layout
     {
