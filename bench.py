@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- sliding-window BA solves/sec on MI355X (BASELINE.json metric).
 
-One step = one batched execution of the optimizationwithLine() body (<=5 trust-region
-iterations -> gauge fix -> MARGIN_OLD marginalisation -> new prior) over a batch of
-independent synthetic windows of the named shape (10 KF window = 11 frames, 200 points +
-80 lines + VP observations, prior from a warm-up solve of the preceding window), inputs
-already resident in HBM.  Multi-GPU: one process per GPU, the batch dimension is sharded,
-no collective in the data path (weak scaling: every rank solves `--windows` windows).
+One step = one batched execution of the optimizationwithLine() body (<= 5 trust-region iterations -> gauge fix ->
+MARGIN_OLD marginalisation -> new prior) over a batch of independent synthetic windows of the named shape (10 KF window
+= 11 frames, 200 points + 80 lines + VP observations, prior from a warm-up solve of the preceding window), inputs
+already resident in HBM.
+
+Multi-GPU (BASELINE config 5): ONE batch of `--windows` (512) windows is block-partitioned over the
+ranks (512 / 256 / 128 / 64 per GPU at 1 / 2 / 4 / 8), one process per GPU, every rank solves its block, then one RCCL
+all-gather of the per-window states (183 doubles per window) and an all-reduce(MAX) of the timing / parity summary.
+`value` is that strong-scaling figure; `weak_scaling` in the same JSON line is the same measurement with `--windows`
+windows on EVERY rank.  `python bench.py --gpus N` without a launcher starts the N ranks itself (before any GPU call);
+under torchrun, WORLD_SIZE must equal --gpus.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -19,31 +24,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np
-import torch
-
-import vplines_slam_amd as v
-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes(P, L, n_prior, obs_p, obs_l):
-    """SURVEY.md 8d compulsory FP64 traffic of one trust-region iteration of one window, and the
-    share of it that each kernel of this implementation must move (DESIGN.md 'bytes')."""
+    """SURVEY.md 8d compulsory FP64 traffic of one trust-region iteration of ONE window, and the share of it that each
+    kernel of this implementation must move (DESIGN.md 'bytes')."""
     F_p = obs_p - P          # point factors
     F_l = obs_l              # line factors (start frame included)
     F_v = obs_l
+    nfull = 171 + P + 4 * L
     reads = 8 * ((11 * 16 + 7 + P + 4 * L) + (6 * F_p + 4 * F_l + 3 * F_v) + 10 * 287 + (n_prior ** 2 + n_prior + 86))
     writes = 8 * ((171 * 171 + 171) + (2 * P + 20 * L) + (42 * P + 168 * L))
-    k_lin = reads + 8 * ((171 * 172 // 2 + 171) + (2 * P + 20 * L) + (42 * P + 168 * L))
-    k_solve = 8 * ((171 * 172 // 2 + 171) + (2 * P + 20 * L) + (42 * P + 168 * L)) + 8 * 2 * (171 + P + 4 * L)
+    lin_out = 8 * ((171 * 172 // 2 + 171) + (2 * P + 20 * L) + (42 * P + 168 * L))
+    k_lin = reads + lin_out
+    k_solve = lin_out + 8 * 2 * nfull                 # a window that computes a new Gauss-Newton step
+    k_solve_reuse = 8 * 6 * nfull                     # a window that re-uses the step of a rejected iteration: vectors only
     k_cost = 8 * ((11 * 16 + 7 + P + 4 * L) + (3 * obs_p + 8 * obs_l) + 10 * 62 + (n_prior ** 2 + n_prior + 86))
-    return dict(iteration=reads + writes, k_lin=k_lin, k_solve=k_solve, k_cost=k_cost)
+    return dict(iteration=reads + writes, k_lin=k_lin, k_solve=k_solve, k_solve_reuse=k_solve_reuse, k_cost=k_cost)
 
 
 def pmc_traffic(kernel, nW, P, L):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/pmc_traffic.json, produced
-    by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this very command at the default workload,
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/pmc_traffic.json, produced by
+    tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this very command at the default workload,
     corrected as MI355X_MICROARCH.md prescribes).  None when the workload differs from the profiled one."""
     if (nW, P, L) != (512, 200, 80):
         return None
@@ -56,25 +59,209 @@ def pmc_traffic(kernel, nW, P, L):
     return k[key]["total"] if key in k else None
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (torch.distributed.run) BEFORE this process
+    touches the GPU, pass their output through and exit with their code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+class Batch:
+    """One resident batch of primed windows on a context + the timing / profile helpers."""
+
+    def __init__(self, v, ctx, ids, cfg, opt, config_id):
+        self.v, self.ctx, self.ids = v, ctx, list(ids)
+        t0 = time.time()
+        self.B, self.keep = v.workload.primed_batch(ctx, self.ids, cfg, opt, config_id)
+        self.pristine = [b.copy() for b in self.B]      # download() overwrites B in place
+        ctx.upload(self.B, opt)                          # inputs now resident in HBM
+        self.n_prior = int(round(sum(self.keep[i].n for i in range(len(self.B))) / max(1, len(self.B))))
+        self.setup_s = time.time() - t0
+
+    def step(self):
+        self.ctx.reset_state()
+        self.ctx.solve()
+
+
+def timed(torch, dist, dev, batch, steps, warmup, v):
+    for _ in range(warmup):
+        batch.step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    return v.shard.reduce_max_vec(dist, [elapsed], dev)[0]
+
+
+def launch_profile(torch, dev, batch, reps):
+    """Per-launch device time (HIP events on the launch stream) and active-window counts, averaged over `reps` solves."""
+    ctx = batch.ctx
+    ctx.enable_kernel_timing(True)
+    acc = None
+    for _ in range(reps):
+        batch.step()
+        torch.cuda.synchronize(dev)
+        prof = ctx.launch_profile()
+        if acc is None:
+            acc = [[name, 0.0, [0, 0, 0, 0]] for (name, _, _) in prof]
+        for a, (name, ms, act) in zip(acc, prof):
+            a[1] += ms / reps
+            for k in range(4):
+                a[2][k] += act[k] / reps
+    kt = ctx.kernel_times()
+    ctx.enable_kernel_timing(False)
+    return acc, {k: ms / reps for k, (ms, _) in kt.items()}
+
+
+def roofline_from_profile(prof, ab, nW, P, L):
+    """Prices every launch of k_lin / k_solve / k_cost by the windows that DID WORK in it (device-side counters), not by
+    the batch size.  Returns the roofline object of the dominant kernel plus the per-kernel table."""
+    per = {}
+    for name, ms, act in prof:
+        if name == "k_lin":
+            b = ab["k_lin"] * act[0]
+        elif name == "k_solve":
+            b = ab["k_solve"] * act[1] + ab["k_solve_reuse"] * act[2]
+        elif name == "k_cost":
+            b = ab["k_cost"] * act[3]
+        else:
+            continue
+        e = per.setdefault(name, dict(ms=0.0, bytes=0.0, launches=0, heavy=None))
+        e["ms"] += ms
+        e["bytes"] += b
+        e["launches"] += 1
+        full = {"k_lin": act[0], "k_solve": act[1], "k_cost": act[3]}[name]
+        if full >= 0.999 * nW and (e["heavy"] is None or ms > e["heavy"]["ms"]):
+            e["heavy"] = dict(ms=ms, bytes=b, windows=full)          # slowest launch in which every window did the full work
+    dom = max(per, key=lambda k: per[k]["ms"])
+    table = {}
+    for k, e in per.items():
+        gbs = e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["ms"] > 0 else 0.0
+        table[k] = {"ms_per_solve": e["ms"], "launches": e["launches"], "avg_launch_ms": e["ms"] / e["launches"],
+                    "algorithmic_bytes_per_solve": e["bytes"], "GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
+        if e["heavy"]:
+            h = e["heavy"]
+            hg = h["bytes"] / (h["ms"] * 1e-3) / 1e9
+            table[k]["heavy_launch"] = {"ms": h["ms"], "windows": h["windows"], "GBps": hg, "frac": hg / HBM_PEAK_GBS}
+    d = table[dom]
+    roof = {"bound": "hbm", "kernel": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+            "traffic": pmc_traffic(dom, nW, P, L), "avg_launch_ms": d["avg_launch_ms"],
+            "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_solve"] / d["launches"],
+            "pricing": "algorithmic bytes of the windows that did work in each launch (device counters) / launch time "
+                       "(HIP events on the launch stream), summed over the %d launches of one solve" % d["launches"],
+            "heavy_launch": d.get("heavy_launch"), "per_kernel": table}
+    it_ms = sum(e["ms"] for e in per.values())
+    it_bytes = sum(e["bytes"] for e in per.values())
+    roof["pipeline_GBps"] = it_bytes / (it_ms * 1e-3) / 1e9
+    roof["pipeline_frac"] = roof["pipeline_GBps"] / HBM_PEAK_GBS
+    return roof
+
+
+def step_stats(reports, n):
+    import numpy as np
+    it = np.array([reports[i].iterations for i in range(n)])
+    ok = np.array([reports[i].num_successful_steps for i in range(n)])     # includes iteration 0 (ceres convention)
+    term = np.array([reports[i].termination for i in range(n)])
+    acc = np.maximum(ok - 1, 0)
+    return {"mean_tr_iterations": float(it.mean()), "mean_accepted_steps": float(acc.mean()),
+            "mean_rejected_steps": float((it - acc).mean()),
+            "accepted_histogram": [int((acc == k).sum()) for k in range(int(it.max()) + 1)],
+            "terminated_by_tolerance": int((term == 1).sum()), "failed": int((term == 2).sum())}
+
+
+def frontend_config4(torch, v, dev, steps=5, warm=2):
+    """BASELINE config 4 as an extra key: EDLines + KLT matching of the 64-frame 752x480 stream, frames resident in HBM."""
+    import numpy as np
+    n = 64
+    imgs = v.workload.frame_stream(n)
+    fe = v.frontend.FrontendContext(device=dev.index or 0, max_images=n, width=752, height=480, max_lines=256,
+                                    stream=torch.cuda.current_stream(dev).cuda_stream)
+    fe.match_reserve(n - 1, 8192)
+    fe.upload(imgs)
+    pairs = [(i, i + 1) for i in range(n - 1)]
+
+    def step():
+        fe.detect()
+        fe.synchronize()
+        lines = [l[:256] for l in fe.download()]
+        fe.match_upload(pairs, [lines[a] for a, _ in pairs], [lines[b] for _, b in pairs])
+        fe.match_run()
+        fe.synchronize()
+        return lines, fe.match_download()
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lines, (r2c, ok) = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record(); fe.detect(); e1.record(); fe.match_run(); e2.record()
+    torch.cuda.synchronize(dev)
+    fe.enable_kernel_timing(True)      # per-kernel device time of one more batch (hipEvents on the launch stream)
+    fe.detect(); fe.match_run()
+    fe.synchronize()
+    kt = fe.kernel_times()
+    fe.enable_kernel_timing(False)
+    out = {"metric": "line front-end frames/s (EDLines + KLT matching, 752x480, batch 64)", "value": n / dt,
+           "unit": "frames/s", "ms_per_batch": 1e3 * dt, "device_ms_detect": e0.elapsed_time(e1),
+           "device_ms_match": e1.elapsed_time(e2), "mean_lines_per_frame": float(np.mean([len(l) for l in lines])),
+           "mean_matches_per_pair": float(np.mean([(r >= 0).sum() for r in r2c])),
+           "kernels_ms_per_batch": {k: round(x, 4) for k, x in kt.items()}}
+    if "k_ed_grad" in kt:
+        ms = kt["k_ed_grad"]
+        out["k_ed_grad"] = {"ms": ms, "algorithmic_bytes": n * 752 * 480 * 8, "GBps": n * 752 * 480 * 8 / (ms * 1e-3) / 1e9,
+                            "frac": n * 752 * 480 * 8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    fe.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--windows", type=int, default=512, help="windows per GPU per step")
+    ap.add_argument("--windows", type=int, default=512, help="the batch: windows in total (strong) / per GPU (weak)")
     ap.add_argument("--points", type=int, default=200)
     ap.add_argument("--lines", type=int, default=80)
-    ap.add_argument("--cpu-windows", type=int, default=0, help="oracle sample size (0 = auto, ~10-30 s)")
+    ap.add_argument("--cpu-windows", type=int, default=64, help="oracle sample size for parity + CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config-2 / config-4 / weak-scaling extra keys")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torchrun --nproc-per-node %d) "
+                         "or run without a launcher" % (args.gpus, world, args.gpus))
+
+    import numpy as np
+    import torch
+    import vplines_slam_amd as v
+
     dist = None
     if world > 1 or os.environ.get("VPL_FORCE_DIST"):   # VPL_FORCE_DIST: exercise the RCCL path with a single rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -82,129 +269,153 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    nW, P, L = args.windows, args.points, args.lines
+    total, P, L = args.windows, args.points, args.lines
     opt = v.default_options()
     cfg = v.workload.config(P, L, True)
     TL = cfg.track_len
-    ctx = v.Context(device=local_rank, max_windows=nW, max_points=max(P, 1), max_point_obs=max(P * TL, 1),
-                    max_lines=max(L, 1), max_line_obs=max(L * TL, 1))
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
+    config_id = 3 if L else 2
 
-    # ---- setup (untimed): windows A (preceding window, no prior) and B (the timed batch) ----
-    t_setup = time.time()
-    lo, hi = v.shard.window_range(rank, world, nW)
-    seeds = [v.shard.window_seeds(3, g) for g in range(lo, hi)]
-    A = [v.workload.generate(sa, cfg, t) for (sa, sb, t) in seeds]
-    B = [v.workload.generate(sb, cfg, t + cfg.kf_dt) for (sa, sb, t) in seeds]
-    pre = ctx.preintegrate(*v.workload.imu_batch_arrays(A + B), opt)     # IntegrationBase on device
-    v.workload.set_preintegrations(A + B, pre)
-    priors, _ = ctx.solve_windows(A, opt)                                # warm-up solve -> priors for B
-    keep = (v.Prior * nW)()
-    C.memmove(keep, priors, C.sizeof(keep))
-    for i in range(nW):
-        B[i].prior = keep[i]
-    pristine = [b.copy() for b in B]                                     # download() overwrites B in place
-    ctx.upload(B, opt)                                                   # inputs now resident in HBM
-    n_prior = int(np.mean([keep[i].n for i in range(nW)]))
-    t_setup = time.time() - t_setup
+    def new_ctx(nw, p, l):
+        c = v.Context(device=local_rank, max_windows=max(nw, 1), max_points=max(p, 1), max_point_obs=max(p * TL, 1),
+                      max_lines=max(l, 1), max_line_obs=max(l * TL, 1))
+        c.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        return c
 
-    def step():
-        ctx.reset_state()
-        ctx.solve()
+    # ---- strong scaling: the ONE batch of `total` windows, block-partitioned ----
+    lo, hi = v.shard.split_batch(total, rank, world)
+    ctx = new_ctx(hi - lo, P, L)
+    strong = Batch(v, ctx, range(lo, hi), cfg, opt, config_id)
+    elapsed = timed(torch, dist, dev, strong, args.steps, args.warmup, v)
+    value = total * args.steps / elapsed
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        elapsed = v.shard.reduce_max(dist, elapsed, dev)
-    value = world * nW * args.steps / elapsed
-
-    # ---- per-kernel device time with HIP events on the launch stream (separate, un-timed pass) ----
-    ctx.enable_kernel_timing(True)
-    ksteps = max(3, min(args.steps, 10))
-    for _ in range(ksteps):
-        step()
-    torch.cuda.synchronize(dev)
-    kt = ctx.kernel_times()
-    ctx.enable_kernel_timing(False)
+    # results: one all-gather of the per-window states, parity of the gathered set against the oracle on rank 0
     _, reports = ctx.download()
-    iters = float(np.mean([reports[i].iterations for i in range(nW)]))
-    succ = float(np.mean([reports[i].num_successful_steps for i in range(nW)]))
+    n_local = hi - lo
+    gathered = v.shard.gather_states(dist, v.shard.pack_states(strong.B), total, dev)
+    stats = step_stats(reports, n_local)
+
+    # ---- per-launch profile (separate, un-timed pass) ----
+    prof, kms = launch_profile(torch, dev, strong, max(3, min(args.steps, 10)))
+    ab = algorithmic_bytes(P, L, strong.n_prior, P * TL, L * TL)
+    roof = roofline_from_profile(prof, ab, n_local, P, L)
 
     out = None
     if rank == 0:
-        ab = algorithmic_bytes(P, L, n_prior, P * TL, L * TL)
-        kavg = {k: (ms / max(1, cnt)) for k, (ms, cnt) in kt.items()}
-        total_ms = sum(ms for ms, _ in kt.values()) / ksteps
-        dom = max(("k_lin", "k_solve", "k_cost"), key=lambda k: kt.get(k, (0, 1))[0])
-        # windows that actually run the dominant kernel differ per launch (rejected steps skip the
-        # re-linearisation): the launch processes the whole batch, priced at nW windows per launch
-        achieved = ab[dom] * nW / (kavg[dom] * 1e-3) / 1e9
-        iter_ms = sum(kt.get(k, (0, 0))[0] for k in ("k_lin", "k_solve", "k_cost")) / ksteps
-        pipeline = ab["iteration"] * nW * iters / (iter_ms * 1e-3) / 1e9
         out = {
             "metric": "sliding-window BA solves/sec (10 KF, 200 pts + 80 lines, 5 iters)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "batch of %d independent synthetic sliding windows per GPU: 11 frames, %d points + "
-                                   "%d lines (x%d obs) + VP obs, 10 IMU factors, prior n=%d from a warm-up solve; "
-                                   "max 5 TR iterations + gauge fix + MARGIN_OLD marginalisation" % (nW, P, L, TL, n_prior),
-                       "windows_per_gpu": nW, "points": P, "lines": L, "track_len": TL, "prior_dim": n_prior,
-                       "mean_tr_iterations": iters, "mean_successful_steps": succ, "parallelism": "batch-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, nW, P, L),
-                         "avg_launch_ms": kavg[dom], "algorithmic_bytes_per_launch": ab[dom] * nW,
-                         "pipeline_GBps": pipeline, "pipeline_frac": pipeline / HBM_PEAK_GBS},
-            "kernels_ms_per_step": {k: ms / ksteps for k, (ms, _) in kt.items()},
-            "device_ms_per_step": total_ms,
-            "setup_s": t_setup,
+            "config": {"workload": "one batch of %d independent synthetic sliding windows (BASELINE config %d shape) block-"
+                                   "partitioned over %d GPU(s): 11 frames at 10 Hz, %d points + %d lines (x%d obs) + VP obs, "
+                                   "10 IMU factors (20 samples each), prior n=%d from a warm-up solve; max %d TR iterations + "
+                                   "gauge fix + MARGIN_OLD marginalisation"
+                                   % (total, config_id if world == 1 else 5, world, P, L, TL, strong.n_prior, opt.num_iterations),
+                       "windows_total": total, "windows_per_gpu": n_local, "points": P, "lines": L, "track_len": TL,
+                       "prior_dim": strong.n_prior, "parallelism": "batch block-partitioned x%d, all-gather of results" % world,
+                       **stats},
+            "roofline": roof,
+            "kernels_ms_per_step": kms,
+            "device_ms_per_step": sum(kms.values()),
+            "launches": [{"kernel": n, "ms": round(ms, 5), "active": [round(a, 1) for a in act]} for n, ms, act in prof],
+            "setup_s": strong.setup_s,
         }
 
-    # ---- CPU baseline + parity on a bounded sample: rank 0, single-GPU run only ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- parity of the gathered result set + CPU baseline on a bounded sample (rank 0) ----
+    if rank == 0 and not args.no_cpu_baseline:
         import oracle_api as o       # the oracle is the CPU baseline / checker here, never the product path
-        cores = min(os.cpu_count() or 1, 16)   # the GPU box's CPU share for one GPU
-        ns = args.cpu_windows or nW
-        # single-thread figure first, on a small sample, to size the threaded run to ~10-20 s of work
-        ns1 = max(2, min(ns, 8))
-        s1 = [pristine[i].copy() for i in range(ns1)]
+        from test_gpu_solve import rot_angle
+        ns = min(args.cpu_windows, total)
+        sample_ids = [int(round(k * (total - 1) / max(1, ns - 1))) for k in range(ns)] if ns > 1 else [0]
+        sample_ids = sorted(set(sample_ids))
+        # the sampled windows span every rank's block; rank 0 rebuilds their inputs from the window ids alone
+        if world == 1:
+            sample = [strong.pristine[g].copy() for g in sample_ids]
+        else:
+            sctx = new_ctx(len(sample_ids), P, L)
+            sb, _keep = v.workload.primed_batch(sctx, sample_ids, cfg, opt, config_id)
+            sample = [b.copy() for b in sb]
+            sctx.close()
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        native = o.build_native()
+        if native:
+            o.load(native)
+        lib = o.load()
+        # (i) the reference's own threading: one solve thread + NUM_THREADS = 4 for the marginalisation assembly
+        lib.orc_set_marg_threads(4)
+        s1 = [w.copy() for w in sample[: max(2, min(len(sample), 8))]]
         t1 = time.perf_counter()
         o.solve_windows(s1, opt, threads=1)
         t1 = time.perf_counter() - t1
-        reps = max(1, int(round(12.0 * cores * (ns1 / t1) / ns)))
+        lib.orc_set_marg_threads(1)
+        # (ii) windows fanned over all host cores, sized to ~10-20 s of CPU work
+        reps = max(1, int(round(12.0 * cores * (len(s1) / t1) / len(sample))))
         tc = 0.0
         for _ in range(reps):
-            sample = [pristine[i].copy() for i in range(ns)]
+            res = [w.copy() for w in sample]
             t = time.perf_counter()
-            o.solve_windows(sample, opt, threads=cores)
+            o.solve_windows(res, opt, threads=cores)
             tc += time.perf_counter() - t
-        dpm, drm = 0.0, 0.0
-        from test_gpu_solve import pose_err
-        for i in range(ns):
-            dp, dr = pose_err(B[i], sample[i])   # B[i] holds the downloaded GPU result
+        dpm = drm = 0.0
+        for k, g in enumerate(sample_ids):
+            pose, _, _ = v.shard.unpack_state(gathered[g])
+            dp = np.linalg.norm(pose[:, :3] - res[k].pose[:, :3], axis=1).max()
+            dr = max(rot_angle(pose[i, 3:], res[k].pose[i, 3:]) for i in range(11))
             dpm, drm = max(dpm, dp), max(drm, dr)
-        out["cpu_baseline"] = {"value": ns * reps / tc, "unit": "solves/s", "cores": cores, "kind": "port",
-                               "sample": "%d of the %d timed windows x %d repeats, oracle (CPU restatement of the "
-                                         "reference path) fanned over %d host threads, %.1f s" % (ns, nW, reps, cores, tc),
-                               "single_thread_solves_per_s": ns1 / t1}
-        out["parity"] = {"windows": ns, "max_dp_m": dpm, "max_dr_rad": drm}
+        out["cpu_baseline"] = {
+            "value": len(sample) * reps / tc, "unit": "solves/s", "cores": cores, "kind": "port",
+            "cpu_model": o.cpu_model(), "nproc": os.cpu_count(),
+            "build": "-O3 -march=native (built on this host)" if native else "-O2 portable build (native compile failed)",
+            "sample": "%d of the %d timed windows x %d repeats, oracle (CPU restatement of the reference path) fanned over "
+                      "%d host threads, %.1f s" % (len(sample), total, reps, cores, tc),
+            "reference_threading_solves_per_s": len(s1) / t1,
+            "reference_threading": "1 solve thread + 4 marginalisation threads (marginalization_factor.h:13), %d windows" % len(s1)}
+        out["parity"] = {"windows": len(sample), "of_gathered": total, "max_dp_m": dpm, "max_dr_rad": drm,
+                         "bar": "1e-4 m / 1e-6 rad"}
+    # all-reduce(MAX) of the parity summary: every rank ends up with the figures rank 0 prints
+    par = v.shard.reduce_max_vec(dist, [out["parity"]["max_dp_m"], out["parity"]["max_dr_rad"]] if (out and "parity" in out) else [0.0, 0.0], dev)
+    if rank == 0 and out and "parity" in out:
+        out["parity"]["allreduce_max"] = par
+
+    # ---- extra keys: weak scaling, config 2 (points only), config 4 (line front-end) ----
+    if not args.no_extras:
+        if world > 1:
+            ctx.close()
+            wl, wh = v.shard.window_range(rank, world, total)
+            wctx = new_ctx(total, P, L)
+            weak = Batch(v, wctx, range(wl, wh), cfg, opt, config_id)
+            we = timed(torch, dist, dev, weak, args.steps, args.warmup, v)
+            if rank == 0:
+                out["weak_scaling"] = {"value": world * total * args.steps / we, "unit": "solves/s",
+                                       "windows_per_gpu": total, "ms_per_step": 1e3 * we / args.steps}
+            wctx.close()
+        elif rank == 0:
+            out["weak_scaling"] = {"value": value, "unit": "solves/s", "windows_per_gpu": total,
+                                   "ms_per_step": 1e3 * elapsed / args.steps}
+        if rank == 0 and world == 1 and L > 0:
+            ctx.close()
+            c2 = new_ctx(total, P, 0)
+            cfg2 = v.workload.config(P, 0, True)
+            b2 = Batch(v, c2, range(total), cfg2, opt, 2)
+            st = max(3, args.steps // 2)
+            e2 = timed(torch, None, dev, b2, st, 2, v)
+            _, r2 = c2.download()
+            p2, k2 = launch_profile(torch, dev, b2, 3)
+            ab2 = algorithmic_bytes(P, 0, b2.n_prior, P * TL, 0)
+            rf2 = roofline_from_profile(p2, ab2, total, P, 0)
+            out["config2"] = {"metric": "sliding-window BA solves/sec (10 KF, 200 pts, no lines, 5 iters)",
+                              "value": total * st / e2, "unit": "solves/s", "ms_per_step": 1e3 * e2 / st,
+                              "roofline_kernel": rf2["kernel"], "roofline_frac": rf2["frac"],
+                              "heavy_launch": rf2["heavy_launch"], **step_stats(r2, total)}
+            c2.close()
+            try:
+                out["config4"] = frontend_config4(torch, v, dev)
+            except Exception as e:   # the headline line must survive a front-end failure; it is reported, not hidden
+                out["config4"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
-    ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

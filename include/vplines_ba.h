@@ -262,6 +262,10 @@ int vpl_ba_only_line_opt(vpl_ctx* ctx, int n_windows, vpl_window* windows, const
  * context's stream. names/ms arrays of length *count on input; count updated. */
 int vpl_ba_enable_kernel_timing(vpl_ctx* ctx, int enable);
 int vpl_ba_kernel_times(vpl_ctx* ctx, int* count, const char** names, double* total_ms, int* launches);
+/* Per-launch profile of the last solve that ran with kernel timing enabled: kernel name, device time [ms] and the
+ * number of windows that did work in that launch, active[i][4] = (linearised, new Gauss-Newton step, re-used step of a
+ * rejected iteration, candidate evaluated).  Arrays of length *count on input; count updated. */
+int vpl_ba_launch_profile(vpl_ctx* ctx, int* count, const char** names, double* ms, int* active);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,11 @@ int vpl_pre_download(vpl_fe_ctx* ctx, int n_images, uint8_t* images);
 int vpl_pre_batch(vpl_fe_ctx* ctx, int n_images, const uint8_t* raw_images, int equalize, double clip_limit, int tiles_x,
                   int tiles_y, uint8_t* images);
 
+/* instrumentation (bench.py): device time of every kernel launch of vpl_edlines_detect / vpl_match_run since timing was
+ * enabled, measured with hipEvents on the context's stream, in launch order.  Arrays of length *count on input. */
+int vpl_fe_enable_kernel_timing(vpl_fe_ctx* ctx, int enable);
+int vpl_fe_kernel_times(vpl_fe_ctx* ctx, int* count, const char** names, double* ms);
+
 /* three-phase form (inputs resident in HBM while timing) */
 int vpl_edlines_upload(vpl_fe_ctx* ctx, int n_images, const uint8_t* images /* [n][H][W] */);
 int vpl_edlines_detect(vpl_fe_ctx* ctx, const vpl_edline_param* param);   /* enqueue; asynchronous */

@@ -2,8 +2,11 @@
 #include "marginalization.h"
 #include <functional>
 #include <numeric>
+#include <thread>
 
 namespace orc {
+
+int g_marg_threads = 1;   // NUM_THREADS of marginalization_factor.h:13 is 4; 1 = the same sums without threads
 
 // marginalization_factor.cpp:3-69
 void ResidualBlockInfo::Evaluate() {
@@ -86,33 +89,51 @@ void MarginalizationInfo::marginalize() {
 
   MatX A(pos, pos);
   VecX b(pos, 0.0);
-  // ThreadsConstructA (:144-175); the 4 pthread partial sums are added in one pass here
-  for (auto* it : factors) {
-    const int nres = (int)it->residuals.size();
-    const std::vector<int>& sizes = it->cost_function->parameter_block_sizes();
-    for (size_t i = 0; i < it->parameter_blocks.size(); ++i) {
-      int idx_i = parameter_block_idx[reinterpret_cast<long>(it->parameter_blocks[i])];
-      int gs_i = sizes[i];
-      int size_i = localSize(parameter_block_size[reinterpret_cast<long>(it->parameter_blocks[i])]);
-      const double* Ji = it->jacobians[i].data();
-      for (size_t j = i; j < it->parameter_blocks.size(); ++j) {
-        int idx_j = parameter_block_idx[reinterpret_cast<long>(it->parameter_blocks[j])];
-        int gs_j = sizes[j];
-        int size_j = localSize(parameter_block_size[reinterpret_cast<long>(it->parameter_blocks[j])]);
-        const double* Jj = it->jacobians[j].data();
-        for (int a = 0; a < size_i; ++a)
-          for (int c = 0; c < size_j; ++c) {
-            double s = 0;
-            for (int r = 0; r < nres; ++r) s += Ji[(size_t)r * gs_i + a] * Jj[(size_t)r * gs_j + c];
-            A(idx_i + a, idx_j + c) += s;
-            if (i != j) A(idx_j + c, idx_i + a) = A(idx_i + a, idx_j + c);
-          }
+  // ThreadsConstructA (:144-175): factor i goes to thread i % NUM_THREADS, every thread fills its own pos x pos matrix,
+  // the partial sums are added afterwards (:253-280).  g_marg_threads == 1 adds everything in one pass (same sums).
+  auto construct = [&](int t, int nt, MatX& At, VecX& bt) {
+    for (size_t fi = t; fi < factors.size(); fi += nt) {
+      ResidualBlockInfo* it = factors[fi];
+      const int nres = (int)it->residuals.size();
+      const std::vector<int>& sizes = it->cost_function->parameter_block_sizes();
+      for (size_t i = 0; i < it->parameter_blocks.size(); ++i) {
+        int idx_i = parameter_block_idx.at(reinterpret_cast<long>(it->parameter_blocks[i]));
+        int gs_i = sizes[i];
+        int size_i = localSize(parameter_block_size.at(reinterpret_cast<long>(it->parameter_blocks[i])));
+        const double* Ji = it->jacobians[i].data();
+        for (size_t j = i; j < it->parameter_blocks.size(); ++j) {
+          int idx_j = parameter_block_idx.at(reinterpret_cast<long>(it->parameter_blocks[j]));
+          int gs_j = sizes[j];
+          int size_j = localSize(parameter_block_size.at(reinterpret_cast<long>(it->parameter_blocks[j])));
+          const double* Jj = it->jacobians[j].data();
+          for (int a = 0; a < size_i; ++a)
+            for (int c = 0; c < size_j; ++c) {
+              double s = 0;
+              for (int r = 0; r < nres; ++r) s += Ji[(size_t)r * gs_i + a] * Jj[(size_t)r * gs_j + c];
+              At(idx_i + a, idx_j + c) += s;
+              if (i != j) At(idx_j + c, idx_i + a) = At(idx_i + a, idx_j + c);
+            }
+        }
+        for (int a = 0; a < size_i; ++a) {
+          double s = 0;
+          for (int r = 0; r < nres; ++r) s += Ji[(size_t)r * gs_i + a] * it->residuals[r];
+          bt[idx_i + a] += s;
+        }
       }
-      for (int a = 0; a < size_i; ++a) {
-        double s = 0;
-        for (int r = 0; r < nres; ++r) s += Ji[(size_t)r * gs_i + a] * it->residuals[r];
-        b[idx_i + a] += s;
-      }
+    }
+  };
+  if (g_marg_threads <= 1) {
+    construct(0, 1, A, b);
+  } else {
+    const int nt = g_marg_threads;
+    std::vector<MatX> As(nt, MatX(pos, pos));
+    std::vector<VecX> bs(nt, VecX(pos, 0.0));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(construct, t, nt, std::ref(As[t]), std::ref(bs[t]));
+    for (int t = 0; t < nt; ++t) {
+      th[t].join();
+      for (size_t k = 0; k < A.a.size(); ++k) A.a[k] += As[t].a[k];
+      for (int k = 0; k < pos; ++k) b[k] += bs[t][k];
     }
   }
 

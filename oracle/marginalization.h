@@ -17,6 +17,9 @@
 
 namespace orc {
 
+extern int g_marg_threads;   // threads of the A, b assembly (ThreadsConstructA); set through orc_set_marg_threads
+
+
 struct ResidualBlockInfo {
   ResidualBlockInfo(CostFunction* c, LossFunction* l, std::vector<double*> pb, std::vector<int> ds)
       : cost_function(c), loss_function(l), parameter_blocks(std::move(pb)), drop_set(std::move(ds)) {}

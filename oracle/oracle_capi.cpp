@@ -150,6 +150,9 @@ int orc_slide_window(vpl_window* w, const vpl_ba_options* opt, int flag, double 
 }
 int orc_only_line_opt(vpl_window* w, const vpl_ba_options* opt, vpl_solve_report* rep) { return only_line_opt(w, opt, rep); }
 
+// threads of MarginalizationInfo's A, b assembly (the reference runs 4, marginalization_factor.h:13)
+void orc_set_marg_threads(int n) { g_marg_threads = n < 1 ? 1 : n; }
+
 // windows fanned over `threads` host threads (cpu_baseline leg of bench.py)
 int orc_solve_windows(int n, vpl_window* w, const vpl_ba_options* opt, vpl_prior* priors_out, vpl_solve_report* reps,
                       int threads) {

@@ -3,6 +3,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <typeinfo>
+#include <algorithm>
 
 namespace orc {
 
@@ -200,6 +202,30 @@ struct Program {
     return true;
   }
 };
+
+// ORC_DEBUG=2: cost of a state split by cost-function class (diagnosis of rejected steps, tools/diag_rho.py)
+void DebugCostByType(const Program& pr, const VecX& x, const char* tag) {
+  std::map<std::string, double> by;
+  std::vector<double> r;
+  for (auto& rb : pr.p->residuals_) {
+    const int nres = rb.cost->num_residuals();
+    std::vector<const double*> params(rb.blocks.size());
+    for (size_t b = 0; b < rb.blocks.size(); ++b) {
+      int a = pr.act_of[rb.blocks[b]];
+      params[b] = a >= 0 ? &x[pr.st0[a]] : pr.p->params_[rb.blocks[b]].user;
+    }
+    r.assign(nres, 0.0);
+    rb.cost->Evaluate(params.data(), r.data(), nullptr);
+    double sq = 0;
+    for (double v : r) sq += v * v;
+    double rho[3] = {sq, 1, 0};
+    if (rb.loss) rb.loss->Evaluate(sq, rho);
+    by[typeid(*rb.cost).name()] += 0.5 * rho[0];
+  }
+  fprintf(stderr, "   %s:", tag);
+  for (auto& kv : by) fprintf(stderr, " %s=%.6g", kv.first.c_str(), kv.second);
+  fprintf(stderr, "\n");
+}
 
 // ---- block sparse matrix ops on the row blocks --------------------------------
 void SquaredColumnNorm(const Program& pr, const std::vector<RowBlock>& J, VecX& out) {
@@ -630,6 +656,41 @@ static void SolveWith(const SolverOptions& opt, Problem* problem, SolverSummary*
       fprintf(stderr, "it %d cost %.6g cand %.6g model_change %.6g rho %.4g radius %.4g gn_norm %.4g step_norm %.4g mu %.3g\n", it.iteration,
               x_cost, candidate_cost, model_cost_change, it.relative_decrease, strategy.radius,
               norm(strategy.gauss_newton_step), strategy.dogleg_step_norm, strategy.mu);
+    if (getenv("ORC_DEBUG") && atoi(getenv("ORC_DEBUG")) >= 2) {
+      DebugCostByType(pr, x, "x   ");
+      DebugCostByType(pr, candidate_x, "cand");
+    }
+    if (getenv("ORC_DEBUG") && atoi(getenv("ORC_DEBUG")) >= 3) {
+      // the residual blocks whose cost rises most, with the last parameter block (the landmark) before / after
+      std::vector<std::pair<double, int>> inc;
+      std::vector<double> r;
+      auto cost_of = [&](int i, const VecX& xx) {
+        auto& rb = problem->residuals_[i];
+        std::vector<const double*> params(rb.blocks.size());
+        for (size_t b = 0; b < rb.blocks.size(); ++b) {
+          int a = pr.act_of[rb.blocks[b]];
+          params[b] = a >= 0 ? &xx[pr.st0[a]] : problem->params_[rb.blocks[b]].user;
+        }
+        r.assign(rb.cost->num_residuals(), 0.0);
+        rb.cost->Evaluate(params.data(), r.data(), nullptr);
+        double sq = 0;
+        for (double v : r) sq += v * v;
+        double rho[3] = {sq, 1, 0};
+        if (rb.loss) rb.loss->Evaluate(sq, rho);
+        return 0.5 * rho[0];
+      };
+      for (size_t i = 0; i < problem->residuals_.size(); ++i) inc.push_back({cost_of((int)i, candidate_x) - cost_of((int)i, x), (int)i});
+      std::sort(inc.begin(), inc.end(), [](auto& a, auto& b) { return a.first > b.first; });
+      for (int k = 0; k < 12 && k < (int)inc.size(); ++k) {
+        auto& rb = problem->residuals_[inc[k].second];
+        int a = pr.act_of[rb.blocks.back()];
+        fprintf(stderr, "   +%.4g blk %d %s cost_x %.4g lm#%d:", inc[k].first, inc[k].second, typeid(*rb.cost).name(), cost_of(inc[k].second, x), a);
+        for (int c = 0; c < pr.gsize(a); ++c) fprintf(stderr, " %.5f->%.5f", x[pr.st0[a] + c], candidate_x[pr.st0[a] + c]);
+        fprintf(stderr, " | delta");
+        for (int c = 0; c < pr.lsize(a); ++c) fprintf(stderr, " %.4g", delta[pr.col0[a] + c]);
+        fprintf(stderr, "\n");
+      }
+    }
     it.gradient_max_norm = prev_gmax;
     if (it.relative_decrease > opt.min_relative_decrease) {
       x = candidate_x;

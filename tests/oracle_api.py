@@ -17,14 +17,47 @@ _dp = C.POINTER(C.c_double)
 _lib = None
 
 
-def load():
+def build_native():
+    """bench.py's cpu_baseline leg: the oracle compiled with -O3 -march=native ON THE MACHINE THAT RUNS IT
+    (oracle/_build_native, rebuilt when the CPU model differs from the one it was built on).  Returns the path, or None
+    when the compile fails (the portable -O2 build is used then, and the caller says so)."""
+    odir = os.path.join(ROOT, "oracle")
+    bdir = os.path.join(odir, "_build_native")
+    model = cpu_model()
+    tag = os.path.join(bdir, "cpu.txt")
+    try:
+        if not (os.path.exists(tag) and open(tag).read() == model):
+            subprocess.check_call(["rm", "-rf", bdir])
+        subprocess.check_call(["make", "-j%d" % min(16, os.cpu_count() or 1), "BUILD=_build_native", "OPT=-O3 -march=native"],
+                              cwd=odir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        open(tag, "w").write(model)
+        return os.path.join(bdir, "liboracle.so")
+    except Exception:
+        return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def load(path=None):
+    """Loads the oracle library (the portable build by default; `path` switches every later call to another build)."""
     global _lib
-    if _lib is not None:
+    if _lib is not None and path is None:
         return _lib
-    path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
-    if not os.path.exists(path):
-        subprocess.check_call(["make", "-j4"], cwd=os.path.join(ROOT, "oracle"), stdout=subprocess.DEVNULL)
+    if path is None:
+        path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-j4"], cwd=os.path.join(ROOT, "oracle"), stdout=subprocess.DEVNULL)
     lib = C.CDLL(path)
+    lib.orc_set_marg_threads.argtypes = [C.c_int]
+    lib.orc_set_marg_threads.restype = None
     lib.orc_preintegrate.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, C.POINTER(BaOptions), C.POINTER(Preintegration)]
     for n in ("orc_projection_factor", "orc_line_factor", "orc_vp_factor"):
         getattr(lib, n).argtypes = [_dp, _dp, C.c_double, _dp, _dp]

@@ -39,7 +39,16 @@ def _worker(rank, world, port, nw, out_q):
     elapsed = v.shard.reduce_max(dist, 1.0 + rank)           # rank-dependent fake timings
     stats = v.shard.gather_stats(dist, [float(lo), float(hi), csum])
     slo, shi = v.shard.split_batch(7, r, w)
-    out_q.put((rank, elapsed, stats, (slo, shi), [s[1] for s in seeds]))
+    # results of a block-partitioned batch of 7 windows (uneven blocks 3 + 4): every rank contributes the states of ITS
+    # windows, one all-gather puts the whole batch on every rank in window order (bench.py does this over RCCL)
+    import numpy as np
+    local = []
+    for g in range(slo, shi):
+        wnd = v.workload.generate(v.shard.window_seeds(3, g)[1], cfg, 0.0)
+        local.append(wnd)
+    gathered = v.shard.gather_states(dist, v.shard.pack_states(local), 7)
+    par = v.shard.reduce_max_vec(dist, [float(rank), 10.0 - rank])
+    out_q.put((rank, elapsed, stats, (slo, shi), [s[1] for s in seeds], gathered, par))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,6 +76,18 @@ def test_two_rank_sharding_gloo():
     assert not set(res[0][4]) & set(res[1][4])
     # strong-scaling split covers the batch exactly
     assert res[0][3] == (0, 3) and res[1][3] == (3, 7)
+    # the gathered result set is identical on both ranks, in window order, and equals what one process computes
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import vplines_slam_amd as v
+    g0, g1 = res[0][5], res[1][5]
+    assert g0.shape == (7, v.shard.STATE_DOUBLES) and np.array_equal(g0, g1)
+    cfg = v.workload.config(12, 4, True)
+    ref = v.shard.pack_states([v.workload.generate(v.shard.window_seeds(3, g)[1], cfg, 0.0) for g in range(7)])
+    assert np.array_equal(g0, ref)
+    pose, sb, ex = v.shard.unpack_state(g0[4])
+    assert pose.shape == (11, 7) and sb.shape == (11, 9) and ex.shape == (7,)
+    assert res[0][6] == [1.0, 10.0] and res[1][6] == [1.0, 10.0]     # element-wise MAX over ranks
 
 
 def test_split_batch_covers_everything():

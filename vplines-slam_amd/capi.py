@@ -199,6 +199,7 @@ def load_hip_library():
     lib.vpl_ba_only_line_opt.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(SolveReport)]
     lib.vpl_ba_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.vpl_ba_kernel_times.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), _dp, _ip]
+    lib.vpl_ba_launch_profile.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), _dp, _ip]
     _hip = lib
     return lib
 
@@ -392,3 +393,12 @@ class Context:
         launches = (C.c_int * 64)()
         self._check(self.lib.vpl_ba_kernel_times(self.h, C.byref(cnt), names, ms, launches), "vpl_ba_kernel_times")
         return {names[i].decode(): (ms[i], launches[i]) for i in range(cnt.value)}
+
+    def launch_profile(self):
+        """Launches of the last timed solve, in order: (kernel, ms, (linearised, new step, re-used step, evaluated))."""
+        cnt = C.c_int(64)
+        names = (C.c_char_p * 64)()
+        ms = (C.c_double * 64)()
+        act = (C.c_int * 256)()
+        self._check(self.lib.vpl_ba_launch_profile(self.h, C.byref(cnt), names, ms, act), "vpl_ba_launch_profile")
+        return [(names[i].decode(), ms[i], tuple(act[4 * i + k] for k in range(4))) for i in range(cnt.value)]

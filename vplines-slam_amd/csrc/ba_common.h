@@ -12,6 +12,11 @@ namespace vpl {
 #define VPL_STAMP(B, w, i) do {} while (0)
 #endif
 
+// one workgroup reports that it did the work of kind k (0 k_lin, 1 k_solve new step, 2 k_solve re-used step, 3 k_cost)
+__device__ __forceinline__ void count_active(const DevBatch& B, int k) {
+  if (B.act && threadIdx.x == 0 && B.launch < ACT_SLOTS) atomicAdd(&B.act[4 * B.launch + k], 1);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -163,6 +163,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   TrState* tr = &B.tr[w];
   if (!MARG) {
     if (tr->status != 0 || tr->fresh_lin) return;
+    count_active(B, 0);
   }
   if (PRIOR_ONLY && B.mg_n[w] == 0) return;
   double* Hv = sm;                 // NV*NV, lower triangle used

@@ -70,6 +70,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
   const int lane = tid & 63, wv = tid >> 6;
   TrState* tr = &B.tr[w];
   if (tr->status != 0) return;
+  count_active(B, tr->reuse ? 2 : 1);
   double* S = sm;                 // NAP tile-major lower (row NC = rhs); first used as 2 staging buffers
   double* sc = S + NAP;           // 176 jacobi scale of cam dims
   double* dg = sc + 176;          // 176 dogleg diagonal of cam dims
@@ -795,6 +796,7 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
   const int tid = threadIdx.x, T = COST_THREADS;
   TrState* tr = &B.tr[w];
   if (tr->status != 0 || !tr->step_valid) return;
+  count_active(B, 3);
   __shared__ double xp[84], xs[99], prdx[MAXPN], red[20];
   __shared__ int accept;
   const int nP = B.nP[w], nL = B.nL[w];

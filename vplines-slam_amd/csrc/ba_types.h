@@ -23,6 +23,7 @@ __host__ __device__ inline int wcol(int c, int s, int WS) {
 constexpr int NCP = NC * (NC + 1) / 2; // packed lower triangle of the cam Hessian (14706)
 constexpr int MAXPB = 23;              // prior blocks
 constexpr int MAXPN = 171;             // prior dim
+constexpr int ACT_SLOTS = 64;             // launches of one solve whose activity is counted
 constexpr int MAXKEEP = 80;            // new prior dim after MARGIN_OLD: <= 10*6 + 9 + 6 = 75
 
 __host__ __device__ inline int vis2cam(int v) { return v < 66 ? 15 * (v / 6) + (v % 6) : 165 + (v - 66); }
@@ -118,6 +119,10 @@ struct DevBatch {
   double *mg_A, *mg_b;                           // [W][MAXKEEP*MAXKEEP] [W][MAXKEEP]  (invariant check: A, b before the eig)
   int *mg_m;                                     // [W] MarginalizationInfo::m
   long long *dbg;                                // [W][64] phase stamps (diagnostic builds: -DVPL_STAMPS)
+  // ---- activity of the kernel launches of one solve (bench.py prices a launch by the windows that did work in it) ----
+  int *act;                                      // [ACT_SLOTS][4]: windows that ran k_lin, k_solve (new step), k_solve (re-used
+                                                 // Gauss-Newton step), k_cost in launch `launch`; null = not counted
+  int launch;                                    // slot of this launch (set by the host per launch)
 };
 
 

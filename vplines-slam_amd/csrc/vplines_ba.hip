@@ -18,7 +18,6 @@
 #include "ba_lin.h"
 #include "ba_solve.h"
 #include "ba_marg.h"
-#include "ba_window.h"
 #include "ba_lineopt.h"
 #include "ba_factors.h"
 
@@ -35,6 +34,8 @@ struct vpl_ctx {
   std::string err;
   bool timing = false;
   std::map<std::string, std::pair<double, int>> ktimes;
+  std::vector<std::pair<const char*, double>> ltimes;   // (kernel, ms) of every launch of the last timed solve, in order
+  int* d_act = nullptr;                                 // [ACT_SLOTS][4] activity counters of those launches
   std::vector<std::string> kname_store;
   // host-side marg structure of the uploaded windows
   std::vector<int> h_mg_m;
@@ -45,13 +46,6 @@ struct vpl_ctx {
   std::vector<std::vector<int>> h_lmap;          // per window: device line index -> index in the vpl_window arrays
   size_t marg_smem = 0;
   int maxPriorN = 0;                             // largest prior of the uploaded batch (k_prep stages J0 in LDS)
-  int groups = 1;                                // window groups of the kernel-per-phase path (VPL_BA_GROUPS, experiments)
-  bool fused = false;                            // one k_window launch per solve: measured slower (see ba_window.h); VPL_BA_FUSED=1 enables it
-  DevBatch hB;                                   // host copy of the descriptor of the running k_window launch
-  int slot = -1;                                 // this context's entry of c_window_batch (-1: none left, no k_window)
-  std::vector<hipStream_t> gstreams;
-  std::vector<hipEvent_t> gevents;
-  hipEvent_t fork_ev = nullptr;
 };
 
 static int fail(vpl_ctx* c, int code, const std::string& msg) {
@@ -111,6 +105,7 @@ struct KTimer {
       auto& e = c->ktimes[name];
       e.first += ms;
       e.second += 1;
+      c->ltimes.emplace_back(name, (double)ms);
       hipEventDestroy(a);
       hipEventDestroy(b);
     }
@@ -205,6 +200,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(mg_cam, W * MAXPB); AL(mg_x0, W * MAXPB * 9); AL(mg_J0, W * MAXKEEP * MAXKEEP); AL(mg_r0, W * MAXKEEP);
   AL(mg_A, W * MAXKEEP * MAXKEEP); AL(mg_b, W * MAXKEEP); AL(mg_m, W); AL(dbg, W * 64); AL(ln_removed, W * B.maxL); AL(ln_tri, W * B.maxL);
 #undef AL
+  if (e == hipSuccess) e = dalloc(c, &c->d_act, (size_t)ACT_SLOTS * 4);
   if (e != hipSuccess) {
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -223,12 +219,6 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
   (void)hipGetLastError();
   vpl_ba_default_options(&c->opt);
-  if (const char* gv = std::getenv("VPL_BA_GROUPS")) c->groups = std::max(1, std::atoi(gv));
-  if (const char* fv = std::getenv("VPL_BA_FUSED")) c->fused = std::atoi(fv) != 0;
-  {
-    static int next_slot = 0;                    // contexts beyond WINDOW_SLOTS use the kernel-per-phase path
-    c->slot = next_slot < WINDOW_SLOTS ? next_slot++ : -1;
-  }
   *out = c;
   return VPL_OK;
 }
@@ -238,9 +228,6 @@ void vpl_ctx_destroy(vpl_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (void* p : c->allocs) hipFree(p);
-  for (hipStream_t st : c->gstreams) hipStreamDestroy(st);
-  for (hipEvent_t ev : c->gevents) hipEventDestroy(ev);
-  if (c->fork_ev) hipEventDestroy(c->fork_ev);
   delete c;
 }
 
@@ -808,78 +795,44 @@ int vpl_ba_only_line_opt(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_optio
 static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
   DevBatch B = c->B;
   B.w0 = w0;
+  // with kernel timing on, every launch also counts the windows that did work in it (vpl_ba_launch_profile)
+  B.act = c->timing ? c->d_act : nullptr;
+  B.launch = 0;
+  if (c->timing) { c->ltimes.clear(); hipMemsetAsync(c->d_act, 0, sizeof(int) * ACT_SLOTS * 4, s); }
   const dim3 grid(nw);
   { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(PREP_THREADS), prep_smem(c->maxPriorN), s, B, std::min(c->maxPriorN, PREP_NMAX)); }
+  ++B.launch;
   { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
+  ++B.launch;
   for (int it = 0; it < c->opt.num_iterations; ++it) {
     { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), solve_smem(B.maxP, B.maxL), s, B); }
+    ++B.launch;
     { KTimer t(c, "k_cost"); hipLaunchKernelGGL(k_cost, grid, dim3(COST_THREADS), 0, s, B); }
+    ++B.launch;
     if (it + 1 < c->opt.num_iterations) {
       KTimer t(c, "k_lin");
       hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B);
     }
+    if (it + 1 < c->opt.num_iterations) ++B.launch;
   }
   { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
+  ++B.launch;
   if (c->opt.marginalization_flag == VPL_MARGIN_OLD) {
     { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<1>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
+    ++B.launch;
     { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   } else if (c->any_second_new) {
     { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<2>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
+    ++B.launch;
     { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   }
 }
 
-// vpl_ba_solve: the kernel-per-phase sequence over the whole batch.  Two alternatives are kept behind environment switches
-// because they were measured and lost: VPL_BA_FUSED=1 runs the solve as one k_window launch
-// (ba_window.h; 138 k against 150 k solves/s), VPL_BA_GROUPS=n cuts the batch into n window groups on streams of their own
-// (the group kernels do not overlap on this GPU: 4 groups cost 30 %).
+// vpl_ba_solve: the kernel-per-phase sequence over the whole batch, asynchronous on the context's stream.
 int vpl_ba_solve(vpl_ctx* c) {
   if (!c || c->nW < 1) return VPL_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  const int nstage = std::min(c->maxPriorN, PREP_NMAX);
-  const size_t prep8 = (size_t)((WINDOW_THREADS / 64) * 675 + nstage * nstage) * sizeof(double);
-  const size_t dyn = std::max(std::max(prep8, lin_smem(c->maxP, c->maxL)), std::max(solve_smem(c->maxP, c->maxL), c->marg_smem));
-  const bool fused = c->fused && c->slot >= 0 && !c->timing && dyn + WINDOW_STATIC_LDS <= 160 * 1024;
-  if (fused) {
-    static size_t window_max = 0;
-    if (dyn > window_max) {
-      HIPCHK(c, hipFuncSetAttribute((const void*)k_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-      window_max = dyn;
-    }
-    const int mode = c->opt.marginalization_flag == VPL_MARGIN_OLD ? 1 : c->any_second_new ? 2 : 0;
-    c->hB = c->B;
-    c->hB.w0 = 0;
-    HIPCHK(c, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_window_batch), &c->hB, sizeof(DevBatch), (size_t)c->slot * sizeof(DevBatch),
-                                     hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_window, dim3(c->nW), dim3(WINDOW_THREADS), dyn, c->stream, c->slot, nstage, c->opt.num_iterations, mode);
-    HIPCHK(c, hipGetLastError());
-    return VPL_OK;
-  }
-  const int G = c->timing ? 1 : std::min(c->groups, std::max(1, c->nW / 32));
-  if (G <= 1) {
-    launch_solve(c, 0, c->nW, c->stream);
-    HIPCHK(c, hipGetLastError());
-    return VPL_OK;
-  }
-  while ((int)c->gstreams.size() < G) {
-    hipStream_t st = nullptr;
-    hipEvent_t ev = nullptr;
-    HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    c->gstreams.push_back(st);
-    c->gevents.push_back(ev);
-  }
-  if (!c->fork_ev) HIPCHK(c, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
-  HIPCHK(c, hipEventRecord(c->fork_ev, c->stream));
-  const int per = (c->nW + G - 1) / G;
-  for (int g = 0; g < G; ++g) {
-    const int w0 = g * per, nw = std::min(per, c->nW - w0);
-    if (nw <= 0) break;
-    HIPCHK(c, hipStreamWaitEvent(c->gstreams[g], c->fork_ev, 0));
-    launch_solve(c, w0, nw, c->gstreams[g]);
-    HIPCHK(c, hipEventRecord(c->gevents[g], c->gstreams[g]));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->gevents[g], 0));
-  }
+  launch_solve(c, 0, c->nW, c->stream);
   HIPCHK(c, hipGetLastError());
   return VPL_OK;
 }
@@ -1010,6 +963,25 @@ int vpl_ba_kernel_times(vpl_ctx* c, int* count, const char** names, double* tota
     ++i;
   }
   *count = i;
+  return VPL_OK;
+}
+
+// Per-launch profile of the LAST solve run with kernel timing enabled: kernel name, device time and the number of windows
+// that did work in the launch (k_lin: linearised; k_solve: [1] computed a new Gauss-Newton step, [2] re-used the step of a
+// rejected iteration; k_cost: evaluated a candidate).  active is [count][4] in the order k_lin, k_solve new, k_solve
+// re-used, k_cost.
+int vpl_ba_launch_profile(vpl_ctx* c, int* count, const char** names, double* ms, int* active) {
+  if (!c || !count || !names || !ms || !active) return VPL_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<int> act((size_t)ACT_SLOTS * 4);
+  HIPCHK(c, hipMemcpy(act.data(), c->d_act, act.size() * sizeof(int), hipMemcpyDeviceToHost));
+  const int n = std::min(*count, (int)c->ltimes.size());
+  for (int i = 0; i < n; ++i) {
+    names[i] = c->ltimes[i].first;
+    ms[i] = c->ltimes[i].second;
+    for (int k = 0; k < 4; ++k) active[4 * i + k] = i < ACT_SLOTS ? act[4 * i + k] : 0;
+  }
+  *count = n;
   return VPL_OK;
 }
 

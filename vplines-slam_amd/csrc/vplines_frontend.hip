@@ -43,6 +43,29 @@ struct vpl_fe_ctx {
   int vpN = 0;
   std::vector<void*> allocs;
   std::string err;
+  bool timing = false;                                    // vpl_fe_enable_kernel_timing
+  std::vector<std::pair<const char*, double>> ktimes;     // (kernel, ms) of the launches since timing was enabled
+};
+
+// times one kernel launch with hipEvents on the context's stream when timing is on (bench.py: k_ed_grad GB/s)
+struct FeTimer {
+  vpl_fe_ctx* c;
+  const char* name;
+  hipEvent_t a = nullptr, b = nullptr;
+  FeTimer(vpl_fe_ctx* c_, const char* n) : c(c_), name(n) {
+    if (c->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+  }
+  ~FeTimer() {
+    if (c->timing) {
+      hipEventRecord(b, c->stream);
+      hipEventSynchronize(b);
+      float ms = 0;
+      hipEventElapsedTime(&ms, a, b);
+      c->ktimes.emplace_back(name, (double)ms);
+      hipEventDestroy(a);
+      hipEventDestroy(b);
+    }
+  }
 };
 
 static int fe_fail(vpl_fe_ctx* c, int code, const std::string& m) {
@@ -123,6 +146,19 @@ void vpl_fe_destroy(vpl_fe_ctx* c) {
   delete c;
 }
 int vpl_fe_set_stream(vpl_fe_ctx* c, void* s) { if (!c) return VPL_E_INVALID; c->stream = (hipStream_t)s; return VPL_OK; }
+int vpl_fe_enable_kernel_timing(vpl_fe_ctx* c, int enable) {
+  if (!c) return VPL_E_INVALID;
+  c->timing = enable != 0;
+  c->ktimes.clear();
+  return VPL_OK;
+}
+int vpl_fe_kernel_times(vpl_fe_ctx* c, int* count, const char** names, double* ms) {
+  if (!c || !count || !names || !ms) return VPL_E_INVALID;
+  const int n = std::min(*count, (int)c->ktimes.size());
+  for (int i = 0; i < n; ++i) { names[i] = c->ktimes[i].first; ms[i] = c->ktimes[i].second; }
+  *count = n;
+  return VPL_OK;
+}
 int vpl_fe_synchronize(vpl_fe_ctx* c) { if (!c) return VPL_E_INVALID; FECHK(c, hipStreamSynchronize(c->stream)); return VPL_OK; }
 const char* vpl_fe_last_error(const vpl_fe_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
@@ -232,11 +268,11 @@ int vpl_edlines_detect(vpl_fe_ctx* c, const vpl_edline_param* p) {
   const int PX = c->W * c->H;
   hipStream_t s = c->stream;
   FECHK(c, hipMemsetAsync(B.nLines, 0, c->n * sizeof(int), s));
-  hipLaunchKernelGGL(k_ed_grad, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B);
-  hipLaunchKernelGGL(k_ed_anchor, dim3(c->n), dim3(1024), 0, s, B);
-  hipLaunchKernelGGL(k_ed_code, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B);
-  hipLaunchKernelGGL(k_ed_route, dim3(c->n), dim3(64), c->routeSmem, s, B);
-  hipLaunchKernelGGL(k_ed_fit, dim3(ED_FIT_BLOCKS, c->n), dim3(64), 0, s, B);
+  { FeTimer t(c, "k_ed_grad"); hipLaunchKernelGGL(k_ed_grad, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B); }
+  { FeTimer t(c, "k_ed_anchor"); hipLaunchKernelGGL(k_ed_anchor, dim3(c->n), dim3(1024), 0, s, B); }
+  { FeTimer t(c, "k_ed_code"); hipLaunchKernelGGL(k_ed_code, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B); }
+  { FeTimer t(c, "k_ed_route"); hipLaunchKernelGGL(k_ed_route, dim3(c->n), dim3(64), c->routeSmem, s, B); }
+  { FeTimer t(c, "k_ed_fit"); hipLaunchKernelGGL(k_ed_fit, dim3(ED_FIT_BLOCKS, c->n), dim3(64), 0, s, B); }
   FECHK(c, hipGetLastError());
   return VPL_OK;
 }
@@ -409,13 +445,14 @@ int vpl_match_run(vpl_fe_ctx* c, const vpl_match_param* p) {
   M.epsilon = eps * eps;
   hipStream_t s = c->stream;
   auto blocks = [&](int l) { return (unsigned)(((size_t)M.ls[l] * (M.lh[l] + 2 * LM_WIN) + 255) / 256); };
-  hipLaunchKernelGGL(k_lm_level0, dim3(blocks(0), c->n), dim3(256), 0, s, M);
-  for (int l = 1; l < M.nLevels; ++l) hipLaunchKernelGGL(k_lm_down, dim3(blocks(l), c->n), dim3(256), 0, s, M, l);
-  hipLaunchKernelGGL(k_lm_scharr, dim3(blocks(0), c->n, M.nLevels), dim3(256), 0, s, M);
-  hipLaunchKernelGGL(k_lm_anchors, dim3(c->nPairs), dim3(256), (size_t)M.maxLines * sizeof(int), s, M);
-  hipLaunchKernelGGL(k_lm_plan, dim3(1), dim3(64), 0, s, M);
-  hipLaunchKernelGGL(k_lm_klt, dim3(LM_KLT_GRID), dim3(64), LM_KLT_SMEM, s, M);
-  hipLaunchKernelGGL(k_lm_vote, dim3(c->nPairs), dim3(256), (2 * M.maxLines + 1) * sizeof(int), s, M);
+  { FeTimer t(c, "k_lm_pyramid");
+    hipLaunchKernelGGL(k_lm_level0, dim3(blocks(0), c->n), dim3(256), 0, s, M);
+    for (int l = 1; l < M.nLevels; ++l) hipLaunchKernelGGL(k_lm_down, dim3(blocks(l), c->n), dim3(256), 0, s, M, l); }
+  { FeTimer t(c, "k_lm_scharr"); hipLaunchKernelGGL(k_lm_scharr, dim3(blocks(0), c->n, M.nLevels), dim3(256), 0, s, M); }
+  { FeTimer t(c, "k_lm_anchors"); hipLaunchKernelGGL(k_lm_anchors, dim3(c->nPairs), dim3(256), (size_t)M.maxLines * sizeof(int), s, M);
+    hipLaunchKernelGGL(k_lm_plan, dim3(1), dim3(64), 0, s, M); }
+  { FeTimer t(c, "k_lm_klt"); hipLaunchKernelGGL(k_lm_klt, dim3(LM_KLT_GRID), dim3(64), LM_KLT_SMEM, s, M); }
+  { FeTimer t(c, "k_lm_vote"); hipLaunchKernelGGL(k_lm_vote, dim3(c->nPairs), dim3(256), (2 * M.maxLines + 1) * sizeof(int), s, M); }
   FECHK(c, hipGetLastError());
   return VPL_OK;
 }

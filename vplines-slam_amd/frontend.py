@@ -108,6 +108,8 @@ def _bind(lib):
                                          C.POINTER(Line), ip, C.POINTER(MatchParam), ip, ip]
     lib.vpl_match_debug_kps.argtypes = [vp, C.c_int, C.c_int] + [C.c_void_p] * 5 + [ip]
     lib.vpl_match_debug_level.argtypes = [vp, C.c_int, C.c_int, C.c_void_p, C.c_void_p, ip, ip]
+    lib.vpl_fe_enable_kernel_timing.argtypes = [vp, C.c_int]
+    lib.vpl_fe_kernel_times.argtypes = [vp, ip, C.POINTER(C.c_char_p), C.POINTER(C.c_double)]
     _bound = True
 
 
@@ -213,6 +215,20 @@ class FrontendContext:
     def detect(self, param=None):
         self._param = param or default_param()
         self._check(self.lib.vpl_edlines_detect(self.h, C.byref(self._param)), "vpl_edlines_detect")
+
+    def enable_kernel_timing(self, on=True):
+        self._check(self.lib.vpl_fe_enable_kernel_timing(self.h, 1 if on else 0), "vpl_fe_enable_kernel_timing")
+
+    def kernel_times(self):
+        """{kernel: total ms} of the launches since timing was enabled (hipEvents on the context's stream)"""
+        cnt = C.c_int(256)
+        names = (C.c_char_p * 256)()
+        ms = (C.c_double * 256)()
+        self._check(self.lib.vpl_fe_kernel_times(self.h, C.byref(cnt), names, ms), "vpl_fe_kernel_times")
+        out = {}
+        for i in range(cnt.value):
+            out[names[i].decode()] = out.get(names[i].decode(), 0.0) + ms[i]
+        return out
 
     def synchronize(self):
         self._check(self.lib.vpl_fe_synchronize(self.h), "vpl_fe_synchronize")

@@ -47,3 +47,55 @@ def gather_stats(dist, stats, device=None):
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [o.cpu().tolist() for o in out]
+
+
+# ---- results of a sharded batch (SURVEY.md 8e): one all-gather of the per-window states at batch end --------------
+STATE_DOUBLES = 11 * 16 + 7     # per window: 11 x (pose 7 + speed/bias 9) + extrinsic 7 = 183 doubles
+
+
+def pack_states(windows):
+    """[n, 183] float64: pose, speed_bias, ex_pose of every window (what a consumer of the batch needs back)"""
+    import numpy as np
+    out = np.zeros((len(windows), STATE_DOUBLES))
+    for i, w in enumerate(windows):
+        out[i, :77] = np.asarray(w.pose).reshape(-1)
+        out[i, 77:176] = np.asarray(w.speed_bias).reshape(-1)
+        out[i, 176:] = np.asarray(w.ex_pose).reshape(-1)
+    return out
+
+
+def unpack_state(row):
+    """(pose [11,7], speed_bias [11,9], ex_pose [7]) of one gathered row"""
+    return row[:77].reshape(11, 7), row[77:176].reshape(11, 9), row[176:183]
+
+
+def gather_states(dist, local_states, total_windows, device=None):
+    """All-gather of the block-partitioned per-window states (split_batch order) -> [total_windows, 183] on every rank.
+    dist=None: single process, returns the local array.  Blocks of unequal size are padded to the largest one."""
+    import numpy as np
+    import torch
+    if dist is None:
+        assert len(local_states) == total_windows
+        return np.asarray(local_states)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [split_batch(total_windows, r, world) for r in range(world)]
+    cap = max(hi - lo for lo, hi in sizes)
+    buf = torch.zeros((cap, STATE_DOUBLES), dtype=torch.float64, device=device)
+    lo, hi = sizes[rank]
+    assert len(local_states) == hi - lo
+    if hi > lo:
+        buf[: hi - lo] = torch.as_tensor(np.asarray(local_states), dtype=torch.float64).to(buf.device)
+    out = torch.zeros((world * cap, STATE_DOUBLES), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, buf)
+    out = out.cpu().numpy().reshape(world, cap, STATE_DOUBLES)
+    return np.concatenate([out[r, : sizes[r][1] - sizes[r][0]] for r in range(world)], axis=0)
+
+
+def reduce_max_vec(dist, values, device=None):
+    """element-wise MAX over ranks of a short list of floats (parity / timing summary)"""
+    import torch
+    if dist is None:
+        return [float(x) for x in values]
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.cpu()]

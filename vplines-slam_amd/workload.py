@@ -13,9 +13,9 @@ _ip = C.POINTER(C.c_int)
 class Config(C.Structure):
     _fields_ = [("n_points", C.c_int), ("n_lines", C.c_int), ("track_len", C.c_int), ("with_vp", C.c_int),
                 ("imu_rate_div", C.c_int), ("kf_dt", C.c_double), ("pose_sigma_p", C.c_double), ("pose_sigma_theta_deg", C.c_double),
-                ("vel_sigma", C.c_double), ("pix_sigma", C.c_double), ("depth_rel_sigma", C.c_double),
+                ("vel_sigma", C.c_double), ("frame_sigma_scale", C.c_double), ("pix_sigma", C.c_double), ("depth_rel_sigma", C.c_double),
                 ("orth_sigma", C.c_double), ("acc_n", C.c_double), ("gyr_n", C.c_double), ("ba_sigma", C.c_double),
-                ("bg_sigma", C.c_double)]
+                ("bg_sigma", C.c_double), ("triad_roll_deg", C.c_double), ("line_dir_sign", C.c_int)]
 
 
 _lib = None
@@ -39,8 +39,10 @@ def config(n_points=200, n_lines=80, with_vp=True):
 
 
 def seed_for(config_id, window_index):
-    """seed = 0x5EED0000 + config*1000 + window_index"""
-    return 0x5EED0000 + config_id * 1000 + window_index
+    """SURVEY.md 8d seeds one window as 0x5EED0000 + config*1000 + window_index; with more than 1000 windows per config
+    (the 512-window batch uses two seeds per window) those ranges overlap, so the config stride is 2**20 here."""
+    assert 0 <= window_index < (1 << 20)
+    return 0x5EED0000 + (config_id << 20) + window_index
 
 
 def generate(seed, cfg, t_start):
@@ -94,3 +96,70 @@ def set_preintegrations(windows, pre_array):
         for j in range(1, NF):
             C.memmove(C.byref(w.preint[j]), C.byref(pre_array[k]), C.sizeof(pre_array[k]))
             k += 1
+
+
+# ---- config 4: the 752x480 frame stream (SURVEY.md 8d "Frame stream") -------------------------------------------
+def mh04_fixtures():
+    """The 15 EuRoC MH_04 frames the reference ships as test data (tests/golden/mh04_frames.npz, pixels only)."""
+    import os
+    path = os.path.join(_build.ROOT, "tests", "golden", "mh04_frames.npz")
+    return np.load(path)["frames"]
+
+
+def warp_homography(img, Hm):
+    """dst(x, y) = bilinear sample of img at Hm @ (x, y, 1); border replicated.  float64 arithmetic, uint8 in, float out."""
+    H, W = img.shape
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    d = Hm[2, 0] * xs + Hm[2, 1] * ys + Hm[2, 2]
+    sx = np.clip((Hm[0, 0] * xs + Hm[0, 1] * ys + Hm[0, 2]) / d, 0.0, W - 1.0)
+    sy = np.clip((Hm[1, 0] * xs + Hm[1, 1] * ys + Hm[1, 2]) / d, 0.0, H - 1.0)
+    x0 = np.minimum(np.floor(sx).astype(np.int64), W - 2)
+    y0 = np.minimum(np.floor(sy).astype(np.int64), H - 2)
+    fx, fy = sx - x0, sy - y0
+    a = img.astype(np.float64)
+    return ((1 - fy) * ((1 - fx) * a[y0, x0] + fx * a[y0, x0 + 1]) + fy * ((1 - fx) * a[y0 + 1, x0] + fx * a[y0 + 1, x0 + 1]))
+
+
+def frame_stream(n=64, base=None):
+    """n frames 752x480 uint8: frame i < 15 is MH_04 fixture i; later frames are fixture i % 15 warped by a small
+    homography about the image centre (rotation <= 0.5 deg, scale +-0.5 %, shift <= 3 px, perspective <= 2e-6 / px) plus
+    N(0, 2^2) noise, seeded per frame with seed_for(4, i) (numpy PCG64).  Consecutive frames stay matchable."""
+    fx = mh04_fixtures() if base is None else base
+    out = []
+    for i in range(n):
+        if i < len(fx):
+            out.append(fx[i].copy())
+            continue
+        rng = np.random.Generator(np.random.PCG64(seed_for(4, i)))
+        th = np.deg2rad(rng.uniform(-0.5, 0.5))
+        sc = 1.0 + rng.uniform(-0.005, 0.005)
+        tx, ty = rng.uniform(-3, 3, 2)
+        px, py = rng.uniform(-2e-6, 2e-6, 2)
+        cx, cy = 375.5, 239.5
+        A = np.array([[sc * np.cos(th), -sc * np.sin(th), tx], [sc * np.sin(th), sc * np.cos(th), ty], [px, py, 1.0]])
+        C = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1.0]])
+        Ci = np.array([[1, 0, -cx], [0, 1, -cy], [0, 0, 1.0]])
+        im = warp_homography(fx[i % len(fx)], C @ A @ Ci) + rng.normal(0.0, 2.0, fx[0].shape)
+        out.append(np.clip(np.rint(im), 0, 255).astype(np.uint8))
+    return np.stack(out)
+
+
+# ---- the benchmark batch (configs 2, 3, 5): windows with the prior of a warm-up solve on the preceding window ------
+def primed_batch(ctx, global_ids, cfg, opt, config_id=3):
+    """Builds the windows `global_ids` of the benchmark batch exactly as bench.py times them: for every id the preceding
+    window A (no prior) and the window B one keyframe later (shard.window_seeds), IntegrationBase of both on the device,
+    one batched solve of the A windows whose MARGIN_OLD priors become the priors of the B windows.  Returns (B, priors)
+    where priors is the ctypes array that owns the memory B[i].prior points to (keep it alive)."""
+    from . import shard
+    from .capi import Prior
+    seeds = [shard.window_seeds(config_id, g) for g in global_ids]
+    A = [generate(sa, cfg, t) for (sa, sb, t) in seeds]
+    B = [generate(sb, cfg, t + cfg.kf_dt) for (sa, sb, t) in seeds]
+    pre = ctx.preintegrate(*imu_batch_arrays(A + B), opt)
+    set_preintegrations(A + B, pre)
+    pri, _ = ctx.solve_windows(A, opt)
+    keep = (Prior * len(B))()
+    C.memmove(keep, pri, C.sizeof(keep))
+    for i, b in enumerate(B):
+        b.prior = keep[i]
+    return B, keep

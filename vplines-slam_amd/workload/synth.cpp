@@ -5,7 +5,7 @@
 //
 //   RNG  : PCG64 (XSL-RR 128/64), seed = caller-provided 64-bit value
 //   path : circle r = 2 m, omega = 0.5 rad/s, z = 1 + 0.3 sin(1.3 t), small roll/pitch/yaw wobble;
-//          keyframes every 0.2 s, IMU at 200 Hz (40 samples per keyframe interval)
+//          keyframes at 10 Hz, IMU at 200 Hz (20 samples per keyframe interval), as SURVEY.md 8d
 //   body : x = tangent, y = up, z = radially outward, so that the EuRoC camera
 //          (optical axis ~ body z, config/euroc/euroc_config.yaml:35-43) looks outward
 //   noise: EuRoC values (config/euroc/euroc_config.yaml:59-63)
@@ -168,17 +168,26 @@ struct vplw_config {
   int with_vp;        // every line observation carries its VP (flag 1.0)
   int imu_rate_div;   // IMU samples per keyframe interval
   double kf_dt;       // keyframe spacing [s]
-  double pose_sigma_p, pose_sigma_theta_deg, vel_sigma;  // initial state perturbation
+  double pose_sigma_p, pose_sigma_theta_deg, vel_sigma;  // initial state perturbation (window drift)
+  double frame_sigma_scale;                              // independent per-frame part, as a fraction of the above
   double pix_sigma;   // observation noise in normalised units (1/460)
   double depth_rel_sigma, orth_sigma;
   double acc_n, gyr_n, ba_sigma, bg_sigma;
+  double triad_roll_deg;  // rotation of the Manhattan triad about the mid-window direction of travel
+  // Sign of the z component of the initial Pluecker direction in the start camera frame.  The observed VP always has
+  // z > 0 (the detector's convention, vanishing_point_detection.cpp:154,160).  vpProjectionFactor's literal Jacobian
+  // (line_projection_factor.cpp:62-64) equals -d_z/|d| * |d| times the true derivative in its first two columns: a
+  // descent direction only for d_z < 0.  -1: d_z < 0 (default), +1: d_z > 0, 0: alternating per line
+  int line_dir_sign;
 };
 
 void vplw_default_config(vplw_config* c, int n_points, int n_lines, int with_vp) {
-  c->n_points = n_points; c->n_lines = n_lines; c->track_len = 6; c->with_vp = with_vp; c->imu_rate_div = 40; c->kf_dt = 0.2;
-  c->pose_sigma_p = 0.05; c->pose_sigma_theta_deg = 1.0; c->vel_sigma = 0.05;
+  c->n_points = n_points; c->n_lines = n_lines; c->track_len = 6; c->with_vp = with_vp; c->imu_rate_div = 20; c->kf_dt = 0.1;
+  c->pose_sigma_p = 0.05; c->pose_sigma_theta_deg = 1.0; c->vel_sigma = 0.05; c->frame_sigma_scale = 0.1;
   c->pix_sigma = 1.0 / 460.0; c->depth_rel_sigma = 0.1; c->orth_sigma = 0.02;
   c->acc_n = 0.08; c->gyr_n = 0.004; c->ba_sigma = 0.02; c->bg_sigma = 0.002;
+  c->triad_roll_deg = 90.0;
+  c->line_dir_sign = -1;
 }
 
 // Output buffers (caller-allocated):
@@ -208,6 +217,10 @@ int vplw_generate(uint64_t seed, const vplw_config* cfg, double t_start, double*
   // ground truth + perturbed initial states
   M3 Rinit[NF];
   V3 pinit[NF];
+  const double sth0 = cfg->pose_sigma_theta_deg * M_PI / 180.0;
+  const M3 Edrift = expso3(V3{rng.normal() * sth0, rng.normal() * sth0, rng.normal() * sth0});
+  const V3 drift_p{rng.normal() * cfg->pose_sigma_p, rng.normal() * cfg->pose_sigma_p, rng.normal() * cfg->pose_sigma_p};
+  const V3 drift_v{rng.normal() * cfg->vel_sigma, rng.normal() * cfg->vel_sigma, rng.normal() * cfg->vel_sigma};
   for (int i = 0; i < NF; ++i) {
     double q[4];
     mat2quat(st[i].R, q);
@@ -215,18 +228,22 @@ int vplw_generate(uint64_t seed, const vplw_config* cfg, double t_start, double*
     pt[0] = st[i].p.x; pt[1] = st[i].p.y; pt[2] = st[i].p.z; pt[3] = q[0]; pt[4] = q[1]; pt[5] = q[2]; pt[6] = q[3];
     double* sb = speed_bias_true + 9 * i;
     sb[0] = st[i].v.x; sb[1] = st[i].v.y; sb[2] = st[i].v.z; sb[3] = ba.x; sb[4] = ba.y; sb[5] = ba.z; sb[6] = bg.x; sb[7] = bg.y; sb[8] = bg.z;
-    V3 dp{rng.normal() * cfg->pose_sigma_p, rng.normal() * cfg->pose_sigma_p, rng.normal() * cfg->pose_sigma_p};
-    double sth = cfg->pose_sigma_theta_deg * M_PI / 180.0;
+    // estimator error = drift shared by the whole window (a rigid motion about frame 0 plus a velocity offset, drawn
+    // once below) + a small independent part per frame (frame_sigma_scale of the same sigmas)
+    const double fs = cfg->frame_sigma_scale;
+    V3 dp{rng.normal() * cfg->pose_sigma_p * fs, rng.normal() * cfg->pose_sigma_p * fs, rng.normal() * cfg->pose_sigma_p * fs};
+    double sth = cfg->pose_sigma_theta_deg * M_PI / 180.0 * fs;
     V3 dth{rng.normal() * sth, rng.normal() * sth, rng.normal() * sth};
-    pinit[i] = st[i].p + dp;
-    Rinit[i] = mul(st[i].R, expso3(dth));
+    pinit[i] = st[0].p + mul(Edrift, st[i].p - st[0].p) + drift_p + dp;
+    Rinit[i] = mul(mul(Edrift, st[i].R), expso3(dth));
     mat2quat(Rinit[i], q);
     double* p = pose + 7 * i;
     p[0] = pinit[i].x; p[1] = pinit[i].y; p[2] = pinit[i].z; p[3] = q[0]; p[4] = q[1]; p[5] = q[2]; p[6] = q[3];
     double* s = speed_bias + 9 * i;
-    s[0] = st[i].v.x + rng.normal() * cfg->vel_sigma;
-    s[1] = st[i].v.y + rng.normal() * cfg->vel_sigma;
-    s[2] = st[i].v.z + rng.normal() * cfg->vel_sigma;
+    V3 vi = mul(Edrift, st[i].v) + drift_v;
+    s[0] = vi.x + rng.normal() * cfg->vel_sigma * fs;
+    s[1] = vi.y + rng.normal() * cfg->vel_sigma * fs;
+    s[2] = vi.z + rng.normal() * cfg->vel_sigma * fs;
     for (int k = 3; k < 9; ++k) s[k] = 0.0;  // bias estimates start at zero
   }
   {
@@ -296,18 +313,27 @@ int vplw_generate(uint64_t seed, const vplw_config* cfg, double t_start, double*
     inv_depth[k] = (1.0 / pc.z) * (1.0 + rng.normal() * cfg->depth_rel_sigma);
   }
 
-  // Manhattan triad with equal angles to the mid-window optical axis (keeps every VP finite)
-  M3 Q0;
+  // Manhattan triad.  A line whose interpretation plane contains the camera motion cannot be triangulated, so the three
+  // families make equal angles (54.7 deg) with the mid-window direction of travel instead of with the optical axis; the
+  // roll about that direction (triad_roll_deg, default 90) keeps every family away from the image plane so that all
+  // vanishing points stay finite (camera-frame z components 0.82, 0.41, 0.41 at mid-window).
+  M3 triad;
   {
-    V3 z{1 / std::sqrt(3.0), 1 / std::sqrt(3.0), 1 / std::sqrt(3.0)};
-    V3 a{1, -1, 0};
-    a = a * (1 / norm(a));
-    V3 b = cross(z, a);
-    // columns of B = (a, b, z); triad = B^T e_i expressed so that each axis has z-component 1/sqrt(3)
-    M3 B = cols(a, b, z);
-    Q0 = M3{{{B.m[0][0], B.m[1][0], B.m[2][0]}, {B.m[0][1], B.m[1][1], B.m[2][1]}, {B.m[0][2], B.m[1][2], B.m[2][2]}}};
+    V3 tc = mulT(Rwc[5], st[5].v);           // direction of travel in the mid-window camera frame
+    tc = tc * (1.0 / norm(tc));
+    V3 zc{0, 0, 1};
+    V3 xo = zc - tc * dot(zc, tc);            // optical axis made orthogonal to the travel direction
+    xo = xo * (1.0 / norm(xo));
+    V3 yo = cross(tc, xo);
+    const double rr = cfg->triad_roll_deg * M_PI / 180.0;
+    M3 Q0;
+    for (int i = 0; i < 3; ++i) {
+      double a = rr + i * 2.0 * M_PI / 3.0;
+      V3 e = tc * (1 / std::sqrt(3.0)) + (yo * std::cos(a) + xo * std::sin(a)) * std::sqrt(2.0 / 3.0);
+      Q0.m[0][i] = e.x; Q0.m[1][i] = e.y; Q0.m[2][i] = e.z;
+    }
+    triad = mul(Rwc[5], Q0);  // columns = world directions of the 3 line families
   }
-  M3 triad = mul(Rwc[5], Q0);  // columns = world directions of the 3 line families
 
   for (int k = 0; k < cfg->n_lines; ++k) {
     int s = k % (11 - TL + 1);   // track_len 6: start frames 0..5
@@ -334,10 +360,17 @@ int vplw_generate(uint64_t seed, const vplw_config* cfg, double t_start, double*
       project(s + f, e2, u, v);
       o[2] = u + rng.normal() * cfg->pix_sigma; o[3] = v + rng.normal() * cfg->pix_sigma;
       V3 vp = mulT(Rwc[s + f], dir);
+      if (vp.z < 0) vp = vp * -1.0;
       o[4] = vp.x; o[5] = vp.y; o[6] = vp.z; o[7] = cfg->with_vp ? 1.0 : 0.0;
     }
     // world Pluecker (n = p x d, v = d) -> orthonormal -> perturb angles -> start camera frame of the INITIAL pose
     V3 nw = cross(e1, dir), vw = dir;
+    {
+      const double want = cfg->line_dir_sign ? (double)cfg->line_dir_sign : ((k / 3) % 2 ? -1.0 : 1.0);
+      const double dz = mulT(Rwc[s], dir).z;
+      const double sgn = (dz * want >= 0) ? 1.0 : -1.0;
+      nw = nw * sgn; vw = vw * sgn;
+    }
     double o4[4];
     plk_to_orth(nw, vw, o4);
     for (int c = 0; c < 4; ++c) o4[c] += rng.normal() * cfg->orth_sigma;
