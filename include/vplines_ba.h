@@ -130,6 +130,13 @@ typedef struct vpl_window {
 
   int has_prior;            /* last_marginalization_info != nullptr */
   const vpl_prior* prior;   /* used when has_prior */
+
+  /* Estimator::failure_occur (estimator.cpp:818-823): after a detected failure the gauge fix of double2vector2 restores the
+   * yaw / position of last_R0 / last_P0 (the first frame of the last good window) instead of those of the first frame
+   * before this solve.  0 = normal operation; last_R0 is row-major 3x3. */
+  int failure_occur;
+  double last_P0[3];
+  double last_R0[9];
 } vpl_window;
 
 /* Per-window solve report (mirrors the fields of ceres::Solver::Summary the
@@ -220,6 +227,19 @@ int vpl_ctx_synchronize(vpl_ctx* ctx);
 /* Convenience: upload + solve + synchronize + download. */
 int vpl_ba_solve_windows(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt,
                          vpl_prior* priors_out, vpl_solve_report* reports);
+
+/* ---- marginalisation on its own -------------------------------------------------------------------------- *
+ * Replaces MarginalizationInfo::{addResidualBlockInfo, preMarginalize, marginalize, getParameterBlocks}
+ * (marginalization_factor.cpp:89-129,177-363,458-478) as Estimator::optimizationwithLine() drives them
+ * (estimator.cpp:1229-1378 for VPL_MARGIN_OLD, :1380-1447 for VPL_MARGIN_SECOND_NEW), WITHOUT a solve: the factor subset of
+ * the flag (MARGIN_OLD: last prior, IMU factor (0,1), the point and line factors of the tracks that start in frame 0; no VP
+ * factors -- MARGIN_SECOND_NEW: the last prior alone) is linearised at the windows' CURRENT states, landmarks and dropped
+ * blocks are eliminated, and the kept block is returned as the next prior: priors_out[w] = (n, kept-block table with the
+ * frames renumbered for the next window, x0, J0, r0), m[w] / n[w] = MarginalizationInfo::m / n (either may be NULL).
+ * The windows are not modified.  With VPL_MARGIN_SECOND_NEW a window whose prior does not hold pose WINDOW_SIZE-1 gets its
+ * input prior back (estimator.cpp:1385).  Synchronous (upload, kernels, download). */
+int vpl_ba_marginalize(vpl_ctx* ctx, int n_windows, const vpl_window* windows, const vpl_ba_options* opt,
+                       int marginalization_flag, vpl_prior* priors_out, int* m, int* n);
 
 /* ---- line map maintenance that precedes the main solve (estimator.cpp:635-638) -------------------------------- */
 /* FeatureManager::triangulateLine (feature_manager.cpp:413-563): lines with line_triangulated[i] == 0 are triangulated

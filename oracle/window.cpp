@@ -51,6 +51,9 @@ struct Est {
 
   MarginalizationInfo* last_marginalization_info = nullptr;
   std::vector<double*> last_marginalization_parameter_blocks;
+  bool failure_occur = false;   // estimator.h: failure_occur, last_R0, last_P0
+  Mat3 last_R0;
+  Vec3 last_P0;
 
   ~Est() {
     for (auto* p : pre_integrations) delete p;
@@ -90,6 +93,11 @@ struct Est {
   void double2vector2(bool line_gauge = true) {
     Vec3 origin_R0 = R2ypr(Rs[0]);
     Vec3 origin_P0 = Ps[0];
+    if (failure_occur) {   // estimator.cpp:818-823
+      origin_R0 = R2ypr(last_R0);
+      origin_P0 = last_P0;
+      failure_occur = 0;
+    }
     Vec3 origin_R00 = R2ypr(Quat(para_Pose[0][6], para_Pose[0][3], para_Pose[0][4], para_Pose[0][5]).toRotationMatrix());
     double y_diff = origin_R0[0] - origin_R00[0];
     Mat3 rot_diff = ypr2R(Vec3{y_diff, 0, 0});
@@ -290,6 +298,12 @@ void load_window(const vpl_window& w, const vpl_ba_options& opt, Est& e, bool al
     e.Vs[i] = Vec3{w.speed_bias[i][0], w.speed_bias[i][1], w.speed_bias[i][2]};
     e.Bas[i] = Vec3{w.speed_bias[i][3], w.speed_bias[i][4], w.speed_bias[i][5]};
     e.Bgs[i] = Vec3{w.speed_bias[i][6], w.speed_bias[i][7], w.speed_bias[i][8]};
+  }
+  e.failure_occur = w.failure_occur != 0;
+  if (e.failure_occur) {
+    e.last_P0 = Vec3{w.last_P0[0], w.last_P0[1], w.last_P0[2]};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) e.last_R0(r, c) = w.last_R0[3 * r + c];
   }
   e.tic = Vec3{w.ex_pose[0], w.ex_pose[1], w.ex_pose[2]};
   e.ric = Quat(w.ex_pose[6], w.ex_pose[3], w.ex_pose[4], w.ex_pose[5]).normalized().toRotationMatrix();

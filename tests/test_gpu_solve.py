@@ -310,3 +310,97 @@ def test_tiny_and_full_capacity_windows(gpu_ctx, P, L, vp):
         dp, dr = pose_err(wg[i], wc[i])
         assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)
         assert pri_g[i].n == pri_c.n
+
+
+def _prior_invariants(p):
+    J, r = p.J(), p.r()
+    return J.T @ J, J.T @ r
+
+
+@pytest.mark.parametrize("flag", [0, 1])
+def test_marginalize_standalone_matches_oracle(gpu_ctx, flag):
+    """vpl_ba_marginalize (MarginalizationInfo without a solve) against the oracle's marginalisation of the same state:
+    the oracle runs its optimizationwithLine body with max_num_iterations = 0, i.e. vector2double -> evaluation only ->
+    double2vector2 -> marginalisation.  Compared through the prior's invariants J0^T J0 and J0^T r0, m, n and the
+    kept-block table (MARGIN_OLD and MARGIN_SECOND_NEW)."""
+    opt = v.default_options()
+    cfg = v.workload.config(60, 24, True)
+    n = 3
+    if flag == 0:
+        B, keep = v.workload.primed_batch(gpu_ctx, range(40, 40 + n), cfg, opt, 3)
+    else:   # MARGIN_SECOND_NEW acts on a prior that holds pose WINDOW_SIZE-1: window A with tracks over all 11 frames
+        cfgA = v.workload.config(60, 24, True)
+        cfgA.track_len = 11
+        A = [v.workload.generate(v.workload.seed_for(3, 900 + i), cfgA, 0.4 * i) for i in range(n)]
+        B = [v.workload.generate(v.workload.seed_for(3, 950 + i), cfg, 0.4 * i + cfg.kf_dt) for i in range(n)]
+        o.preintegrate_windows(A + B, opt)
+        keep = [o.solve_window(a.copy(), opt)[0] for a in A]
+        for i in range(n):
+            B[i].prior = keep[i]
+            assert 9 in [keep[i].block_frame[b] for b in range(keep[i].n_blocks) if keep[i].block_kind[b] == 0]
+    before = [b.copy() for b in B]
+    priors, m, nn = gpu_ctx.marginalize(B, opt, flag)
+    for i in range(n):       # the windows are not modified
+        assert np.array_equal(B[i].pose, before[i].pose) and np.array_equal(B[i].line_plk, before[i].line_plk)
+    o0 = v.default_options()
+    o0.num_iterations = 0
+    o0.marginalization_flag = flag
+    for i in range(n):
+        wc = before[i].copy()
+        pc, rc = o.solve_window(wc, o0)
+        assert rc.iterations == 0
+        assert m[i] == rc.prior_m and nn[i] == rc.prior_n == pc.n and priors[i].n == pc.n
+        nb = pc.n_blocks
+        assert priors[i].n_blocks == nb
+        assert list(priors[i].block_kind[:nb]) == list(pc.block_kind[:nb])
+        assert list(priors[i].block_frame[:nb]) == list(pc.block_frame[:nb])
+        assert list(priors[i].block_idx[:nb]) == list(pc.block_idx[:nb])
+        for b in range(nb):
+            gs = 9 if pc.block_kind[b] == 1 else 7
+            assert np.abs(np.array(priors[i].x0[b][:gs]) - np.array(pc.x0[b][:gs])).max() < 1e-12
+        if pc.n == 0:
+            continue
+        Ag, bg = _prior_invariants(priors[i])
+        Ac, bc = _prior_invariants(pc)
+        assert np.abs(Ag - Ac).max() <= 1e-6 * np.abs(Ac).max()
+        lam, V = np.linalg.eigh(0.5 * (Ac + Ac.T))
+        sig = V[:, lam > 1e-6 * lam[-1]]
+        assert np.abs(sig.T @ (bg - bc)).max() <= 1e-5 * max(1.0, np.abs(bc).max())
+    # the device's own solve with zero iterations ends in the same prior (k_gauge in between is the identity)
+    ws = [b.copy() for b in before]
+    pg, _ = gpu_ctx.solve_windows(ws, o0)
+    for i in range(n):
+        if priors[i].n:
+            Ag, bg = _prior_invariants(priors[i])
+            A2, b2 = _prior_invariants(pg[i])
+            assert np.abs(Ag - A2).max() <= 1e-9 * np.abs(A2).max()
+
+
+def test_failure_occur_gauge_reference(gpu_ctx):
+    """Estimator::failure_occur (estimator.cpp:818-823): the gauge fix restores yaw / position of last_R0 / last_P0"""
+    ws, opt = make_windows(2, 60, 20, True, seed0=70)
+    th = 0.4
+    R0 = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    P0 = np.array([1.5, -2.0, 0.7])
+    for w in ws:
+        w.failure = (P0, R0)
+    wg = [w.copy() for w in ws]
+    wc = [w.copy() for w in ws]
+    gpu_ctx.solve_windows(wg, opt)
+    for i in range(len(ws)):
+        o.solve_window(wc[i], opt)
+        dp, dr = pose_err(wg[i], wc[i])
+        assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)
+        # frame 0 sits at last_P0 with the yaw of last_R0
+        assert np.abs(wg[i].pose[0, :3] - P0).max() < 1e-12
+        x, y, z, w_ = wg[i].pose[0, 3:]
+        yaw = np.arctan2(2 * (w_ * z + x * y), 1 - 2 * (y * y + z * z))
+        assert abs(yaw - th) < 1e-9
+    # without the flag the same windows keep the yaw / position of their own first frame
+    plain = [w.copy() for w in ws]
+    for w in plain:
+        w.failure = None
+    before = [w.pose[0, :3].copy() for w in plain]
+    gpu_ctx.solve_windows(plain, opt)
+    for i in range(len(ws)):
+        assert np.abs(plain[i].pose[0, :3] - before[i]).max() < 1e-12

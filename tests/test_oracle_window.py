@@ -179,3 +179,27 @@ def test_remove_line_outlier_flags():
     prior1, rep1 = o.solve_window(w1, opt)
     assert rep1.prior_n == rep.prior_n and rep1.prior_m == rep.prior_m
     assert np.abs(prior1.J().T @ prior1.J() - prior.J().T @ prior.J()).max() <= 1e-9 * np.abs(prior.J().T @ prior.J()).max()
+
+
+def test_oracle_failure_occur_restores_last_frame0():
+    """estimator.cpp:818-823: with failure_occur the gauge fix puts frame 0 at last_P0 with the yaw of last_R0"""
+    import vplines_slam_amd as v
+    opt = v.default_options()
+    cfg = v.workload.config(40, 12, True)
+    w = v.workload.generate(v.workload.seed_for(3, 5), cfg, 0.3)
+    o.preintegrate_windows([w], opt)
+    th = -0.7
+    R0 = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    P0 = np.array([0.3, 4.0, -1.0])
+    a, b = w.copy(), w.copy()
+    a.failure = (P0, R0)
+    o.solve_window(a, opt)
+    o.solve_window(b, opt)
+    assert np.abs(a.pose[0, :3] - P0).max() < 1e-12
+    x, y, z, qw = a.pose[0, 3:]
+    assert abs(np.arctan2(2 * (qw * z + x * y), 1 - 2 * (y * y + z * z)) - th) < 1e-9
+    # the two results differ by one rigid yaw + translation: relative poses agree
+    da = np.linalg.norm(a.pose[5, :3] - a.pose[0, :3])
+    db = np.linalg.norm(b.pose[5, :3] - b.pose[0, :3])
+    assert abs(da - db) < 1e-9
+    assert np.abs(b.pose[0, :3] - w.pose[0, :3]).max() < 1e-12

@@ -65,7 +65,8 @@ class CWindow(C.Structure):
                 ("inv_depth", _dp),
                 ("n_lines", C.c_int), ("line_start", _ip), ("line_nobs", _ip), ("line_obs", _dp), ("line_plk", _dp),
                 ("line_removed", _ip), ("line_triangulated", _ip),
-                ("preint", Preintegration * NF), ("has_prior", C.c_int), ("prior", C.POINTER(Prior))]
+                ("preint", Preintegration * NF), ("has_prior", C.c_int), ("prior", C.POINTER(Prior)),
+                ("failure_occur", C.c_int), ("last_P0", C.c_double * 3), ("last_R0", C.c_double * 9)]
 
 
 class SolveReport(C.Structure):
@@ -98,6 +99,7 @@ class Window:
         self.line_triangulated = np.ones(max(len(self.line_start), 1), np.int32)   # is_triangulation (in/out)
         self.preint = preint if preint is not None else (Preintegration * NF)()
         self.prior = prior
+        self.failure = None       # (last_P0 [3], last_R0 [3,3]) => failure_occur = 1 (estimator.cpp:818-823)
         self.extra = {}
 
     def copy(self):
@@ -106,6 +108,7 @@ class Window:
         w = Window(self.pose, self.speed_bias, self.ex_pose, self.point_start, self.point_nobs, self.point_obs,
                    self.inv_depth, self.line_start, self.line_nobs, self.line_obs, self.line_plk, pre, self.prior)
         w.extra = dict(self.extra)
+        w.failure = self.failure
         w.line_triangulated[:] = self.line_triangulated
         return w
 
@@ -129,6 +132,15 @@ class Window:
         C.memmove(cw.preint, self.preint, C.sizeof(Preintegration) * NF)
         cw.has_prior = 1 if self.prior is not None else 0
         cw.prior = C.pointer(self.prior) if self.prior is not None else C.POINTER(Prior)()
+        cw.failure_occur = 0
+        if self.failure is not None:
+            cw.failure_occur = 1
+            p0 = np.ascontiguousarray(self.failure[0], np.float64).reshape(3)
+            r0 = np.ascontiguousarray(self.failure[1], np.float64).reshape(9)
+            for k in range(3):
+                cw.last_P0[k] = p0[k]
+            for k in range(9):
+                cw.last_R0[k] = r0[k]
         return cw
 
     def from_c(self, cw):
@@ -194,6 +206,7 @@ def load_hip_library():
     lib.vpl_ba_solve_windows.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(Prior),
                                          C.POINTER(SolveReport)]
     lib.vpl_ba_triangulate_lines.argtypes = [vp, C.c_int, C.POINTER(CWindow)]
+    lib.vpl_ba_marginalize.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.c_int, C.POINTER(Prior), _ip, _ip]
     lib.vpl_ba_slide_window.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.c_int, C.c_double, C.POINTER(CSlideTracks)]
     lib.vpl_ba_triangulate_points.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.c_double]
     lib.vpl_ba_only_line_opt.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(SolveReport)]
@@ -340,6 +353,19 @@ class Context:
         self.solve()
         self.synchronize()
         return self.download()
+
+    def marginalize(self, windows, opt, flag):
+        """vpl_ba_marginalize: (priors, m, n) of the windows' current states, no solve"""
+        n = len(windows)
+        cw = (CWindow * n)()
+        for i, w in enumerate(windows):
+            w.to_c(cw[i])
+        priors = (Prior * n)()
+        m = np.zeros(n, np.int32)
+        nn = np.zeros(n, np.int32)
+        self._check(self.lib.vpl_ba_marginalize(self.h, n, cw, C.byref(opt), flag, priors, m.ctypes.data_as(_ip),
+                                                nn.ctypes.data_as(_ip)), "vpl_ba_marginalize")
+        return priors, m, nn
 
     def triangulate_lines(self, windows):
         """FeatureManager::triangulateLine on the device; updates line_plk / line_triangulated of the Windows in place"""

@@ -67,6 +67,12 @@ __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double
       V3 ypr = R2ypr(R0);
       double* g = B.gauge + (size_t)w * 4;
       g[0] = ypr.x; g[1] = x[0]; g[2] = x[1]; g[3] = x[2];
+      const double* fr = B.fail_ref + (size_t)w * 13;
+      if (fr[0] != 0.0) {   // failure_occur: origin_R0 = R2ypr(last_R0), origin_P0 = last_P0 (estimator.cpp:818-823)
+        M3 Rl;
+        for (int k = 0; k < 9; ++k) Rl.m[k] = fr[4 + k];
+        g[0] = R2ypr(Rl).x; g[1] = fr[1]; g[2] = fr[2]; g[3] = fr[3];
+      }
     }
     x[3] = q.x; x[4] = q.y; x[5] = q.z; x[6] = q.w;
   }

@@ -182,7 +182,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(pose, W * 77); AL(sb, W * 99); AL(ex, W * 7); AL(invd, W * B.maxP); AL(orth, W * B.maxL * 4);
   AL(pose_c, W * 77); AL(sb_c, W * 99); AL(ex_c, W * 7); AL(invd_c, W * B.maxP); AL(orth_c, W * B.maxL * 4);
   AL(pose_0, W * 77); AL(sb_0, W * 99); AL(ex_0, W * 7); AL(invd_0, W * B.maxP); AL(plk_0, W * B.maxL * 6);
-  AL(plk, W * B.maxL * 6); AL(gauge, W * 4);
+  AL(plk, W * B.maxL * 6); AL(gauge, W * 4); AL(fail_ref, W * 13);
   AL(nP, W); AL(nL, W);
   AL(pt_start, W * B.maxP); AL(pt_nobs, W * B.maxP); AL(pt_off, W * B.maxP); AL(pt_obs, W * B.maxPO * 3);
   AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1)); AL(pu_tab, W * B.maxPU * 4); AL(pu_cnt, W);
@@ -401,6 +401,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
   std::vector<DevPreint> pre(W * NF);
+  std::vector<double> fail_ref(W * 13, 0.0);
   std::vector<int> pr_n(W, 0), pr_nb(W, 0), pr_kind(W * MAXPB, 0), pr_frame(W * MAXPB, 0), pr_idx(W * MAXPB, 0);
   std::vector<double> pr_x0(W * MAXPB * 9, 0.0), pr_r0(W * MAXPN, 0.0);
   std::vector<int> mg_n(W, 0), mg_nb(W, 0), mg_kind(W * MAXPB, 0), mg_frame(W * MAXPB, 0), mg_idx(W * MAXPB, 0),
@@ -439,6 +440,11 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     std::memcpy(&pose[w * 77], v.pose, 77 * 8);
     std::memcpy(&sb[w * 99], v.speed_bias, 99 * 8);
     std::memcpy(&ex[w * 7], v.ex_pose, 7 * 8);
+    if (v.failure_occur) {
+      fail_ref[w * 13] = 1.0;
+      std::memcpy(&fail_ref[w * 13 + 1], v.last_P0, 3 * 8);
+      std::memcpy(&fail_ref[w * 13 + 4], v.last_R0, 9 * 8);
+    }
     nP[w] = v.n_points;
     c->h_nP[w] = v.n_points;
     int off = 0;
@@ -552,7 +558,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     if (c->marg_smem > 159 * 1024) return fail(c, VPL_E_CAPACITY, "marginalisation workspace exceeds LDS");
   }
   HIPCHK(c, up(c, B.pose, pose)); HIPCHK(c, up(c, B.sb, sb)); HIPCHK(c, up(c, B.ex, ex)); HIPCHK(c, up(c, B.invd, invd));
-  HIPCHK(c, up(c, B.plk, plk));
+  HIPCHK(c, up(c, B.plk, plk)); HIPCHK(c, up(c, B.fail_ref, fail_ref));
   HIPCHK(c, up(c, B.pose_0, pose)); HIPCHK(c, up(c, B.sb_0, sb)); HIPCHK(c, up(c, B.ex_0, ex)); HIPCHK(c, up(c, B.invd_0, invd));
   HIPCHK(c, up(c, B.plk_0, plk));
   HIPCHK(c, up(c, B.nP, nP)); HIPCHK(c, up(c, B.nL, nL));
@@ -837,6 +843,48 @@ int vpl_ba_solve(vpl_ctx* c) {
   return VPL_OK;
 }
 
+// priors of the last marginalisation (k_marg) of the uploaded batch -> host; mn[2 w] = m, mn[2 w + 1] = n
+static int fetch_priors(vpl_ctx* c, int nW, vpl_prior* priors, std::vector<int>& mn) {
+  DevBatch& B = c->B;
+  const size_t W = nW;
+  hipStream_t s = c->stream;
+  std::vector<int> mg_n(W), mg_nb(W), mg_kind(W * MAXPB), mg_frame(W * MAXPB), mg_idx(W * MAXPB), mg_m(W);
+  std::vector<double> mg_x0(W * MAXPB * 9), mg_J0(W * MAXKEEP * MAXKEEP), mg_r0(W * MAXKEEP);
+  HIPCHK(c, hipMemcpyAsync(mg_m.data(), B.mg_m, W * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(mg_n.data(), B.mg_n, W * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(mg_nb.data(), B.mg_nb, W * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(mg_kind.data(), B.mg_kind, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(mg_frame.data(), B.mg_frame, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(mg_idx.data(), B.mg_idx, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(mg_x0.data(), B.mg_x0, W * MAXPB * 9 * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(mg_J0.data(), B.mg_J0, W * MAXKEEP * MAXKEEP * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(mg_r0.data(), B.mg_r0, W * MAXKEEP * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  mn.assign(2 * W, 0);
+  for (size_t w = 0; w < W; ++w) {
+    mn[2 * w] = mg_m[w];
+    if (c->h_passthrough[w] >= 0) {   // MARGIN_SECOND_NEW without pose WINDOW_SIZE-1 in the prior: the prior stays (estimator.cpp:1385)
+      priors[w] = c->h_pass_priors[c->h_passthrough[w]];
+      mn[2 * w + 1] = priors[w].n;
+      continue;
+    }
+    vpl_prior& p = priors[w];
+    std::memset(&p, 0, sizeof(int) * (2 + 3 * VPL_MAX_PRIOR_BLOCKS));
+    const int n = mg_n[w];
+    p.n = n; p.n_blocks = mg_nb[w];
+    mn[2 * w + 1] = n;
+    for (int b = 0; b < p.n_blocks; ++b) {
+      p.block_kind[b] = mg_kind[w * MAXPB + b];
+      p.block_frame[b] = mg_frame[w * MAXPB + b];
+      p.block_idx[b] = mg_idx[w * MAXPB + b];
+      std::memcpy(p.x0[b], &mg_x0[(w * MAXPB + b) * 9], 9 * 8);
+    }
+    std::memcpy(p.J0, &mg_J0[w * MAXKEEP * MAXKEEP], (size_t)n * n * 8);
+    std::memcpy(p.r0, &mg_r0[w * MAXKEEP], (size_t)n * 8);
+  }
+  return VPL_OK;
+}
+
 int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_solve_report* reports) {
   if (!c || nW != c->nW || !win) return VPL_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
@@ -851,25 +899,15 @@ int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_
   HIPCHK(c, hipMemcpyAsync(invd.data(), B.invd, W * B.maxP * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(plk.data(), B.plk, W * B.maxL * 6 * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(tr.data(), B.tr, W * sizeof(TrState), hipMemcpyDeviceToHost, s));
-  std::vector<int> mg_n, mg_nb, mg_kind, mg_frame, mg_idx;
-  std::vector<double> mg_x0, mg_J0, mg_r0;
   const bool marg = priors != nullptr && c->opt.marginalization_flag != VPL_MARGIN_NONE;
-  std::vector<int> mg_m(W), removed(W * B.maxL);
+  std::vector<int> mg_m(W), removed(W * B.maxL), mn;
   HIPCHK(c, hipMemcpyAsync(mg_m.data(), B.mg_m, W * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(removed.data(), B.ln_removed, W * B.maxL * 4, hipMemcpyDeviceToHost, s));
-  if (marg) {
-    mg_n.resize(W); mg_nb.resize(W); mg_kind.resize(W * MAXPB); mg_frame.resize(W * MAXPB); mg_idx.resize(W * MAXPB);
-    mg_x0.resize(W * MAXPB * 9); mg_J0.resize(W * MAXKEEP * MAXKEEP); mg_r0.resize(W * MAXKEEP);
-    HIPCHK(c, hipMemcpyAsync(mg_n.data(), B.mg_n, W * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(mg_nb.data(), B.mg_nb, W * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(mg_kind.data(), B.mg_kind, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(mg_frame.data(), B.mg_frame, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(mg_idx.data(), B.mg_idx, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(mg_x0.data(), B.mg_x0, W * MAXPB * 9 * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(mg_J0.data(), B.mg_J0, W * MAXKEEP * MAXKEEP * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(mg_r0.data(), B.mg_r0, W * MAXKEEP * 8, hipMemcpyDeviceToHost, s));
-  }
   HIPCHK(c, hipStreamSynchronize(s));
+  if (marg) {
+    const int rc = fetch_priors(c, nW, priors, mn);
+    if (rc) return rc;
+  }
   for (size_t w = 0; w < W; ++w) {
     vpl_window& v = win[w];
     std::memcpy(v.pose, &pose[w * 77], 77 * 8);
@@ -888,30 +926,54 @@ int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_
       r.initial_cost = tr[w].initial_cost;
       r.final_cost = tr[w].x_cost;
       r.prior_m = mg_m[w];
-      r.prior_n = marg ? mg_n[w] : 0;
+      r.prior_n = marg ? mn[2 * w + 1] : 0;
       for (size_t dl = 0; dl < lmap.size(); ++dl) r.n_lines_removed += removed[w * B.maxL + dl] ? 1 : 0;
     }
     if (v.line_removed) {
       for (int l = 0; l < v.n_lines; ++l) v.line_removed[l] = 0;
       for (size_t dl = 0; dl < lmap.size(); ++dl) v.line_removed[lmap[dl]] = removed[w * B.maxL + dl] ? 1 : 0;
     }
-    if (marg && c->h_passthrough[w] >= 0) {
-      priors[w] = c->h_pass_priors[c->h_passthrough[w]];
-      if (reports) reports[w].prior_n = priors[w].n;
-    } else if (marg) {
-      vpl_prior& p = priors[w];
-      std::memset(&p, 0, sizeof(int) * (2 + 3 * VPL_MAX_PRIOR_BLOCKS));
-      const int n = mg_n[w];
-      p.n = n; p.n_blocks = mg_nb[w];
-      for (int b = 0; b < p.n_blocks; ++b) {
-        p.block_kind[b] = mg_kind[w * MAXPB + b];
-        p.block_frame[b] = mg_frame[w * MAXPB + b];
-        p.block_idx[b] = mg_idx[w * MAXPB + b];
-        std::memcpy(p.x0[b], &mg_x0[(w * MAXPB + b) * 9], 9 * 8);
-      }
-      std::memcpy(p.J0, &mg_J0[w * MAXKEEP * MAXKEEP], (size_t)n * n * 8);
-      std::memcpy(p.r0, &mg_r0[w * MAXKEEP], (size_t)n * 8);
-    }
+  }
+  return VPL_OK;
+}
+
+// MarginalizationInfo::{addResidualBlockInfo, preMarginalize, marginalize} for a batch of windows WITHOUT a solve
+// (marginalization_factor.cpp:89-129,177-363 as driven by estimator.cpp:1229-1447): the factor subset of the flag is
+// linearised at the windows' current states (k_lin<1|2>), the landmarks and the dropped frame are eliminated and the kept
+// block is factored into (J0, r0) (k_marg).  The states are not touched.
+int vpl_ba_marginalize(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt_in, int marginalization_flag,
+                       vpl_prior* priors, int* m_out, int* n_out) {
+  if (!c || !win || !opt_in || !priors || nW < 1) return VPL_E_INVALID;
+  if (marginalization_flag != VPL_MARGIN_OLD && marginalization_flag != VPL_MARGIN_SECOND_NEW)
+    return fail(c, VPL_E_INVALID, "vpl_ba_marginalize: flag must be VPL_MARGIN_OLD or VPL_MARGIN_SECOND_NEW");
+  vpl_ba_options opt = *opt_in;
+  opt.marginalization_flag = marginalization_flag;
+  opt.remove_line_outliers = 0;
+  int rc = upload_impl(c, nW, win, &opt, false);
+  if (rc) return rc;
+  DevBatch B = c->B;
+  B.w0 = 0; B.act = nullptr; B.launch = 0;
+  const dim3 grid(nW);
+  hipStream_t s = c->stream;
+  // k_prep: whitening matrices, q <- Quaterniond(R(q)) and the world orth of the lines (the vector2double() the reference
+  // runs before it marginalises, estimator.cpp:1233), J0^T J0 of the incoming prior
+  { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(PREP_THREADS), prep_smem(c->maxPriorN), s, B, std::min(c->maxPriorN, PREP_NMAX)); }
+  bool ran = false;
+  if (marginalization_flag == VPL_MARGIN_OLD) {
+    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<1>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
+    ran = true;
+  } else if (c->any_second_new) {
+    { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<2>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
+    ran = true;
+  }
+  if (ran) { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
+  HIPCHK(c, hipGetLastError());
+  std::vector<int> mn;
+  rc = fetch_priors(c, nW, priors, mn);
+  if (rc) return rc;
+  for (int w = 0; w < nW; ++w) {
+    if (m_out) m_out[w] = mn[2 * w];
+    if (n_out) n_out[w] = mn[2 * w + 1];
   }
   return VPL_OK;
 }
