@@ -348,11 +348,17 @@ def main():
         o.solve_windows(s1, opt, threads=1)
         t1 = time.perf_counter() - t1
         lib.orc_set_marg_threads(1)
-        # (ii) windows fanned over all host cores, sized to ~10-20 s of CPU work
-        reps = max(1, int(round(12.0 * cores * (len(s1) / t1) / len(sample))))
+        # (ii) windows fanned over all host cores: the sample repeated until every core has work, one pass timed to size
+        #      the run to ~10-15 s of wall clock
+        work = [w for _ in range(max(1, -(-2 * cores // len(sample)))) for w in sample]
+        res = [w.copy() for w in work]
+        t = time.perf_counter()
+        o.solve_windows(res, opt, threads=cores)
+        tp = time.perf_counter() - t
+        reps = max(1, min(50, int(10.0 / max(tp, 1e-3))))
         tc = 0.0
         for _ in range(reps):
-            res = [w.copy() for w in sample]
+            res = [w.copy() for w in work]
             t = time.perf_counter()
             o.solve_windows(res, opt, threads=cores)
             tc += time.perf_counter() - t
@@ -363,11 +369,11 @@ def main():
             dr = max(rot_angle(pose[i, 3:], res[k].pose[i, 3:]) for i in range(11))
             dpm, drm = max(dpm, dp), max(drm, dr)
         out["cpu_baseline"] = {
-            "value": len(sample) * reps / tc, "unit": "solves/s", "cores": cores, "kind": "port",
+            "value": len(work) * reps / tc, "unit": "solves/s", "cores": cores, "kind": "port",
             "cpu_model": o.cpu_model(), "nproc": os.cpu_count(),
             "build": "-O3 -march=native (built on this host)" if native else "-O2 portable build (native compile failed)",
-            "sample": "%d of the %d timed windows x %d repeats, oracle (CPU restatement of the reference path) fanned over "
-                      "%d host threads, %.1f s" % (len(sample), total, reps, cores, tc),
+            "sample": "%d of the %d timed windows (x%d so that every core has work) x %d repeats, oracle (CPU restatement of "
+                      "the reference path) fanned over %d host threads, %.1f s" % (len(sample), total, len(work) // len(sample), reps, cores, tc),
             "reference_threading_solves_per_s": len(s1) / t1,
             "reference_threading": "1 solve thread + 4 marginalisation threads (marginalization_factor.h:13), %d windows" % len(s1)}
         out["parity"] = {"windows": len(sample), "of_gathered": total, "max_dp_m": dpm, "max_dr_rad": drm,

@@ -645,6 +645,9 @@ static void SolveWith(const SolverOptions& opt, Problem* problem, SolverSummary*
     }
     // FunctionToleranceReached
     it.cost_change = x_cost - candidate_cost;
+    if (getenv("ORC_DEBUG"))
+      fprintf(stderr, "it %d ftol check: |dcost| %.6g vs %.6g (ratio %.4g)\n", it.iteration, std::fabs(it.cost_change),
+              opt.function_tolerance * x_cost, std::fabs(it.cost_change) / (opt.function_tolerance * x_cost));
     if (std::fabs(it.cost_change) <= opt.function_tolerance * x_cost) {
       sum->termination_type = CONVERGENCE;
       sum->message = "Function tolerance reached.";

@@ -225,8 +225,8 @@ def test_remove_line_outliers(gpu_ctx):
         obs = np.concatenate([w.point_obs[off[i]:off[i] + nobs[i]] for i in range(len(nobs))])
         w2 = v.capi.Window(w.pose, w.speed_bias, w.ex_pose, w.point_start, nobs, obs, w.inv_depth,
                            w.line_start, w.line_nobs, w.line_obs, w.line_plk, w.preint, None)
-        w2.line_obs[0::2, [1, 3]] += 0.03                          # inconsistent observations: every line an outlier,
-        w2.line_obs[1::2, [1, 3]] -= 0.03                          # bounded by the Huber loss
+        w2.line_obs[0::2, [1, 3]] += 0.08                          # inconsistent observations: every line an outlier,
+        w2.line_obs[1::2, [1, 3]] -= 0.08                          # bounded by the Huber loss
         g.append(w2.copy())
         c.append(w2.copy())
     pg, rg = gpu_ctx.solve_windows(g, opt2)

@@ -17,6 +17,11 @@ __device__ __forceinline__ void count_active(const DevBatch& B, int k) {
   if (B.act && threadIdx.x == 0 && B.launch < ACT_SLOTS) atomicAdd(&B.act[4 * B.launch + k], 1);
 }
 
+// window of this work-group in a launch of trust-region iteration B.ord_it (identity before the first k_cost)
+__device__ __forceinline__ int ordered_window(const DevBatch& B) {
+  return B.ord_it == 0 ? (int)blockIdx.x : B.order[(size_t)(B.ord_it & 1) * B.nW + blockIdx.x];
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

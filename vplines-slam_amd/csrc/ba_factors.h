@@ -176,42 +176,147 @@ __global__ __launch_bounds__(256) void k_eval_prior(int n, int nb, const int* ki
   }
 }
 
-// IntegrationBase over raw samples: one lane per keyframe interval, big matrices in scratch
-__global__ void k_preintegrate(int n, const int* offset, const int* nsamples, const double* samples, const double* acc0,
-                               const double* gyr0, const double* lba, const double* lbg, double an2, double gn2,
-                               double aw2, double gw2, DevPreint* out, double* scratch /* n * (225*2 + 225+270+225) */) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double* base = scratch + (size_t)i * 1170;
-  PreintState* st = nullptr;
-  (void)st;
-  // state lives in scratch to keep the register file small
-  double* Jm = base;
-  double* Pm = base + 225;
-  double* F = base + 450;
-  double* Vv = base + 675;
-  double* Tm = base + 945;
-  PreintState s;
-  s.dp = V3{0, 0, 0}; s.dv = V3{0, 0, 0}; s.dq = Q4{1, 0, 0, 0}; s.sum_dt = 0;
-  for (int k = 0; k < 225; ++k) { s.J[k] = (k / 15 == k % 15) ? 1.0 : 0.0; s.P[k] = 0.0; }
-  const double nz2[4] = {an2, gn2, aw2, gw2};
+// IntegrationBase over raw samples (integration_base.h:30-36,54-198): 16 lanes per keyframe interval, 4 intervals per wave.
+// Lane j < 15 owns COLUMN j of the 15 x 15 jacobian and of the covariance in registers.  F is block sparse (3 x 3 blocks
+// built from four matrices: Rq + Rr, Rr [a1]x, Rq [a0]x + Rr [a1]x (I - [w]x dt), I - [w]x dt), so J <- F J and T = F P are
+// ~100 FMAs per lane without any matrix in memory; P <- T F^T is F applied to the ROWS of T (P is symmetric), which is the
+// one cross-lane step: T passes through a 15 x 16 LDS tile per interval.  V Q V^T has closed-form blocks.  The old kernel
+// kept F, V, T, J and P of every lane in scratch: 50 ms and 16 GB of traffic for 10 240 intervals.
+constexpr int PREINT_GROUP = 16;
+
+struct PreintF {     // the four matrices F and V are made of, and the step
+  M3 S1, S2, S3, ImW;
+  double dt;
+};
+// y = F x for one column x (15 doubles, blocks of 3: p, theta, v, ba, bg)
+__device__ __forceinline__ void preint_apply_F(const PreintF& f, const double* x, double* y) {
+  const double dt = f.dt;
+  const V3 x0{x[0], x[1], x[2]}, x1{x[3], x[4], x[5]}, x2{x[6], x[7], x[8]}, x3{x[9], x[10], x[11]}, x4{x[12], x[13], x[14]};
+  const V3 u = mul(f.S3, x1), sv = mul(f.S1, x3), r = mul(f.S2, x4);
+  const V3 y0 = x0 + u * (-0.25 * dt * dt) + x2 * dt + sv * (-0.25 * dt * dt) + r * (-0.25 * dt * dt * -dt);
+  const V3 y1 = mul(f.ImW, x1) + x4 * (-1.0 * dt);
+  const V3 y2 = u * (-0.5 * dt) + x2 + sv * (-0.5 * dt) + r * (-0.5 * dt * -dt);
+  y[0] = y0.x; y[1] = y0.y; y[2] = y0.z; y[3] = y1.x; y[4] = y1.y; y[5] = y1.z; y[6] = y2.x; y[7] = y2.y; y[8] = y2.z;
+  y[9] = x3.x; y[10] = x3.y; y[11] = x3.z; y[12] = x4.x; y[13] = x4.y; y[14] = x4.z;
+}
+// column / row c of a 3 x 3 matrix by selects (a dynamic index would move the matrix to scratch)
+__device__ __forceinline__ V3 m3col(const M3& A, int c) {
+  return V3{c == 0 ? A.m[0] : c == 1 ? A.m[1] : A.m[2], c == 0 ? A.m[3] : c == 1 ? A.m[4] : A.m[5],
+            c == 0 ? A.m[6] : c == 1 ? A.m[7] : A.m[8]};
+}
+__device__ __forceinline__ V3 m3row(const M3& A, int r) {
+  return V3{r == 0 ? A.m[0] : r == 1 ? A.m[3] : A.m[6], r == 0 ? A.m[1] : r == 1 ? A.m[4] : A.m[7],
+            r == 0 ? A.m[2] : r == 1 ? A.m[5] : A.m[8]};
+}
+
+__global__ __launch_bounds__(64) void k_preintegrate(int n, const int* offset, const int* nsamples, const double* samples,
+                                                     const double* acc0, const double* gyr0, const double* lba,
+                                                     const double* lbg, double an2, double gn2, double aw2, double gw2,
+                                                     DevPreint* out) {
+  __shared__ double tile[4][15 * PREINT_GROUP];
+  const int grp = threadIdx.x / PREINT_GROUP, j = threadIdx.x % PREINT_GROUP;
+  const int iv = blockIdx.x * 4 + grp;
+  const bool live = iv < n;
+  const int i = live ? iv : n - 1;            // idle groups shadow the last interval (no stores) so that barriers stay uniform
+  const int jc = j < 15 ? j : 14, jb = jc / 3, jj = jc % 3;
+  double Jc[15], Pc[15], T[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) { Jc[k] = (k == jc) ? 1.0 : 0.0; Pc[k] = 0.0; }
+  V3 dp{0, 0, 0}, dv{0, 0, 0};
+  Q4 dq{1, 0, 0, 0};
+  double sum_dt = 0.0;
   V3 a0{acc0[3 * i], acc0[3 * i + 1], acc0[3 * i + 2]}, g0{gyr0[3 * i], gyr0[3 * i + 1], gyr0[3 * i + 2]};
-  V3 ba{lba[3 * i], lba[3 * i + 1], lba[3 * i + 2]}, bg{lbg[3 * i], lbg[3 * i + 1], lbg[3 * i + 2]};
+  const V3 ba{lba[3 * i], lba[3 * i + 1], lba[3 * i + 2]}, bg{lbg[3 * i], lbg[3 * i + 1], lbg[3 * i + 2]};
   const double* sp = samples + (size_t)offset[i] * 7;
-  for (int k = 0; k < nsamples[i]; ++k) {
-    const double* p = sp + 7 * k;
-    V3 a1{p[1], p[2], p[3]}, g1{p[4], p[5], p[6]};
-    preint_step(s, p[0], a0, g0, a1, g1, ba, bg, nz2, F, Vv, Tm);
-    a0 = a1; g0 = g1;
+  // every group of the block runs the same number of steps (barriers inside); a group past its own count idles
+  int ns = nsamples[i], nmax = ns;
+  nmax = max(nmax, __shfl_xor(nmax, 16, 64));
+  nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+  double* tl = tile[grp];
+  for (int k = 0; k < nmax; ++k) {
+    const bool on = k < ns;
+    const double* p = sp + 7 * (on ? k : 0);
+    const double dt = p[0];
+    const V3 a1{p[1], p[2], p[3]}, g1{p[4], p[5], p[6]};
+    // midPointIntegration (:54-198)
+    const V3 un_acc_0 = qrot(dq, a0 - ba);
+    const V3 un_gyr = (g0 + g1) * 0.5 - bg;
+    const Q4 rq = qmul(dq, Q4{1, un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2});
+    const V3 un_acc_1 = qrot(rq, a1 - ba);
+    const V3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+    const V3 rp = dp + dv * dt + un_acc * (0.5 * dt * dt);
+    const V3 rv = dv + un_acc * dt;
+    const M3 Rq = qmat(dq), Rr = qmat(rq);
+    PreintF f;
+    f.dt = dt;
+    f.ImW = add(ident(), scale(skew(un_gyr), -dt));
+    f.S2 = mul(Rr, skew(a1 - ba));                       // Rr [a1 - ba]x
+    f.S3 = add(mul(Rq, skew(a0 - ba)), mul(f.S2, f.ImW));
+    f.S1 = add(Rq, Rr);
+    // J <- F J ; T = F P
+    double Jn[15];
+    preint_apply_F(f, Jc, Jn);
+    preint_apply_F(f, Pc, T);
+    // rows of T through LDS: lane k wrote column k, lane j reads row j
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 15; ++r) tl[r * PREINT_GROUP + j] = T[r];
+    __syncthreads();
+    double Tr[15], Pn[15];
+#pragma unroll
+    for (int c = 0; c < 15; ++c) Tr[c] = tl[jc * PREINT_GROUP + c];
+    preint_apply_F(f, Tr, Pn);                           // column j of F T^T = column j of (T F^T)^T = column j of P'
+    // + column j of N = V Q V^T (V of :107-125; Q = diag(an2, gn2, an2, gn2, aw2, gw2) x I3)
+    {
+      const double a = 0.25 * dt * dt, b = -(0.25 * dt * dt * 0.5 * dt), c = 0.5 * dt, d = 0.5 * dt, e = -(0.5 * dt * 0.5 * dt);
+      const M3 G = add(mul(Rq, transpose(Rq)), mul(Rr, transpose(Rr)));        // A A^T + B B^T
+      const M3 CC = mul(f.S2, transpose(f.S2));
+      V3 n0{0, 0, 0}, n1{0, 0, 0}, n2{0, 0, 0};
+      double n3 = 0.0, n4 = 0.0;
+      if (jb == 0) {        // blocks N00, N10 = N01^T, N20 = N02^T
+        n0 = m3col(G, jj) * (an2 * a * a) + m3col(CC, jj) * (2.0 * gn2 * b * b);
+        n1 = m3row(f.S2, jj) * (2.0 * gn2 * b * c);
+        n2 = m3row(G, jj) * (an2 * a * d) + m3row(CC, jj) * (2.0 * gn2 * b * e);
+      } else if (jb == 1) { // N01, N11, N21 = N12^T
+        n0 = m3col(f.S2, jj) * (2.0 * gn2 * b * c);
+        n1 = V3{jj == 0 ? 1.0 : 0.0, jj == 1 ? 1.0 : 0.0, jj == 2 ? 1.0 : 0.0} * (2.0 * gn2 * c * c);
+        n2 = m3col(f.S2, jj) * (2.0 * gn2 * c * e);
+      } else if (jb == 2) { // N02, N12, N22
+        n0 = m3col(G, jj) * (an2 * a * d) + m3col(CC, jj) * (2.0 * gn2 * b * e);
+        n1 = m3row(f.S2, jj) * (2.0 * gn2 * c * e);
+        n2 = m3col(G, jj) * (an2 * d * d) + m3col(CC, jj) * (2.0 * gn2 * e * e);
+      } else if (jb == 3) {
+        n3 = aw2 * dt * dt;
+      } else {
+        n4 = gw2 * dt * dt;
+      }
+      Pn[0] += n0.x; Pn[1] += n0.y; Pn[2] += n0.z; Pn[3] += n1.x; Pn[4] += n1.y; Pn[5] += n1.z;
+      Pn[6] += n2.x; Pn[7] += n2.y; Pn[8] += n2.z;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        Pn[9 + q] += (jb == 3 && jj == q) ? n3 : 0.0;
+        Pn[12 + q] += (jb == 4 && jj == q) ? n4 : 0.0;
+      }
+    }
+    if (on) {
+#pragma unroll
+      for (int r = 0; r < 15; ++r) { Jc[r] = Jn[r]; Pc[r] = Pn[r]; }
+      dp = rp; dv = rv; dq = qnormalized(rq);
+      sum_dt += dt;
+      a0 = a1; g0 = g1;
+    }
   }
-  (void)Jm; (void)Pm;
-  DevPreint& o = out[i];
-  o.sum_dt = s.sum_dt;
-  o.dp[0] = s.dp.x; o.dp[1] = s.dp.y; o.dp[2] = s.dp.z;
-  o.dv[0] = s.dv.x; o.dv[1] = s.dv.y; o.dv[2] = s.dv.z;
-  o.dq[0] = s.dq.x; o.dq[1] = s.dq.y; o.dq[2] = s.dq.z; o.dq[3] = s.dq.w;
-  for (int k = 0; k < 3; ++k) { o.lba[k] = lba[3 * i + k]; o.lbg[k] = lbg[3 * i + k]; }
-  for (int k = 0; k < 225; ++k) { o.cov[k] = s.P[k]; o.sqrt_info[k] = s.J[k]; }  // sqrt_info slot carries the full 15x15 jacobian out
+  if (!live || j >= 15) return;
+  DevPreint& o = out[iv];
+  if (j == 0) {
+    o.sum_dt = sum_dt;
+    o.dp[0] = dp.x; o.dp[1] = dp.y; o.dp[2] = dp.z;
+    o.dv[0] = dv.x; o.dv[1] = dv.y; o.dv[2] = dv.z;
+    o.dq[0] = dq.x; o.dq[1] = dq.y; o.dq[2] = dq.z; o.dq[3] = dq.w;
+    for (int k = 0; k < 3; ++k) { o.lba[k] = lba[3 * iv + k]; o.lbg[k] = lbg[3 * iv + k]; }
+  }
+#pragma unroll
+  for (int r = 0; r < 15; ++r) { o.cov[r * 15 + j] = Pc[r]; o.sqrt_info[r * 15 + j] = Jc[r]; }  // sqrt_info slot carries the 15x15 jacobian out
 }
 
 }  // namespace vpl

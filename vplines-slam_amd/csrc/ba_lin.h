@@ -136,7 +136,7 @@ __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double
 }
 __global__ __launch_bounds__(PREP_THREADS) void k_prep(DevBatch B, int nstage) {
   extern __shared__ double psm[];
-  prep_body(B, blockIdx.x + B.w0, psm, nstage);
+  prep_body(B, blockIdx.x, psm, nstage);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -687,7 +687,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 template <int MODE>
 __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   extern __shared__ double sm[];
-  lin_body<MODE>(B, blockIdx.x + B.w0, sm);
+  lin_body<MODE>(B, MODE == 0 ? ordered_window(B) : (int)blockIdx.x, sm);
 }
 
 inline size_t lin_smem(int maxP, int maxL) {

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(LOPT_THREADS) void k_line_opt(DevBatch B) {
     if (anyfail > 0.0 || !(model_cost_change > 0.0)) {
       if (anyfail > 0.0) reuse_diagonal = false;
       last_successful = false;
-      if (++num_invalid >= 5) { status = 2; break; }
+      if (++num_invalid >= 5) { status = 2; --iter; break; }
       continue;   // StepIsInvalid() is empty for this strategy
     }
     num_invalid = 0;
@@ -370,8 +370,9 @@ __global__ __launch_bounds__(LOPT_THREADS) void k_line_opt(DevBatch B) {
     }
     const double cand_cost = block_sum(cc, red);
     const double step_norm = sqrt(block_sum(sn2, red));
-    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { status = 1; break; }
-    if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { status = 1; break; }
+    // a tolerance fires before the iteration is recorded (ceres: the summary of the terminating iteration is never pushed)
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { status = 1; --iter; break; }
+    if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { status = 1; --iter; break; }
     const double rho = (x_cost - cand_cost) / model_cost_change;
     if (rho > 1e-3) {
       if (live) {

@@ -127,7 +127,7 @@ __device__ __forceinline__ void gauge_body(const DevBatch& B, const int w) {
                     B.mg_cam + (size_t)w * MAXPB, B.mg_n + w, B.mg_nb + w, B.mg_m + w);
   }
 }
-__global__ __launch_bounds__(128) void k_gauge(DevBatch B) { gauge_body(B, blockIdx.x + B.w0); }
+__global__ __launch_bounds__(128) void k_gauge(DevBatch B) { gauge_body(B, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------
 // Spectral factor of a symmetric positive semi-definite matrix held in LDS (full storage, row stride ld):
@@ -616,7 +616,7 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
 }
 __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   extern __shared__ double sm[];
-  marg_body(B, blockIdx.x + B.w0, sm);
+  marg_body(B, blockIdx.x, sm);
 }
 
 }  // namespace vpl

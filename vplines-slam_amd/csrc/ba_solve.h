@@ -518,7 +518,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
         tr->step_valid = 0;
         tr->iter += 1;
         tr->num_invalid += 1;
-        if (tr->num_invalid >= kMaxInvalid) tr->status = 2;
+        if (tr->num_invalid >= kMaxInvalid) { tr->status = 2; tr->iter -= 1; }   // FAILURE breaks before the iteration is recorded
         else if (tr->iter >= B.opt.num_iterations) tr->status = 3;
         tr->mu *= kMuIncrease;   // StepIsInvalid
         tr->reuse = 0;
@@ -712,7 +712,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       tr->step_valid = 0;
       tr->iter += 1;
       tr->num_invalid += 1;
-      if (tr->num_invalid >= kMaxInvalid) tr->status = 2;
+      if (tr->num_invalid >= kMaxInvalid) { tr->status = 2; tr->iter -= 1; }   // FAILURE breaks before the iteration is recorded
       else if (tr->iter >= B.opt.num_iterations) tr->status = 3;
       tr->mu *= kMuIncrease;
       tr->reuse = 0;
@@ -780,7 +780,9 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
 }
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevBatch B) {
   extern __shared__ double sm[];
-  solve_body(B, blockIdx.x + B.w0, sm);
+  // the list k_cost of THIS iteration fills is emptied here (k_cost runs after this whole kernel)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { B.ord_cnt[2 * ((B.ord_it + 1) & 1)] = 0; B.ord_cnt[2 * ((B.ord_it + 1) & 1) + 1] = 0; }
+  solve_body(B, ordered_window(B), sm);
 }
 
 constexpr size_t SOLVE_SMEM = (size_t)(NAP + 5 * 176 + 256 + 24) * sizeof(double) + 4 * sizeof(int);   // + (maxP + maxL) ints, see solve_smem
@@ -927,6 +929,18 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
 }
 // two workgroups per CU (4 waves per SIMD, <= 128 VGPRs): the kernel is a latency chain per lane, occupancy is what helps
 // (0.327 -> 0.283 ms per step against one workgroup per CU at 136 VGPRs)
-__global__ __launch_bounds__(COST_THREADS, 4) void k_cost(DevBatch B) { cost_body(B, blockIdx.x + B.w0); }
+__global__ __launch_bounds__(COST_THREADS, 4) void k_cost(DevBatch B) {
+  const int w = ordered_window(B);
+  cost_body(B, w);
+  // order of the next iteration: windows that will linearise / factor again go to the front of the list, the others (step
+  // rejected: the Gauss-Newton step is re-used; terminated) fill it from the back
+  if (threadIdx.x == 0) {
+    const TrState* tr = &B.tr[w];
+    const bool heavy = tr->status == 0 && (!tr->fresh_lin || !tr->reuse);
+    const int nx = (B.ord_it + 1) & 1;
+    const int pos = atomicAdd(&B.ord_cnt[2 * nx + (heavy ? 0 : 1)], 1);
+    B.order[(size_t)nx * B.nW + (heavy ? pos : B.nW - 1 - pos)] = w;
+  }
+}
 
 }  // namespace vpl

@@ -106,7 +106,14 @@ struct DevBatch {
   // extrinsic columns: WS = 6 * maxTrack + 6 doubles (42 for 6-frame tracks, 72 = NV at most).  wfill: rows have slots no
   // factor writes (shorter tracks, erased lines) and must be zeroed before the factors are accumulated.
   int WS, wfill;
-  int w0;                                        // first window of this launch (the solve is launched per window group)
+  // ---- launch order of the trust-region iterations ----
+  // A window whose last step was rejected neither re-linearises nor re-factors; one whose step was accepted does both
+  // (~150 us of one CU).  Work-groups are dispatched in blockIdx order, so k_cost sorts the windows for the next iteration:
+  // those that will do the heavy work first.  order[it & 1][i] = window of work-group i in iteration `it`; ord_cnt[it & 1]
+  // = {filled from the front, filled from the back}.  ord_it: iteration of this launch (0 = identity order).
+  int *order;                                    // [2][W]
+  int *ord_cnt;                                  // [2][2]
+  int ord_it;
   double *lchol;                                 // [W][maxL][10] Cholesky factors of the regularised line blocks
 
   // ---- trust region vectors over the full index ----

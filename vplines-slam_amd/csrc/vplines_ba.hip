@@ -179,6 +179,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   const size_t W = max_windows;
   hipError_t e = hipSuccess;
 #define AL(ptr, n) if (e == hipSuccess) e = dalloc(c, &B.ptr, (size_t)(n))
+#define AL2(ptr, n) if (e == hipSuccess) e = dalloc(c, &B.ptr, (size_t)(n))
   AL(pose, W * 77); AL(sb, W * 99); AL(ex, W * 7); AL(invd, W * B.maxP); AL(orth, W * B.maxL * 4);
   AL(pose_c, W * 77); AL(sb_c, W * 99); AL(ex_c, W * 7); AL(invd_c, W * B.maxP); AL(orth_c, W * B.maxL * 4);
   AL(pose_0, W * 77); AL(sb_0, W * 99); AL(ex_0, W * 7); AL(invd_0, W * B.maxP); AL(plk_0, W * B.maxL * 6);
@@ -201,6 +202,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(mg_A, W * MAXKEEP * MAXKEEP); AL(mg_b, W * MAXKEEP); AL(mg_m, W); AL(dbg, W * 64); AL(ln_removed, W * B.maxL); AL(ln_tri, W * B.maxL);
 #undef AL
   if (e == hipSuccess) e = dalloc(c, &c->d_act, (size_t)ACT_SLOTS * 4);
+  AL2(order, 2 * W); AL2(ord_cnt, 4);
   if (e != hipSuccess) {
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -254,7 +256,7 @@ int vpl_preintegrate_batch(vpl_ctx* c, int n, const int* offset, const int* nsam
   size_t total = 0;
   for (int i = 0; i < n; ++i) total = std::max(total, (size_t)offset[i] + nsamples[i]);
   int *d_off, *d_ns;
-  double *d_s, *d_a, *d_g, *d_ba, *d_bg, *d_scr;
+  double *d_s, *d_a, *d_g, *d_ba, *d_bg;
   DevPreint* d_out;
   HIPCHK(c, hipMalloc(&d_off, n * sizeof(int)));
   HIPCHK(c, hipMalloc(&d_ns, n * sizeof(int)));
@@ -263,7 +265,6 @@ int vpl_preintegrate_batch(vpl_ctx* c, int n, const int* offset, const int* nsam
   HIPCHK(c, hipMalloc(&d_g, n * 3 * sizeof(double)));
   HIPCHK(c, hipMalloc(&d_ba, n * 3 * sizeof(double)));
   HIPCHK(c, hipMalloc(&d_bg, n * 3 * sizeof(double)));
-  HIPCHK(c, hipMalloc(&d_scr, (size_t)n * 1170 * sizeof(double)));
   HIPCHK(c, hipMalloc(&d_out, n * sizeof(DevPreint)));
   HIPCHK(c, hipMemcpyAsync(d_off, offset, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_ns, nsamples, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -272,9 +273,10 @@ int vpl_preintegrate_batch(vpl_ctx* c, int n, const int* offset, const int* nsam
   HIPCHK(c, hipMemcpyAsync(d_g, gyr0, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_ba, lin_ba, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_bg, lin_bg, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_preintegrate, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, d_off, d_ns, d_s, d_a, d_g, d_ba,
-                     d_bg, opt->acc_n * opt->acc_n, opt->gyr_n * opt->gyr_n, opt->acc_w * opt->acc_w,
-                     opt->gyr_w * opt->gyr_w, d_out, d_scr);
+  { KTimer t(c, "k_preintegrate");
+    hipLaunchKernelGGL(k_preintegrate, dim3((n + 3) / 4), dim3(64), 0, c->stream, n, d_off, d_ns, d_s, d_a, d_g, d_ba,
+                       d_bg, opt->acc_n * opt->acc_n, opt->gyr_n * opt->gyr_n, opt->acc_w * opt->acc_w,
+                       opt->gyr_w * opt->gyr_w, d_out); }
   HIPCHK(c, hipGetLastError());
   std::vector<DevPreint> h(n);
   HIPCHK(c, hipMemcpyAsync(h.data(), d_out, n * sizeof(DevPreint), hipMemcpyDeviceToHost, c->stream));
@@ -287,7 +289,7 @@ int vpl_preintegrate_batch(vpl_ctx* c, int n, const int* offset, const int* nsam
     std::memcpy(o.jacobian, h[i].sqrt_info, sizeof(o.jacobian));   // k_preintegrate carries J out in this slot
     std::memcpy(o.covariance, h[i].cov, sizeof(o.covariance));
   }
-  hipFree(d_off); hipFree(d_ns); hipFree(d_s); hipFree(d_a); hipFree(d_g); hipFree(d_ba); hipFree(d_bg); hipFree(d_scr); hipFree(d_out);
+  hipFree(d_off); hipFree(d_ns); hipFree(d_s); hipFree(d_a); hipFree(d_g); hipFree(d_ba); hipFree(d_bg); hipFree(d_out);
   return VPL_OK;
 }
 
@@ -800,7 +802,7 @@ int vpl_ba_only_line_opt(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_optio
 // The whole solve of the windows [w0, w0 + nw) on stream s
 static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
   DevBatch B = c->B;
-  B.w0 = w0;
+  B.ord_it = 0;
   // with kernel timing on, every launch also counts the windows that did work in it (vpl_ba_launch_profile)
   B.act = c->timing ? c->d_act : nullptr;
   B.launch = 0;
@@ -811,16 +813,19 @@ static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
   { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
   ++B.launch;
   for (int it = 0; it < c->opt.num_iterations; ++it) {
+    B.ord_it = it;      // k_solve / k_cost of iteration `it` walk order[it & 1]; k_cost fills order[(it + 1) & 1]
     { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), solve_smem(B.maxP, B.maxL), s, B); }
     ++B.launch;
     { KTimer t(c, "k_cost"); hipLaunchKernelGGL(k_cost, grid, dim3(COST_THREADS), 0, s, B); }
     ++B.launch;
     if (it + 1 < c->opt.num_iterations) {
+      B.ord_it = it + 1;
       KTimer t(c, "k_lin");
       hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B);
     }
     if (it + 1 < c->opt.num_iterations) ++B.launch;
   }
+  B.ord_it = 0;
   { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
   ++B.launch;
   if (c->opt.marginalization_flag == VPL_MARGIN_OLD) {
@@ -952,7 +957,7 @@ int vpl_ba_marginalize(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   int rc = upload_impl(c, nW, win, &opt, false);
   if (rc) return rc;
   DevBatch B = c->B;
-  B.w0 = 0; B.act = nullptr; B.launch = 0;
+  B.ord_it = 0; B.act = nullptr; B.launch = 0;
   const dim3 grid(nW);
   hipStream_t s = c->stream;
   // k_prep: whitening matrices, q <- Quaterniond(R(q)) and the world orth of the lines (the vector2double() the reference
