@@ -73,6 +73,24 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def cpu_share():
+    """host cores this process may really use: the affinity mask, cut by the cgroup CPU quota if there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, (q + per // 2) // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 class Batch:
     """One resident batch of primed windows on a context + the timing / profile helpers."""
 
@@ -336,7 +354,7 @@ def main():
             sb, _keep = v.workload.primed_batch(sctx, sample_ids, cfg, opt, config_id)
             sample = [b.copy() for b in sb]
             sctx.close()
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = cpu_share()
         native = o.build_native()
         if native:
             o.load(native)
