@@ -137,6 +137,12 @@ typedef struct vpl_window {
   int failure_occur;
   double last_P0[3];
   double last_R0[9];
+
+  /* Optional: para_LineFeature as the caller holds it -- [n_lines][4] WORLD-frame orthonormal (psi1,psi2,psi3,phi),
+   * the block lineProjectionFactor / vpProjectionFactor::Evaluate take (feature_manager.cpp:341-365).  NULL (the normal
+   * case): it is derived from line_plk and the start pose, as vector2double does.  Non-NULL: used as is (vpl_ba_marginalize
+   * driven factor by factor, host/vpl_factors.hpp MarginalizationInfo); line_plk is then not read. */
+  const double* line_orth;
 } vpl_window;
 
 /* Per-window solve report (mirrors the fields of ceres::Solver::Summary the

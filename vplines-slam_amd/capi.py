@@ -66,7 +66,8 @@ class CWindow(C.Structure):
                 ("n_lines", C.c_int), ("line_start", _ip), ("line_nobs", _ip), ("line_obs", _dp), ("line_plk", _dp),
                 ("line_removed", _ip), ("line_triangulated", _ip),
                 ("preint", Preintegration * NF), ("has_prior", C.c_int), ("prior", C.POINTER(Prior)),
-                ("failure_occur", C.c_int), ("last_P0", C.c_double * 3), ("last_R0", C.c_double * 9)]
+                ("failure_occur", C.c_int), ("last_P0", C.c_double * 3), ("last_R0", C.c_double * 9),
+                ("line_orth", C.POINTER(C.c_double))]
 
 
 class SolveReport(C.Structure):
@@ -132,6 +133,7 @@ class Window:
         C.memmove(cw.preint, self.preint, C.sizeof(Preintegration) * NF)
         cw.has_prior = 1 if self.prior is not None else 0
         cw.prior = C.pointer(self.prior) if self.prior is not None else C.POINTER(Prior)()
+        cw.line_orth = C.POINTER(C.c_double)()
         cw.failure_occur = 0
         if self.failure is not None:
             cw.failure_occur = 1

@@ -78,7 +78,7 @@ __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double
   }
   __syncthreads();
   // (c) lines: world orth from the start-camera-frame Pluecker (getLineOrthVector, feature_manager.cpp:341-365)
-  const int nL = B.nL[w];
+  const int nL = B.orth_in[w] ? 0 : B.nL[w];
   for (int l = tid; l < nL; l += blockDim.x) {
     const int s = B.ln_start[(size_t)w * B.maxL + l];
     const double* ps = B.pose + ((size_t)w * NF + s) * 7;

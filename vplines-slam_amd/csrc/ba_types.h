@@ -69,6 +69,7 @@ struct DevBatch {
   double *pose_0, *sb_0, *ex_0, *invd_0, *plk_0; // as uploaded (vpl_ba_reset_state)
   double *plk;                                   // [W][maxL][6] start-camera-frame Pluecker (in/out)
   double *gauge;                                 // [W][4]: yaw of R0 before (deg), P0 before
+  int *orth_in;                                  // [W] 1 = B.orth was uploaded (vpl_window.line_orth): k_prep leaves it alone
   double *fail_ref;                              // [W][13]: failure_occur flag, last_P0, last_R0 (row-major) -- the gauge reference
                                                  // of double2vector2 after a failure (estimator.cpp:818-823)
 

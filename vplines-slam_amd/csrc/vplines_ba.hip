@@ -183,7 +183,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(pose, W * 77); AL(sb, W * 99); AL(ex, W * 7); AL(invd, W * B.maxP); AL(orth, W * B.maxL * 4);
   AL(pose_c, W * 77); AL(sb_c, W * 99); AL(ex_c, W * 7); AL(invd_c, W * B.maxP); AL(orth_c, W * B.maxL * 4);
   AL(pose_0, W * 77); AL(sb_0, W * 99); AL(ex_0, W * 7); AL(invd_0, W * B.maxP); AL(plk_0, W * B.maxL * 6);
-  AL(plk, W * B.maxL * 6); AL(gauge, W * 4); AL(fail_ref, W * 13);
+  AL(plk, W * B.maxL * 6); AL(gauge, W * 4); AL(fail_ref, W * 13); AL(orth_in, W);
   AL(nP, W); AL(nL, W);
   AL(pt_start, W * B.maxP); AL(pt_nobs, W * B.maxP); AL(pt_off, W * B.maxP); AL(pt_obs, W * B.maxPO * 3);
   AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1)); AL(pu_tab, W * B.maxPU * 4); AL(pu_cnt, W);
@@ -403,7 +403,8 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
   std::vector<DevPreint> pre(W * NF);
-  std::vector<double> fail_ref(W * 13, 0.0);
+  std::vector<double> fail_ref(W * 13, 0.0), orth(W * B.maxL * 4, 0.0);
+  std::vector<int> orth_in(W, 0);
   std::vector<int> pr_n(W, 0), pr_nb(W, 0), pr_kind(W * MAXPB, 0), pr_frame(W * MAXPB, 0), pr_idx(W * MAXPB, 0);
   std::vector<double> pr_x0(W * MAXPB * 9, 0.0), pr_r0(W * MAXPN, 0.0);
   std::vector<int> mg_n(W, 0), mg_nb(W, 0), mg_kind(W * MAXPB, 0), mg_frame(W * MAXPB, 0), mg_idx(W * MAXPB, 0),
@@ -497,7 +498,8 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
         const size_t dl = w * B.maxL + nl;
         ln_start[dl] = s; ln_nobs[dl] = no; ln_off[dl] = off; ln_tri[dl] = tri_flag;
         std::memcpy(&ln_obs[(w * B.maxLO + off) * 8], v.line_obs + (size_t)woff * 8, (size_t)no * 8 * 8);
-        std::memcpy(&plk[dl * 6], v.line_plk + (size_t)l * 6, 6 * 8);
+        if (v.line_orth) std::memcpy(&orth[dl * 4], v.line_orth + (size_t)l * 4, 4 * 8);
+        else std::memcpy(&plk[dl * 6], v.line_plk + (size_t)l * 6, 6 * 8);
         for (int k = 0; k < no; ++k) lo_ln[w * B.maxLO + off + k] = nl;
         off += no;
         lmap.push_back(l);
@@ -506,6 +508,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       woff += no;
     }
     nL[w] = nl;
+    orth_in[w] = v.line_orth ? 1 : 0;
     c->h_nL[w] = nl;
     nLO[w] = off;
     for (int j = 0; j < NF; ++j) to_dev_preint(v.preint[j], pre[w * NF + j]);
@@ -560,7 +563,8 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     if (c->marg_smem > 159 * 1024) return fail(c, VPL_E_CAPACITY, "marginalisation workspace exceeds LDS");
   }
   HIPCHK(c, up(c, B.pose, pose)); HIPCHK(c, up(c, B.sb, sb)); HIPCHK(c, up(c, B.ex, ex)); HIPCHK(c, up(c, B.invd, invd));
-  HIPCHK(c, up(c, B.plk, plk)); HIPCHK(c, up(c, B.fail_ref, fail_ref));
+  HIPCHK(c, up(c, B.plk, plk)); HIPCHK(c, up(c, B.fail_ref, fail_ref)); HIPCHK(c, up(c, B.orth_in, orth_in));
+  HIPCHK(c, up(c, B.orth, orth));
   HIPCHK(c, up(c, B.pose_0, pose)); HIPCHK(c, up(c, B.sb_0, sb)); HIPCHK(c, up(c, B.ex_0, ex)); HIPCHK(c, up(c, B.invd_0, invd));
   HIPCHK(c, up(c, B.plk_0, plk));
   HIPCHK(c, up(c, B.nP, nP)); HIPCHK(c, up(c, B.nL, nL));
