@@ -25,5 +25,5 @@ for w in (0, 1, 300):
     print("   cholesky split: update(a) %d diag(b) %d (16 steps alone: %d) trsm(c) %d" % (s[40], s[41], s[43], s[42]))
     print("   point phase (thread 0, 5 rounds): factor math %d staging+mfma %d atomics %d" % (s[48], s[49], s[50]))
     print("   line phase (thread 0): ctx %d math %d atomics %d ext-reduce %d" % (s[44], s[45], s[46], s[47]))
-    print("   k_lin: prior %d imu %d zero %d points %d lines+out %d assemble %d" % (s[18]-s[16], s[22]-s[24], s[23]-s[18], s[24]-s[23], s[20]-s[22], s[21]-s[20]))
+    print("   k_lin: prior %d zero %d points %d lines+fold %d imu %d assemble %d" % (s[18]-s[16], s[23]-s[18], s[24]-s[23], s[25]-s[22], s[20]-s[25], s[21]-s[20]))
     print("   k_marg: setup+Ad %d landmark-elim %d E15 %d schur %d G-factor %d out %d" % (s[33]-s[32], 0, s[34]-s[33], s[35]-s[34], s[36]-s[35], s[37]-s[36]))

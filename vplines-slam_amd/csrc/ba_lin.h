@@ -14,7 +14,14 @@ typedef double v4d_lin __attribute__((ext_vector_type(4)));
 constexpr int LIN_THREADS = 512;
 constexpr int STG_LD = 21;                // row stride of the MFMA staging tiles (odd: the 16 writer lanes spread over the banks)
 constexpr int LIN_STAGE = 8 * 32 * STG_LD;   // MFMA staging of the point phase (doubles)
+constexpr int LIN_HW = 720;               // wave-private partial sums of the line phase: 11 x (21 + 36 + 6) + 21 + 6 doubles
 constexpr int PREP_NMAX = 112;            // prior dims staged in LDS by k_prep (larger priors read HBM/L2); 10 x 675 + 112^2 doubles = 151 KB
+__host__ __device__ constexpr int lin_stage_doubles(int maxL) {   // MFMA staging | line partial sums + per-track sums | IMU
+  const int ln = 8 * LIN_HW + 38 * maxL;                 // line phase
+  const int pt = LIN_STAGE + 78 * 36 + NV;               // point phase: MFMA tiles + the second commit chain's Hessian copy
+  const int m = ln > pt ? ln : pt;
+  return m > 4650 ? m : 4650;
+}
 constexpr int PREP_THREADS = 640;         // ten waves: one IMU factor each, all ten in one round
 // per-wave scratch of the whitening (3 x 225) + the staged prior J0 of the batch's largest prior (capped at PREP_NMAX)
 inline size_t prep_smem(int max_prior_n) {
@@ -140,23 +147,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(DevBatch B, int nstage) {
 }
 
 // ---------------------------------------------------------------------------------------
-// helpers accumulating J_a^T J_b (2 residual rows, 6-wide blocks) into the LDS vis Hessian
-__device__ __forceinline__ void acc_off(double* Hv, int ba, int bb, const double* Ja, const double* Jb) {
-  // block row ba > block col bb
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) lds_add(&Hv[(6 * ba + r) * NV + 6 * bb + c], Ja[r] * Jb[c] + Ja[6 + r] * Jb[6 + c]);
-}
-__device__ __forceinline__ void acc_diag(double* Hv, int ba, const double* Ja) {
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c <= r; ++c) lds_add(&Hv[(6 * ba + r) * NV + 6 * ba + c], Ja[r] * Ja[c] + Ja[6 + r] * Ja[6 + c]);
-}
-__device__ __forceinline__ void acc_g(double* gv, int ba, const double* Ja, const double* r) {
-#pragma unroll
-  for (int c = 0; c < 6; ++c) lds_add(&gv[6 * ba + c], Ja[c] * r[0] + Ja[6 + c] * r[1]);
+// The vis Hessian in LDS: lower block triangle of 12 x 12 blocks of 6 x 6 (frames 0..10, extrinsic), every block stored
+// full -- 78 blocks = 2808 doubles instead of the 72 x 72 square.  Entry (r, c), r >= c in vis indices:
+constexpr int HV_DOUBLES = 78 * 36;
+__device__ __forceinline__ int hvi(int r, int c) {
+  const int br = r / 6, bc = c / 6;
+  return 36 * (br * (br + 1) / 2 + bc) + 6 * (r - 6 * br) + (c - 6 * bc);
 }
 
 // MODE 0: solve linearisation; 1: MARGIN_OLD assembly (prior + IMU(0,1) + landmarks that start in frame 0);
@@ -172,16 +168,16 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     count_active(B, 0);
   }
   if (PRIOR_ONLY && B.mg_n[w] == 0) return;
-  double* Hv = sm;                 // NV*NV, lower triangle used
-  double* gv = Hv + NV * NV;       // NV
+  double* Hv = sm;                 // HV_DOUBLES, see hvi()
+  double* gv = Hv + HV_DOUBLES;    // NV
   double* xp = gv + NV;            // 12*7 poses + ex
   double* xs = xp + 84;            // 11*9
-  // [imuJ | imur | lacc] is one region: the point phase (which runs before the IMU and line phases)
-  // uses it as MFMA staging space (8 waves x 32 rows x 20 doubles)
+  // [imuJ | imur] is one region with three tenants in turn: the MFMA staging of the point phase (8 waves x 32 rows x 20
+  // doubles), the wave-private partial sums + per-track accumulators of the line phase (8 x LIN_HW + 38 maxL), the whitened
+  // IMU Jacobians (the assembly reads them)
   double* imuJ = xs + 99;          // 10*450 whitened Jacobians
   double* imur = imuJ + 4500;      // 10*15 whitened residuals
-  double* lacc = imur + 150;       // maxL * 38 per-line accumulators
-  const int stg_doubles = max(LIN_STAGE, 4650 + 38 * B.maxL);
+  const int stg_doubles = lin_stage_doubles(B.maxL);
   double* prr = imuJ + stg_doubles;  // MAXPN prior residual
   double* prdx = prr + MAXPN;      // MAXPN
   double* prg = prdx + MAXPN;      // MAXPN  J0^T r
@@ -189,15 +185,17 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   double* pacc = red + 18;         // maxP x 14: per-track sums over its factors  H_ll | g_l | W_s (6) | W_ext (6)
   int* invmap = (int*)(pacc + 14 * B.maxP);  // NC
   int* imuact = invmap + NC;       // 10
+  int* tick = imuact + 10;         // 3 ticket counters of the point phase's ordered LDS commits
 
   const int nP = B.nP[w], nL = B.nL[w];
   // the marginalisation evaluates every block, constant or not (marginalization_factor.cpp:3-69)
   const bool ex_free = MARG || B.opt.estimate_extrinsic != 0;
-  for (int i = tid; i < NV * NV + NV; i += T) sm[i] = 0.0;
+  for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] = 0.0;
   for (int i = tid; i < 14 * nP; i += T) pacc[i] = 0.0;
   for (int i = tid; i < 84; i += T) xp[i] = i < 77 ? B.pose[(size_t)w * 77 + i] : B.ex[(size_t)w * 7 + (i - 77)];
   for (int i = tid; i < 99; i += T) xs[i] = B.sb[(size_t)w * 99 + i];
   for (int i = tid; i < NC; i += T) invmap[i] = -1;
+  if (tid < 3) tick[tid] = 0;
   __syncthreads();
   double cost = 0.0;
   VPL_STAMP(B, w, 16);
@@ -281,7 +279,30 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     const int* pu = B.pu_tab + (size_t)w * B.maxPU * 4;    // (s, first index in plist, tracks, k) per unit
     double* stg = imuJ + wvi * (32 * STG_LD);              // this wave's staging tile: 32 rows x 20 (stride STG_LD)
     const int m16 = lane & 15, kk = lane >> 4;
-    for (int u0 = 4 * wvi; u0 < nU; u0 += 4 * nwv) {
+    // Every accumulator of this phase is shared by all waves, and floating-point addition does not associate: the adds are
+    // therefore committed IN WAVE ORDER: wave v of (round, quarter) waits for its ticket (tick[1]), adds its Hessian tile
+    // (and, in the first quarter, the per-track sums of its four units), passes the ticket on.  The factor math and the
+    // matrix-core reductions of the other waves go on meanwhile; what is serialised is ~25 LDS instructions per quarter.
+    // All waves run the same number of rounds (empty units included) so that the ticket sequence is complete.
+    const int nRounds = (nU + 4 * nwv - 1) / (4 * nwv);
+    // Two commit chains run side by side: waves 0..3 add into Hv / gv, waves 4..7 into a second copy that lives in the
+    // part of the staging region the MFMA tiles leave free; the copy is folded into Hv after the phase.  The per-track
+    // sums have one chain over all eight waves (tick[0]).
+    const int half = wvi >= nwv / 2 ? 1 : 0, wih = wvi - half * (nwv / 2);
+    double* HvC = half ? imuJ + LIN_STAGE : Hv;
+    double* gvC = half ? imuJ + LIN_STAGE + HV_DOUBLES : gv;
+    if (half) for (int i = tid - T / 2; i < HV_DOUBLES + NV; i += T / 2) imuJ[LIN_STAGE + i] = 0.0;
+    __syncthreads();
+    auto ticket_wait = [&](int which, int seq) {
+      while (__hip_atomic_load(&tick[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) {}
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto ticket_pass = [&](int which, int seq) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&tick[which], seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    for (int round = 0; round < nRounds; ++round) {
+      const int u0 = 4 * nwv * round + 4 * wvi;
       const int u = u0 + kk;
       const bool has = u < nU;
       const int s = has ? pu[4 * u] : 0, k = has ? pu[4 * u + 3] : 1, ucnt = has ? pu[4 * u + 2] : 0;
@@ -292,7 +313,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
       const bool act = live && k < no;
       const int j = s + k;
       double* Wrow = B.Wp + pi * WS;
-      double r[2] = {0, 0}, Ji[12], Jj[12], Je[12];
+      double r[2] = {0, 0}, Ji[12], Jj[12], Je[12], pv[14];
 #pragma unroll
       for (int q = 0; q < 12; ++q) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
       if (act) {
@@ -311,13 +332,12 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #pragma unroll
           for (int q = 0; q < 12; ++q) Je[q] = 0.0;
         }
-        double* pa = pacc + 14 * p;
-        lds_add(&pa[0], Jl[0] * Jl[0] + Jl[1] * Jl[1]);
-        lds_add(&pa[1], Jl[0] * r[0] + Jl[1] * r[1]);
+        pv[0] = Jl[0] * Jl[0] + Jl[1] * Jl[1];
+        pv[1] = Jl[0] * r[0] + Jl[1] * r[1];
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-          lds_add(&pa[2 + a], Jl[0] * Ji[a] + Jl[1] * Ji[6 + a]);
-          lds_add(&pa[8 + a], Jl[0] * Je[a] + Jl[1] * Je[6 + a]);
+          pv[2 + a] = Jl[0] * Ji[a] + Jl[1] * Ji[6 + a];
+          pv[8 + a] = Jl[0] * Je[a] + Jl[1] * Je[6 + a];
           Wrow[6 * k + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];   // this (track, frame) entry has one writer
         }
       }
@@ -326,7 +346,21 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #pragma unroll 1
       for (int qq = 0; qq < 4; ++qq) {
         const unsigned qmask = (unsigned)((actmask >> (16 * qq)) & 0xffffull);
-        if (qmask == 0) continue;   // uniform
+        const int seq = (round * 4 + qq) * (nwv / 2) + wih;
+        if (qq == 0) {              // per-track sums over k of the wave's four units (a track's factors sit in different
+          ticket_wait(0, round * nwv + wvi);   // units, i.e. in different waves): one chain over all waves
+          if (act) {
+            double* pa = pacc + 14 * p;        // (two quarters of a wave may hold the same track with different k: atomic adds)
+#pragma unroll
+            for (int a = 0; a < 14; ++a) lds_add(&pa[a], pv[a]);
+          }
+          ticket_pass(0, round * nwv + wvi);
+        }
+        if (qmask == 0) {           // uniform: no tile to add, the ticket still goes round
+          ticket_wait(1 + half, seq);
+          ticket_pass(1 + half, seq);
+          continue;
+        }
         const int sq = __builtin_amdgcn_readlane(s, 16 * qq), jq = __builtin_amdgcn_readlane(j, 16 * qq);
         const int rows = 2 * (32 - __builtin_clz(qmask));   // staged rows that can be non-zero
         __builtin_amdgcn_wave_barrier();
@@ -356,7 +390,8 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
           c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, c10, 0, 0, 0);
           c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, c11, 0, 0, 0);
         }
-        // accumulator entry (row a = kk + 4 v (+16), col b = m16 (+16)) -> LDS Hessian / gradient
+        // accumulator entry (row a = kk + 4 v (+16), col b = m16 (+16)) -> LDS Hessian / gradient, in wave order
+        ticket_wait(1 + half, seq);
         {
           const double v00[4] = {c00.x, c00.y, c00.z, c00.w}, v10[4] = {c10.x, c10.y, c10.z, c10.w},
                        v11[4] = {c11.x, c11.y, c11.z, c11.w};
@@ -364,21 +399,23 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int a0 = kk + 4 * v, bcol = m16;
-            if (a0 >= bcol) lds_add(&Hv[visof(a0) * NV + visof(bcol)], v00[v]);
+            if (a0 >= bcol) lds_add(&HvC[hvi(visof(a0), visof(bcol))], v00[v]);
             const int a1 = 16 + kk + 4 * v;
-            if (a1 < 18) lds_add(&Hv[visof(a1) * NV + visof(bcol)], v10[v]);
-            else if (a1 == 18) lds_add(&gv[visof(bcol)], v10[v]);
+            if (a1 < 18) lds_add(&HvC[hvi(visof(a1), visof(bcol))], v10[v]);
+            else if (a1 == 18) lds_add(&gvC[visof(bcol)], v10[v]);
             const int b1c = 16 + m16;
             if (b1c < 18) {
-              if (a1 < 18 && a1 >= b1c) lds_add(&Hv[visof(a1) * NV + visof(b1c)], v11[v]);
-              else if (a1 == 18) lds_add(&gv[visof(b1c)], v11[v]);
+              if (a1 < 18 && a1 >= b1c) lds_add(&HvC[hvi(visof(a1), visof(b1c))], v11[v]);
+              else if (a1 == 18) lds_add(&gvC[visof(b1c)], v11[v]);
             }
           }
         }
+        ticket_pass(1 + half, seq);
       }
     }
   }
   __syncthreads();
+  for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] += imuJ[LIN_STAGE + i];   // second commit chain's copy (Hv | gv are contiguous)
   for (int p = tid; p < nP; p += T) {   // per-track sums out of LDS
     const size_t pi = (size_t)w * B.maxP + p;
     const double* pa = pacc + 14 * p;
@@ -390,6 +427,161 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   }
   __syncthreads();   // staging space is handed over to the IMU / line phases
   VPL_STAMP(B, w, 24);
+  VPL_STAMP(B, w, 22);
+  // ---- lines -----------------------------------------------------------------------------------------------------
+  // One lane per (track, observation), laid out by the host table ll_tab: every wave holds WHOLE tracks, k-major --
+  // lane = k * NLW + i for observation k of the wave's i-th line.  Every LDS accumulator of this phase is touched by ONE
+  // wave only: the per-track sums lacc[l] (H4 | g4 | W_ext) because a track lives in one wave, the pose / extrinsic
+  // blocks because each wave adds into its PRIVATE partial sums Hw (LIN_HW doubles per wave), folded into the LDS
+  // Hessian in fixed order after the phase.  The adds of one wave reach the LDS in program order (and the lanes of one
+  // instruction in lane order), so the sums -- and with them the whole solve -- are the same bits on every run; the
+  // cross-wave ds_add_f64 of round 1 made two solves of identical inputs differ by 1e-9 .. 1e-6 m.
+  {
+    const int NLW = B.llNLW, KL = B.llK;
+    const int wvi = tid >> 6;
+    double* Hw = imuJ + wvi * LIN_HW;
+    double* lacc = imuJ + 8 * LIN_HW;                    // maxL * 38 per-track accumulators
+    for (int i = lane; i < LIN_HW; i += 64) Hw[i] = 0.0;
+    for (int i = tid; i < nL * 38; i += T) lacc[i] = 0.0;
+    __syncthreads();
+    const int* ltab = B.ll_tab + (size_t)w * B.llSlots;
+    const int npass = B.ll_np[w];
+    const int krow = lane / NLW;                         // observation index of this lane's slot
+    for (int pass = 0; pass < npass; ++pass) {
+      const int o = (!PRIOR_ONLY && krow < KL) ? ltab[pass * T + tid] : -1;
+      const bool inb = o >= 0;
+      const int l = inb ? B.lo_ln[(size_t)w * B.maxLO + o] : 0;
+      const size_t li = (size_t)w * B.maxL + l;
+      const int s = B.ln_start[li], off = B.ln_off[li];
+      const int k = inb ? o - off : 0, j = s + k;
+      // MARG: start-frame obs skipped (estimator.cpp:1322-1326), erased lines are no longer in f_manager.linefeature
+      const bool act = inb && (!MARG || (s == 0 && k >= 1 && !B.ln_removed[li]));
+      const double* ob = B.ln_obs + ((size_t)w * B.maxLO + (inb ? o : 0)) * 8;
+      LineCtx c;
+      if (act) c = line_ctx(xp + 7 * j, xe, B.orth + li * 4);
+      double Wj[24];
+#pragma unroll
+      for (int q = 0; q < 24; ++q) Wj[q] = 0.0;
+      double* la = lacc + l * 38;
+      double* Hf = Hw + 63 * (act ? j : 0);
+#pragma unroll
+      for (int fct = 0; fct < 2; ++fct) {
+        // VP factor only in the solve and only when flagged (estimator.cpp:1153, :1341-1351)
+        const bool fa = act && (fct == 0 || (!MARG && ob[7] == 1.0));
+        double r[2] = {0, 0}, Je[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) Je[q] = 0.0;
+        if (fa) {
+          double jel[6], Jp[12], Jo[8];
+          if (fct == 0) line_factor_res(c, ob, B.opt.sqrt_info_line, r, jel);
+          else vp_factor_res(c, ob + 4, B.opt.sqrt_info_vp, r, jel);
+          line_chain_jac(c, jel, fct, Jp, Je, Jo);
+          double sc;
+          cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
+          r[0] *= sc; r[1] *= sc;
+#pragma unroll
+          for (int q = 0; q < 12; ++q) { Jp[q] *= sc; Je[q] *= sc; }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) Jo[q] *= sc;
+          if (!ex_free) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) Je[q] = 0.0;
+          }
+          int t = 0;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            lds_add(&la[10 + a], Jo[a] * r[0] + Jo[4 + a] * r[1]);
+#pragma unroll
+            for (int c2 = 0; c2 <= a; ++c2, ++t) lds_add(&la[t], Jo[a] * Jo[c2] + Jo[4 + a] * Jo[4 + c2]);
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2) {
+              Wj[6 * a + c2] += Jo[a] * Jp[c2] + Jo[4 + a] * Jp[6 + c2];
+              lds_add(&la[14 + 6 * a + c2], Jo[a] * Je[c2] + Jo[4 + a] * Je[6 + c2]);
+            }
+          }
+          // blocks (j, j), (ext, j), g_j of this wave's partial sums
+          t = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int c2 = 0; c2 <= a; ++c2, ++t) lds_add(&Hf[t], Jp[a] * Jp[c2] + Jp[6 + a] * Jp[6 + c2]);
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2) lds_add(&Hf[21 + 6 * a + c2], Je[a] * Jp[c2] + Je[6 + a] * Jp[6 + c2]);
+            lds_add(&Hf[57 + a], Jp[a] * r[0] + Jp[6 + a] * r[1]);
+          }
+        }
+        // extrinsic block: every factor touches it.  DPP row_shr sums inside each row of 16 lanes (VALU only), then the four
+        // row leaders add to the wave's partial sums
+        {
+          const bool leader = (lane & 15) == 15;
+          int t = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            const double gev = row_sum16(Je[a] * r[0] + Je[6 + a] * r[1]);
+            if (leader) lds_add(&Hw[714 + a], gev);
+#pragma unroll
+            for (int c2 = 0; c2 <= a; ++c2, ++t) {
+              const double v = row_sum16(Je[a] * Je[c2] + Je[6 + a] * Je[6 + c2]);
+              if (leader) lds_add(&Hw[693 + t], v);
+            }
+          }
+        }
+      }
+      if (act) {
+        double* Wl = B.Wl + li * 4 * WS;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int c2 = 0; c2 < 6; ++c2) Wl[a * WS + 6 * k + c2] = Wj[6 * a + c2];
+      }
+    }
+  }
+  __syncthreads();
+  // per-line results out of the LDS accumulators
+  {
+    const double* lacc = imuJ + 8 * LIN_HW;
+    for (int l = tid; l < nL; l += T) {
+      const size_t li = (size_t)w * B.maxL + l;
+      const double* la = lacc + l * 38;
+      double* Hl = B.Hll + li * 16;
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        B.gl[li * 4 + a] = la[10 + a];
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2, ++t) { Hl[4 * a + c2] = la[t]; Hl[4 * c2 + a] = la[t]; }
+#pragma unroll
+        for (int c2 = 0; c2 < 6; ++c2) B.Wl[(li * 4 + a) * WS + WS - 6 + c2] = la[14 + 6 * a + c2];
+      }
+    }
+  }
+  // fold the eight partial sums into the LDS Hessian / gradient, one thread per entry, waves in order
+  for (int e = tid; e < LIN_HW; e += T) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += imuJ[q * LIN_HW + e];
+    if (e < 693) {
+      const int f = e / 63, q = e - 63 * f;
+      if (q < 21) {
+        int a, c2;
+        tri_decode(q, a, c2);
+        Hv[hvi(6 * f + a, 6 * f + c2)] += v;
+      } else if (q < 57) {
+        const int a = (q - 21) / 6, c2 = (q - 21) % 6;
+        Hv[hvi(66 + a, 6 * f + c2)] += v;
+      } else {
+        gv[6 * f + (q - 57)] += v;
+      }
+    } else if (e < 714) {
+      int a, c2;
+      tri_decode(e - 693, a, c2);
+      Hv[hvi(66 + a, 66 + c2)] += v;
+    } else {
+      gv[66 + (e - 714)] += v;
+    }
+  }
+  __syncthreads();   // the staging region goes to the IMU phase
+  VPL_STAMP(B, w, 25);
   // ---- IMU factors: raw residual / Jacobian per factor, then cooperative whitening ------
   if (tid < 10) {
     const int j = tid + 1;
@@ -437,131 +629,6 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     cost += 0.5 * s;
   }
 
-  for (int i = tid; i < nL * 38; i += T) lacc[i] = 0.0;
-  __syncthreads();
-  VPL_STAMP(B, w, 22);
-  // lines: one lane per (track, observation); per-track sums in the LDS accumulators lacc[l][38]
-  //        = H4 (10, packed lower) | g4 (4) | W_ext (4 x 6)
-  {
-    const int nLO = B.nLO[w];
-    const int* lo_ln = B.lo_ln + (size_t)w * B.maxLO;
-    for (int o0 = 0; o0 < nLO; o0 += T) {
-      const int o = o0 + tid;
-      const bool inb = o < nLO;
-      const int l = inb ? lo_ln[o] : 0;
-      const size_t li = (size_t)w * B.maxL + l;
-      const int s = B.ln_start[li], off = B.ln_off[li];
-      const int k = o - off, j = s + k;
-      // MARG: start-frame obs skipped (estimator.cpp:1322-1326), erased lines are no longer in f_manager.linefeature
-      const bool act = inb && !PRIOR_ONLY && (!MARG || (s == 0 && k >= 1 && !B.ln_removed[li]));
-      const double* ob = B.ln_obs + ((size_t)w * B.maxLO + (inb ? o : 0)) * 8;
-#ifdef VPL_STAMPS
-      long long lt0 = __builtin_readcyclecounter(), lt_ctx = 0, lt_math = 0, lt_atom = 0, lt_ext = 0;
-#endif
-      LineCtx c;
-      if (act) c = line_ctx(xp + 7 * j, xe, B.orth + li * 4);
-#ifdef VPL_STAMPS
-      { const long long t = __builtin_readcyclecounter(); lt_ctx += t - lt0; lt0 = t; }
-#endif
-      double Wj[24];
-#pragma unroll
-      for (int q = 0; q < 24; ++q) Wj[q] = 0.0;
-      double* la = lacc + l * 38;
-#pragma unroll
-      for (int fct = 0; fct < 2; ++fct) {
-        // VP factor only in the solve and only when flagged (estimator.cpp:1153, :1341-1351)
-        const bool fa = act && (fct == 0 || (!MARG && ob[7] == 1.0));
-        double r[2] = {0, 0}, Je[12];
-#pragma unroll
-        for (int q = 0; q < 12; ++q) Je[q] = 0.0;
-        if (fa) {
-          double jel[6], Jp[12], Jo[8];
-          if (fct == 0) line_factor_res(c, ob, B.opt.sqrt_info_line, r, jel);
-          else vp_factor_res(c, ob + 4, B.opt.sqrt_info_vp, r, jel);
-          line_chain_jac(c, jel, fct, Jp, Je, Jo);
-          double sc;
-          cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
-          r[0] *= sc; r[1] *= sc;
-#pragma unroll
-          for (int q = 0; q < 12; ++q) { Jp[q] *= sc; Je[q] *= sc; }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) Jo[q] *= sc;
-          if (!ex_free) {
-#pragma unroll
-            for (int q = 0; q < 12; ++q) Je[q] = 0.0;
-          }
-#ifdef VPL_STAMPS
-          { const long long tt = __builtin_readcyclecounter(); lt_math += tt - lt0; lt0 = tt; }
-#endif
-          int t = 0;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            lds_add(&la[10 + a], Jo[a] * r[0] + Jo[4 + a] * r[1]);
-#pragma unroll
-            for (int c2 = 0; c2 <= a; ++c2, ++t) lds_add(&la[t], Jo[a] * Jo[c2] + Jo[4 + a] * Jo[4 + c2]);
-#pragma unroll
-            for (int c2 = 0; c2 < 6; ++c2) {
-              Wj[6 * a + c2] += Jo[a] * Jp[c2] + Jo[4 + a] * Jp[6 + c2];
-              lds_add(&la[14 + 6 * a + c2], Jo[a] * Je[c2] + Jo[4 + a] * Je[6 + c2]);
-            }
-          }
-          acc_diag(Hv, j, Jp);
-          acc_off(Hv, 11, j, Je, Jp);
-          acc_g(gv, j, Jp, r);
-#ifdef VPL_STAMPS
-          { const long long tt = __builtin_readcyclecounter(); lt_atom += tt - lt0; lt0 = tt; }
-#endif
-        }
-#ifdef VPL_STAMPS
-        lt0 = __builtin_readcyclecounter();
-#endif
-        // extrinsic block: every factor touches it.  Reduction over the wave in two levels: DPP row_shr inside each row of
-        // 16 lanes (VALU only), then the four row leaders add to the LDS Hessian (4-way same-address atomics instead of six
-        // bpermute levels per value)
-        {
-          const bool leader = (lane & 15) == 15;
-#pragma unroll
-          for (int a = 0; a < 6; ++a) {
-            const double gev = row_sum16(Je[a] * r[0] + Je[6 + a] * r[1]);
-            if (leader) lds_add(&gv[66 + a], gev);
-#pragma unroll
-            for (int c2 = 0; c2 <= a; ++c2) {
-              const double v = row_sum16(Je[a] * Je[c2] + Je[6 + a] * Je[6 + c2]);
-              if (leader) lds_add(&Hv[(66 + a) * NV + 66 + c2], v);
-            }
-          }
-        }
-      }
-#ifdef VPL_STAMPS
-      { const long long tt = __builtin_readcyclecounter(); lt_ext += tt - lt0; lt0 = tt; }
-      if (tid == 0) { B.dbg[(size_t)w * 64 + 44] = lt_ctx; B.dbg[(size_t)w * 64 + 45] = lt_math; B.dbg[(size_t)w * 64 + 46] = lt_atom; B.dbg[(size_t)w * 64 + 47] = lt_ext; }
-#endif
-      if (act) {
-        double* Wl = B.Wl + li * 4 * WS;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int c2 = 0; c2 < 6; ++c2) Wl[a * WS + 6 * k + c2] = Wj[6 * a + c2];
-      }
-    }
-  }
-  __syncthreads();
-  // per-line results out of the LDS accumulators
-  for (int l = tid; l < nL; l += T) {
-    const size_t li = (size_t)w * B.maxL + l;
-    const double* la = lacc + l * 38;
-    double* Hl = B.Hll + li * 16;
-    int t = 0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      B.gl[li * 4 + a] = la[10 + a];
-#pragma unroll
-      for (int c2 = 0; c2 <= a; ++c2, ++t) { Hl[4 * a + c2] = la[t]; Hl[4 * c2 + a] = la[t]; }
-#pragma unroll
-      for (int c2 = 0; c2 < 6; ++c2) B.Wl[(li * 4 + a) * WS + WS - 6 + c2] = la[14 + 6 * a + c2];
-    }
-  }
-  __syncthreads();
 
   VPL_STAMP(B, w, 20);
   // ---- assemble the packed cam Hessian and gradient in HBM -----------------------------------
@@ -582,7 +649,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
         double v = 0.0;
         if (vr >= 0 && !dead) {
           const int vc = cam2vis(c);
-          if (vc >= 0) v = Hv[vr * NV + vc];
+          if (vc >= 0) v = Hv[hvi(vr, vc)];
         }
         row[c] = v;
       }
@@ -691,8 +758,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
 }
 
 inline size_t lin_smem(int maxP, int maxL) {
-  const int stg = LIN_STAGE > 4650 + 38 * maxL ? LIN_STAGE : 4650 + 38 * maxL;
-  return (size_t)(NV * NV + NV + 84 + 99 + stg + 3 * MAXPN + 18 + 14 * maxP) * sizeof(double) + (size_t)(NC + 12) * sizeof(int);
+  return (size_t)(HV_DOUBLES + NV + 84 + 99 + lin_stage_doubles(maxL) + 3 * MAXPN + 18 + 14 * maxP) * sizeof(double) + (size_t)(NC + 16) * sizeof(int);
 }
 
 }  // namespace vpl

@@ -5,6 +5,7 @@
 // HIP kernels and reports VPL_E_NODEVICE / VPL_E_HIP when that is impossible.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -189,6 +190,8 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1)); AL(pu_tab, W * B.maxPU * 4); AL(pu_cnt, W);
   AL(ln_start, W * B.maxL); AL(ln_nobs, W * B.maxL); AL(ln_off, W * B.maxL); AL(ln_obs, W * B.maxLO * 8);
   AL(nLO, W); AL(lo_ln, W * B.maxLO);
+  B.llSlots = 512 * ((B.maxL + 8 * (64 / NF) - 1) / (8 * (64 / NF)));   // worst case: 11-frame tracks, 5 lines per wave
+  AL(ll_tab, W * B.llSlots); AL(ll_np, W);
   AL(pre, W * NF);
   AL(pr_n, W); AL(pr_nb, W); AL(pr_kind, W * MAXPB); AL(pr_frame, W * MAXPB); AL(pr_idx, W * MAXPB);
   AL(pr_x0, W * MAXPB * 9); AL(pr_J0, W * MAXPN * MAXPN); AL(pr_r0, W * MAXPN); AL(pr_H, W * MAXPN * MAXPN); AL(pr_g0, W * MAXPN);
@@ -399,7 +402,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   std::vector<int> nP(W), nL(W), pt_start(W * B.maxP, 0), pt_nobs(W * B.maxP, 0), pt_off(W * B.maxP, 0);
   std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0), ln_tri(W * B.maxL, 1);
   std::vector<int> pu_tab(W * B.maxPU * 4, 0), pu_cnt(W, 0);
-  std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0);
+  std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0), ll_tab(W * B.llSlots, -1), ll_np(W, 0);
   std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
   std::vector<DevPreint> pre(W * NF);
@@ -434,6 +437,11 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     }
     maxTrack = std::min(maxTrack, (int)NF);
     B.WS = 6 * maxTrack + 6;
+    int maxLineTrack = 1;
+    for (size_t w = 0; w < W; ++w)
+      for (int l = 0; l < win[w].n_lines; ++l) maxLineTrack = std::max(maxLineTrack, std::min(win[w].line_nobs[l], (int)NF));
+    B.llK = maxLineTrack;
+    B.llNLW = 64 / maxLineTrack;
     B.wfill = (minTrack != maxTrack || opt->remove_line_outliers) ? 1 : 0;
   }
 
@@ -508,6 +516,19 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       woff += no;
     }
     nL[w] = nl;
+    {   // lane layout of the line phase: llNLW whole tracks per wave, k-major; tracks in the caller's order (tracks that start
+        // in the same frame side by side would pile their LDS adds onto the same addresses)
+      std::vector<int> ord(nl);
+      for (int i = 0; i < nl; ++i) ord[i] = i;
+      const int NLW = B.llNLW, perPass = 8 * NLW;
+      ll_np[w] = (nl + perPass - 1) / perPass;
+      if (ll_np[w] * 512 > B.llSlots) return fail(c, VPL_E_CAPACITY, "line layout table too small");
+      for (int q = 0; q < nl; ++q) {
+        const int dl = ord[q], pass = q / perPass, wave = (q % perPass) / NLW, i = q % NLW;
+        const int no = std::min(ln_nobs[w * B.maxL + dl], (int)NF);
+        for (int k = 0; k < no; ++k) ll_tab[w * B.llSlots + pass * 512 + wave * 64 + k * NLW + i] = ln_off[w * B.maxL + dl] + k;
+      }
+    }
     orth_in[w] = v.line_orth ? 1 : 0;
     c->h_nL[w] = nl;
     nLO[w] = off;
@@ -575,6 +596,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
   HIPCHK(c, up(c, B.ln_obs, ln_obs)); HIPCHK(c, up(c, B.ln_tri, ln_tri));
   HIPCHK(c, up(c, B.nLO, nLO)); HIPCHK(c, up(c, B.lo_ln, lo_ln));
+  HIPCHK(c, up(c, B.ll_tab, ll_tab)); HIPCHK(c, up(c, B.ll_np, ll_np));
   HIPCHK(c, up(c, B.pre, pre));
   HIPCHK(c, up(c, B.pr_n, pr_n)); HIPCHK(c, up(c, B.pr_nb, pr_nb)); HIPCHK(c, up(c, B.pr_kind, pr_kind));
   HIPCHK(c, up(c, B.pr_frame, pr_frame)); HIPCHK(c, up(c, B.pr_idx, pr_idx)); HIPCHK(c, up(c, B.pr_x0, pr_x0));
