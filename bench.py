@@ -44,7 +44,7 @@ def algorithmic_bytes(P, L, n_prior, obs_p, obs_l):
     return dict(iteration=reads + writes, k_lin=k_lin, k_solve=k_solve, k_solve_reuse=k_solve_reuse, k_cost=k_cost)
 
 
-def pmc_traffic(kernel, nW, P, L):
+def pmc_traffic(kernel, nW, P, L, which="total"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/pmc_traffic.json, produced by
     tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this very command at the default workload,
     corrected as MI355X_MICROARCH.md prescribes).  None when the workload differs from the profiled one."""
@@ -56,7 +56,7 @@ def pmc_traffic(kernel, nW, P, L):
         return None
     k = json.load(open(files[-1])).get("kernels", {})
     key = {"k_lin": "k_lin<0>"}.get(kernel, kernel)
-    return k[key]["total"] if key in k else None
+    return k[key].get(which) if key in k else None
 
 
 def spawn_ranks(args):
@@ -173,7 +173,8 @@ def roofline_from_profile(prof, ab, nW, P, L):
         if e["heavy"]:
             h = e["heavy"]
             hg = h["bytes"] / (h["ms"] * 1e-3) / 1e9
-            table[k]["heavy_launch"] = {"ms": h["ms"], "windows": h["windows"], "GBps": hg, "frac": hg / HBM_PEAK_GBS}
+            table[k]["heavy_launch"] = {"ms": h["ms"], "windows": h["windows"], "algorithmic_bytes": h["bytes"], "GBps": hg,
+                                        "frac": hg / HBM_PEAK_GBS, "traffic": pmc_traffic(k, nW, P, L, "total_max")}
     d = table[dom]
     roof = {"bound": "hbm", "kernel": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
             "traffic": pmc_traffic(dom, nW, P, L), "avg_launch_ms": d["avg_launch_ms"],

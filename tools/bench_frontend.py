@@ -10,7 +10,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.p
 import numpy as np
 import torch
 import vplines_slam_amd as v
-from bench_edlines import frames
+from bench_edlines import frames as _old_frames
+
+
+def frames(n):
+    return v.workload.frame_stream(n)
 
 
 def main():

@@ -8,8 +8,8 @@ OUT=$ROOT/$1
 mkdir -p $OUT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $OUT/calib tools/pmc_calib/calib.hip
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python3 $ROOT/bench.py --steps 3 --warmup 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python3 $ROOT/bench.py --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cf -o cf -- $OUT/calib > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/cw -o cw -- $OUT/calib > /dev/null 2>&1
 cd $ROOT

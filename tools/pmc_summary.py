@@ -10,7 +10,7 @@ def per_kernel(path, counter):
     d = pd.read_csv(path)
     d = d[d["Counter_Name"] == counter]
     d["k"] = d["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("void ", "").str.replace("vpl::", "")
-    return d.groupby("k")["Counter_Value"].agg(["mean", "count"])
+    return d.groupby("k")["Counter_Value"].agg(["mean", "max", "count"])
 
 def main():
     fetch, write, cf, cw, out = sys.argv[1:6]
@@ -27,7 +27,11 @@ def main():
             continue
         rd = F.loc[k, "mean"] * 1024.0 * fetch_scale
         wr = (W.loc[k, "mean"] if k in W.index else 0.0) * 1024.0 * write_scale
-        res["kernels"][k] = {"read": rd, "write": wr, "total": rd + wr, "launches_sampled": int(F.loc[k, "count"])}
+        rdx = F.loc[k, "max"] * 1024.0 * fetch_scale
+        wrx = (W.loc[k, "max"] if k in W.index else 0.0) * 1024.0 * write_scale
+        # mean over all launches of the run (light and heavy ones) and the launch with the most traffic (every window active)
+        res["kernels"][k] = {"read": rd, "write": wr, "total": rd + wr, "read_max": rdx, "write_max": wrx,
+                             "total_max": rdx + wrx, "launches_sampled": int(F.loc[k, "count"])}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
