@@ -188,25 +188,27 @@ struct PreintF {     // the four matrices F and V are made of, and the step
   M3 S1, S2, S3, ImW;
   double dt;
 };
-// y = F x for one column x (15 doubles, blocks of 3: p, theta, v, ba, bg)
-__device__ __forceinline__ void preint_apply_F(const PreintF& f, const double* x, double* y) {
+// x <- F x for one column x (15 doubles, blocks of 3: p, theta, v, ba, bg), in place
+__device__ __forceinline__ void preint_apply_F(const PreintF& f, double* x) {
   const double dt = f.dt;
-  const V3 x0{x[0], x[1], x[2]}, x1{x[3], x[4], x[5]}, x2{x[6], x[7], x[8]}, x3{x[9], x[10], x[11]}, x4{x[12], x[13], x[14]};
+  const V3 x1{x[3], x[4], x[5]}, x2{x[6], x[7], x[8]}, x3{x[9], x[10], x[11]}, x4{x[12], x[13], x[14]};
   const V3 u = mul(f.S3, x1), sv = mul(f.S1, x3), r = mul(f.S2, x4);
-  const V3 y0 = x0 + u * (-0.25 * dt * dt) + x2 * dt + sv * (-0.25 * dt * dt) + r * (-0.25 * dt * dt * -dt);
+  const V3 y0 = V3{x[0], x[1], x[2]} + u * (-0.25 * dt * dt) + x2 * dt + sv * (-0.25 * dt * dt) + r * (-0.25 * dt * dt * -dt);
   const V3 y1 = mul(f.ImW, x1) + x4 * (-1.0 * dt);
   const V3 y2 = u * (-0.5 * dt) + x2 + sv * (-0.5 * dt) + r * (-0.5 * dt * -dt);
-  y[0] = y0.x; y[1] = y0.y; y[2] = y0.z; y[3] = y1.x; y[4] = y1.y; y[5] = y1.z; y[6] = y2.x; y[7] = y2.y; y[8] = y2.z;
-  y[9] = x3.x; y[10] = x3.y; y[11] = x3.z; y[12] = x4.x; y[13] = x4.y; y[14] = x4.z;
+  x[0] = y0.x; x[1] = y0.y; x[2] = y0.z; x[3] = y1.x; x[4] = y1.y; x[5] = y1.z; x[6] = y2.x; x[7] = y2.y; x[8] = y2.z;
 }
-// column / row c of a 3 x 3 matrix by selects (a dynamic index would move the matrix to scratch)
+// column / row c (lane dependent) of a 3 x 3 matrix as a 0/1-weighted sum: exact, and no dynamic index or select on the
+// matrix elements (either one makes the compiler keep the matrix on the stack)
 __device__ __forceinline__ V3 m3col(const M3& A, int c) {
-  return V3{c == 0 ? A.m[0] : c == 1 ? A.m[1] : A.m[2], c == 0 ? A.m[3] : c == 1 ? A.m[4] : A.m[5],
-            c == 0 ? A.m[6] : c == 1 ? A.m[7] : A.m[8]};
+  const double w0 = c == 0 ? 1.0 : 0.0, w1 = c == 1 ? 1.0 : 0.0, w2 = c == 2 ? 1.0 : 0.0;
+  return V3{A.m[0] * w0 + A.m[1] * w1 + A.m[2] * w2, A.m[3] * w0 + A.m[4] * w1 + A.m[5] * w2,
+            A.m[6] * w0 + A.m[7] * w1 + A.m[8] * w2};
 }
 __device__ __forceinline__ V3 m3row(const M3& A, int r) {
-  return V3{r == 0 ? A.m[0] : r == 1 ? A.m[3] : A.m[6], r == 0 ? A.m[1] : r == 1 ? A.m[4] : A.m[7],
-            r == 0 ? A.m[2] : r == 1 ? A.m[5] : A.m[8]};
+  const double w0 = r == 0 ? 1.0 : 0.0, w1 = r == 1 ? 1.0 : 0.0, w2 = r == 2 ? 1.0 : 0.0;
+  return V3{A.m[0] * w0 + A.m[3] * w1 + A.m[6] * w2, A.m[1] * w0 + A.m[4] * w1 + A.m[7] * w2,
+            A.m[2] * w0 + A.m[5] * w1 + A.m[8] * w2};
 }
 
 __global__ __launch_bounds__(64) void k_preintegrate(int n, const int* offset, const int* nsamples, const double* samples,
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(64) void k_preintegrate(int n, const int* offset, c
   const bool live = iv < n;
   const int i = live ? iv : n - 1;            // idle groups shadow the last interval (no stores) so that barriers stay uniform
   const int jc = j < 15 ? j : 14, jb = jc / 3, jj = jc % 3;
-  double Jc[15], Pc[15], T[15];
+  double Jc[15], Pc[15];
 #pragma unroll
   for (int k = 0; k < 15; ++k) { Jc[k] = (k == jc) ? 1.0 : 0.0; Pc[k] = 0.0; }
   V3 dp{0, 0, 0}, dv{0, 0, 0};
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(64) void k_preintegrate(int n, const int* offset, c
   for (int k = 0; k < nmax; ++k) {
     const bool on = k < ns;
     const double* p = sp + 7 * (on ? k : 0);
-    const double dt = p[0];
+    const double dt = on ? p[0] : 0.0;   // a group past its own sample count applies F = I, N = 0 (exact: every term carries dt)
     const V3 a1{p[1], p[2], p[3]}, g1{p[4], p[5], p[6]};
     // midPointIntegration (:54-198)
     const V3 un_acc_0 = qrot(dq, a0 - ba);
@@ -253,54 +255,48 @@ __global__ __launch_bounds__(64) void k_preintegrate(int n, const int* offset, c
     f.S2 = mul(Rr, skew(a1 - ba));                       // Rr [a1 - ba]x
     f.S3 = add(mul(Rq, skew(a0 - ba)), mul(f.S2, f.ImW));
     f.S1 = add(Rq, Rr);
-    // J <- F J ; T = F P
-    double Jn[15];
-    preint_apply_F(f, Jc, Jn);
-    preint_apply_F(f, Pc, T);
+    // J <- F J ; T = F P (both in place; an idle group keeps working on its registers and never stores them)
+    preint_apply_F(f, Jc);
+    preint_apply_F(f, Pc);
     // rows of T through LDS: lane k wrote column k, lane j reads row j
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 15; ++r) tl[r * PREINT_GROUP + j] = T[r];
+    for (int r = 0; r < 15; ++r) tl[r * PREINT_GROUP + j] = Pc[r];
     __syncthreads();
-    double Tr[15], Pn[15];
 #pragma unroll
-    for (int c = 0; c < 15; ++c) Tr[c] = tl[jc * PREINT_GROUP + c];
-    preint_apply_F(f, Tr, Pn);                           // column j of F T^T = column j of (T F^T)^T = column j of P'
-    // + column j of N = V Q V^T (V of :107-125; Q = diag(an2, gn2, an2, gn2, aw2, gw2) x I3)
+    for (int c = 0; c < 15; ++c) Pc[c] = on ? tl[jc * PREINT_GROUP + c] : Pc[c];
+    preint_apply_F(f, Pc);                               // column j of F T^T = column j of (T F^T)^T = column j of P'
+    // + column j of N = V Q V^T (V of :107-125; Q = diag(an2, gn2, an2, gn2, aw2, gw2) x I3).  With A = Rq, B = Rr,
+    // C = Rr [a1]x: G = A A^T + B B^T and C C^T are symmetric, so their column jj is the matrix times its own row jj
     {
       const double a = 0.25 * dt * dt, b = -(0.25 * dt * dt * 0.5 * dt), c = 0.5 * dt, d = 0.5 * dt, e = -(0.5 * dt * 0.5 * dt);
-      const M3 G = add(mul(Rq, transpose(Rq)), mul(Rr, transpose(Rr)));        // A A^T + B B^T
-      const M3 CC = mul(f.S2, transpose(f.S2));
       V3 n0{0, 0, 0}, n1{0, 0, 0}, n2{0, 0, 0};
-      double n3 = 0.0, n4 = 0.0;
-      if (jb == 0) {        // blocks N00, N10 = N01^T, N20 = N02^T
-        n0 = m3col(G, jj) * (an2 * a * a) + m3col(CC, jj) * (2.0 * gn2 * b * b);
-        n1 = m3row(f.S2, jj) * (2.0 * gn2 * b * c);
-        n2 = m3row(G, jj) * (an2 * a * d) + m3row(CC, jj) * (2.0 * gn2 * b * e);
-      } else if (jb == 1) { // N01, N11, N21 = N12^T
+      if (jb == 0 || jb == 2) {
+        const V3 gcol = mul(Rq, m3row(Rq, jj)) + mul(Rr, m3row(Rr, jj));
+        const V3 ccol = mul(f.S2, m3row(f.S2, jj));
+        if (jb == 0) {        // blocks N00, N10 = N01^T, N20 = N02^T
+          n0 = gcol * (an2 * a * a) + ccol * (2.0 * gn2 * b * b);
+          n1 = m3row(f.S2, jj) * (2.0 * gn2 * b * c);
+          n2 = gcol * (an2 * a * d) + ccol * (2.0 * gn2 * b * e);
+        } else {              // N02, N12, N22
+          n0 = gcol * (an2 * a * d) + ccol * (2.0 * gn2 * b * e);
+          n1 = m3row(f.S2, jj) * (2.0 * gn2 * c * e);
+          n2 = gcol * (an2 * d * d) + ccol * (2.0 * gn2 * e * e);
+        }
+      } else if (jb == 1) {   // N01, N11, N21 = N12^T
         n0 = m3col(f.S2, jj) * (2.0 * gn2 * b * c);
         n1 = V3{jj == 0 ? 1.0 : 0.0, jj == 1 ? 1.0 : 0.0, jj == 2 ? 1.0 : 0.0} * (2.0 * gn2 * c * c);
         n2 = m3col(f.S2, jj) * (2.0 * gn2 * c * e);
-      } else if (jb == 2) { // N02, N12, N22
-        n0 = m3col(G, jj) * (an2 * a * d) + m3col(CC, jj) * (2.0 * gn2 * b * e);
-        n1 = m3row(f.S2, jj) * (2.0 * gn2 * c * e);
-        n2 = m3col(G, jj) * (an2 * d * d) + m3col(CC, jj) * (2.0 * gn2 * e * e);
-      } else if (jb == 3) {
-        n3 = aw2 * dt * dt;
-      } else {
-        n4 = gw2 * dt * dt;
       }
-      Pn[0] += n0.x; Pn[1] += n0.y; Pn[2] += n0.z; Pn[3] += n1.x; Pn[4] += n1.y; Pn[5] += n1.z;
-      Pn[6] += n2.x; Pn[7] += n2.y; Pn[8] += n2.z;
+      Pc[0] += n0.x; Pc[1] += n0.y; Pc[2] += n0.z; Pc[3] += n1.x; Pc[4] += n1.y; Pc[5] += n1.z;
+      Pc[6] += n2.x; Pc[7] += n2.y; Pc[8] += n2.z;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        Pn[9 + q] += (jb == 3 && jj == q) ? n3 : 0.0;
-        Pn[12 + q] += (jb == 4 && jj == q) ? n4 : 0.0;
+        Pc[9 + q] += (jb == 3 && jj == q) ? aw2 * dt * dt : 0.0;
+        Pc[12 + q] += (jb == 4 && jj == q) ? gw2 * dt * dt : 0.0;
       }
     }
     if (on) {
-#pragma unroll
-      for (int r = 0; r < 15; ++r) { Jc[r] = Jn[r]; Pc[r] = Pn[r]; }
       dp = rp; dv = rv; dq = qnormalized(rq);
       sum_dt += dt;
       a0 = a1; g0 = g1;
