@@ -300,10 +300,14 @@ def main():
     TL = cfg.track_len
     config_id = 3 if L else 2
 
+    # a stream of its own (not the legacy default stream): the library replays the solve as a hipGraph captured on it
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+
     def new_ctx(nw, p, l):
         c = v.Context(device=local_rank, max_windows=max(nw, 1), max_points=max(p, 1), max_point_obs=max(p * TL, 1),
                       max_lines=max(l, 1), max_line_obs=max(l * TL, 1))
-        c.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        c.set_stream(stream.cuda_stream)
         return c
 
     # ---- strong scaling: the ONE batch of `total` windows, block-partitioned ----

@@ -37,6 +37,10 @@ struct vpl_ctx {
   std::map<std::string, std::pair<double, int>> ktimes;
   std::vector<std::pair<const char*, double>> ltimes;   // (kernel, ms) of every launch of the last timed solve, in order
   int* d_act = nullptr;                                 // [ACT_SLOTS][4] activity counters of those launches
+  // the ~19 launches of one solve as a hipGraph, captured on the first vpl_ba_solve after an upload (the kernel arguments --
+  // the batch descriptor by value -- are fixed until the next upload); VPL_BA_GRAPH=0 launches kernel by kernel
+  hipGraphExec_t graph_exec = nullptr;
+  bool use_graph = true;
   std::vector<std::string> kname_store;
   // host-side marg structure of the uploaded windows
   std::vector<int> h_mg_m;
@@ -49,6 +53,10 @@ struct vpl_ctx {
   int maxPriorN = 0;                             // largest prior of the uploaded batch (k_prep stages J0 in LDS)
 };
 
+static void drop_graph(vpl_ctx* c) {
+  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+}
+
 static int fail(vpl_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
   return code;
@@ -59,6 +67,10 @@ static int fail(vpl_ctx* c, int code, const std::string& msg) {
     if (e__ != hipSuccess) return fail(ctx, VPL_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
+// One hipMalloc per array.  (Measured alternative, round 2: all ~90 arrays out of one arena, with and without skewed
+// offsets -- k_cost, the kernel closest to the bandwidth roof, then runs at 0.30 ms per step in EVERY process, whereas with
+// separate allocations it is 0.24 ms in most processes and 0.30 ms in some: the difference is where the driver places the
+// buffers, not the code.  DESIGN.md section 8.)
 template <typename T>
 static hipError_t dalloc(vpl_ctx* c, T** p, size_t n) {
   void* q = nullptr;
@@ -224,6 +236,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
   (void)hipGetLastError();
   vpl_ba_default_options(&c->opt);
+  if (const char* gv = std::getenv("VPL_BA_GRAPH")) c->use_graph = std::atoi(gv) != 0;
   *out = c;
   return VPL_OK;
 }
@@ -232,12 +245,14 @@ void vpl_ctx_destroy(vpl_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipDeviceSynchronize();
+  drop_graph(c);
   for (void* p : c->allocs) hipFree(p);
   delete c;
 }
 
 int vpl_ctx_set_stream(vpl_ctx* c, void* s) {
   if (!c) return VPL_E_INVALID;
+  drop_graph(c);
   c->stream = (hipStream_t)s;
   return VPL_OK;
 }
@@ -383,6 +398,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       opt->marginalization_flag != VPL_MARGIN_NONE)
     return fail(c, VPL_E_INVALID, "unknown marginalization_flag");
   HIPCHK(c, hipSetDevice(c->device));
+  drop_graph(c);
   c->opt = *opt;
   c->nW = nW;
   DevBatch& B = c->B;
@@ -869,6 +885,19 @@ static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
 int vpl_ba_solve(vpl_ctx* c) {
   if (!c || c->nW < 1) return VPL_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->use_graph && !c->timing && c->stream != nullptr) {   // (the legacy default stream cannot be captured)
+    if (!c->graph_exec) {
+      hipGraph_t graph = nullptr;
+      HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      launch_solve(c, 0, c->nW, c->stream);
+      HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
+      hipError_t e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (e != hipSuccess) { c->graph_exec = nullptr; return fail(c, VPL_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    }
+    HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+    return VPL_OK;
+  }
   launch_solve(c, 0, c->nW, c->stream);
   HIPCHK(c, hipGetLastError());
   return VPL_OK;
