@@ -384,7 +384,7 @@ def main():
         t = time.perf_counter()
         o.solve_windows(res, opt, threads=cores)
         tp = time.perf_counter() - t
-        reps = max(1, min(50, int(10.0 / max(tp, 1e-3))))
+        reps = max(1, min(400, int(12.0 / max(tp, 1e-3))))
         tc = 0.0
         for _ in range(reps):
             res = [w.copy() for w in work]
