@@ -404,3 +404,51 @@ def test_failure_occur_gauge_reference(gpu_ctx):
     gpu_ctx.solve_windows(plain, opt)
     for i in range(len(ws)):
         assert np.abs(plain[i].pose[0, :3] - before[i]).max() < 1e-12
+
+
+def _ragged(w, rng, min_pt=2, min_ln=5):
+    """the same window with every track cut to a random length, start frames kept: points >= 2 observations
+    (estimator.cpp:1100-1102), lines >= LINE_MIN_OBS = 5 (estimator.cpp:1130, parameters.h:23) -- the caller's filters"""
+    poff = np.concatenate([[0], np.cumsum(w.point_nobs)])
+    loff = np.concatenate([[0], np.cumsum(w.line_nobs)])
+    pn = np.array([rng.integers(min(min_pt, n), n + 1) for n in w.point_nobs], np.int32)
+    ln = np.array([rng.integers(min(min_ln, n), n + 1) for n in w.line_nobs], np.int32)
+    pobs = np.concatenate([w.point_obs[poff[i]:poff[i] + pn[i]] for i in range(len(pn))]) if len(pn) else w.point_obs[:0]
+    lobs = np.concatenate([w.line_obs[loff[i]:loff[i] + ln[i]] for i in range(len(ln))]) if len(ln) else w.line_obs[:0]
+    r = v.capi.Window(w.pose, w.speed_bias, w.ex_pose, w.point_start, pn, pobs, w.inv_depth, w.line_start, ln, lobs,
+                      w.line_plk, w.preint, w.prior)
+    r.extra = dict(w.extra)
+    return r
+
+
+@pytest.mark.parametrize("P,L,TL", [(60, 60, 11), (90, 70, 9), (0, 50, 7), (40, 0, 11)])
+def test_window_solve_parity_long_and_ragged_tracks(P, L, TL):
+    """Tracks of up to 11 observations and of mixed lengths: the line phase of k_lin then runs several passes of 8 waves
+    (5 whole 11-frame tracks per wave), the compact W rows have unwritten slots (zero fill), the point units have
+    different observation counts per chunk.  Device against oracle, both with and without the line outlier step."""
+    opt = v.default_options()
+    cfg = v.workload.config(P, L, True)
+    cfg.track_len = TL
+    rng = np.random.default_rng(1000 + P + L + TL)
+    base = [v.workload.generate(v.workload.seed_for(3, 4000 + i), cfg, 0.43 * i) for i in range(3)]
+    o.preintegrate_windows(base, opt)
+    ws = base + [_ragged(b, rng) for b in base]
+    ctx = v.Context(device=0, max_windows=len(ws), max_points=max(P, 1), max_point_obs=max(P * TL, 1), max_lines=max(L, 1),
+                    max_line_obs=max(L * TL, 1))
+    wg = [w.copy() for w in ws]
+    wc = [w.copy() for w in ws]
+    pri_g, rep_g = ctx.solve_windows(wg, opt)
+    for i in range(len(ws)):
+        pri_c, rep_c = o.solve_window(wc[i], opt)
+        assert rep_g[i].iterations == rep_c.iterations and rep_g[i].num_successful_steps == rep_c.num_successful_steps, i
+        assert abs(rep_g[i].initial_cost - rep_c.initial_cost) <= 1e-9 * rep_c.initial_cost
+        dp, dr = pose_err(wg[i], wc[i])
+        assert dp <= POS_TOL and dr <= ROT_TOL, (i, dp, dr)
+        assert rep_g[i].prior_n == rep_c.prior_n and rep_g[i].prior_m == rep_c.prior_m
+        _compare_prior(pri_g[i], pri_c)
+    # and the solve is reproducible bit for bit on these shapes too
+    w2 = [w.copy() for w in ws]
+    ctx.solve_windows(w2, opt)
+    for a, b in zip(wg, w2):
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.line_plk, b.line_plk)
+    ctx.close()
