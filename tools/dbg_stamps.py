@@ -23,6 +23,7 @@ for w in (0, 1, 300):
     s = list(out)
     print("window", w, "k_solve phases (cycles):", [s[i + 1] - s[i] for i in range(0, 7)])
     print("   cholesky split: update(a) %d diag(b) %d (16 steps alone: %d) trsm(c) %d" % (s[40], s[41], s[43], s[42]))
+    print("   schur chunk loop (thread 0): stage %d mfma %d barrier wait %d" % (s[52], s[53], s[54]))
     print("   point phase (thread 0, 5 rounds): factor math %d staging+mfma %d atomics %d" % (s[48], s[49], s[50]))
     print("   line phase (thread 0): ctx %d math %d atomics %d ext-reduce %d" % (s[44], s[45], s[46], s[47]))
     print("   k_lin: prior %d zero %d points %d lines+fold %d imu %d assemble %d" % (s[18]-s[16], s[23]-s[18], s[24]-s[23], s[25]-s[22], s[20]-s[25], s[21]-s[20]))

@@ -210,7 +210,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       double* pS = S + 2 * CROWS * CW;        // nP   s / sqrt(A)
       double* pE = pS + B.maxP;               // nP   e = u / (s / sqrt(A))
       double* lC = pE + B.maxP;               // nL x 10
-      double* lS = lC + 10 * B.maxL;          // nL x 4   jacobi scale
+      double* lS = lC + 10 * B.maxL;          // nL x 4   jacobi scale / diagonal of C: the row solve multiplies, never divides
       double* lE = lS + 4 * B.maxL;           // nL x 4   e = C^T (u ./ s),  u = s g~ / d  =>  u/s = g~/d
       for (int p = tid; p < nP; p += T) {
         const double smv = ggn[LP + p];
@@ -223,8 +223,11 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
         for (int q = 0; q < 10; ++q) { C[q] = lch[l * 10 + q]; lC[l * 10 + q] = C[q]; }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          lS[4 * l + a] = gscale[LL + 4 * l + a];
+          const double rd = 1.0 / C[tri(a, a)];
+          lS[4 * l + a] = gscale[LL + 4 * l + a] * rd;   // x_a = (s_a w_a - sum_q C_aq x_q) / C_aa = lS_a w_a - sum_q (C_aq / C_aa) x_q
           us[a] = ggrad[LL + 4 * l + a] / gdiag[LL + 4 * l + a];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (q < a) lC[l * 10 + tri(a, q)] = C[tri(a, q)] * rd;
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -295,8 +298,8 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
                 for (int a = 0; a < 4; ++a) {
                   double s2 = lS[4 * l + a] * wv4[k][a];
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) if (q < a) s2 -= C[tri(a, q)] * x[q];
-                  x[a] = s2 / C[tri(a, a)];
+                  for (int q = 0; q < 4; ++q) if (q < a) s2 -= C[tri(a, q)] * x[q];   // off-diagonals pre-divided by C_aa
+                  x[a] = s2;
                 }
               } else {
 #pragma unroll
@@ -308,23 +311,51 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
           }
         }
       };
+#ifdef VPL_STAMPS
+      long long st_stage = 0, st_mfma = 0, st_bar = 0;
+#endif
       if (nch > 0) stage(0, buf0);
       __syncthreads();
       for (int ch = 0; ch < nch; ++ch) {
         double* cur = (ch & 1) ? buf1 : buf0;
+#ifdef VPL_STAMPS
+        long long t1 = __builtin_readcyclecounter();
+#endif
         if (ch + 1 < nch) stage(ch + 1, (ch & 1) ? buf0 : buf1);
+#ifdef VPL_STAMPS
+        { const long long tt = __builtin_readcyclecounter(); st_stage += tt - t1; t1 = tt; }
+#endif
         const int m = lane & 15, kk = lane >> 4;
-#pragma unroll 4
-        for (int ks = 0; ks < CROWS / 4; ++ks) {
-          const double* row = cur + (4 * ks + kk) * CW;
-          const double a0 = row[16 * ta0 + m], b0 = row[16 * tb0 + m];
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-          if (has1) {
-            const double a1v = row[16 * ta1 + m], b1v = row[16 * tb1 + m];
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1v, acc1, 0, 0, 0);
-          }
+        // operands of step ks + 2 are read while the matrix cores work on step ks: with the reads issued right in front of
+        // their MFMA a step took ~280 cycles (LDS latency) for 64 cycles of matrix-core time
+        const double* rowp = cur + kk * CW;
+        const int oa0 = 16 * ta0 + m, ob0 = 16 * tb0 + m, oa1 = 16 * ta1 + m, ob1 = 16 * tb1 + m;
+        double pa0[2], pb0[2], pa1[2], pb1[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const double* row = rowp + 4 * q * CW;
+          pa0[q] = row[oa0]; pb0[q] = row[ob0];
+          pa1[q] = has1 ? row[oa1] : 0.0; pb1[q] = has1 ? row[ob1] : 0.0;
         }
+#pragma unroll
+        for (int ks = 0; ks < CROWS / 4; ++ks) {
+          const double a0 = pa0[ks & 1], b0 = pb0[ks & 1], a1v = pa1[ks & 1], b1v = pb1[ks & 1];
+          if (ks + 2 < CROWS / 4) {
+            const double* row = rowp + 4 * (ks + 2) * CW;
+            pa0[ks & 1] = row[oa0]; pb0[ks & 1] = row[ob0];
+            if (has1) { pa1[ks & 1] = row[oa1]; pb1[ks & 1] = row[ob1]; }
+          }
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+          if (has1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1v, acc1, 0, 0, 0);
+        }
+#ifdef VPL_STAMPS
+        { const long long tt = __builtin_readcyclecounter(); st_mfma += tt - t1; t1 = tt; }
+#endif
         __syncthreads();
+#ifdef VPL_STAMPS
+        { const long long tt = __builtin_readcyclecounter(); st_bar += tt - t1; t1 = tt; }
+        if (tid == 0 && ch + 1 == nch) { long long* dg_ = B.dbg + (size_t)w * 64; dg_[52] = st_stage; dg_[53] = st_mfma; dg_[54] = st_bar; }
+#endif
       }
       VPL_STAMP(B, w, 2);
       // ---- reduced system: S = Hcc - X^T X (tile-major), rhs row = gc - X^T z; Cauchy denominator ----

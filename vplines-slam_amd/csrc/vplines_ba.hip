@@ -177,7 +177,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return VPL_E_NODEVICE; }
   c->maxW = max_windows;
-  c->maxP = max_points > 0 ? max_points : 1;
+  c->maxP = max_points > 0 ? (max_points + 1) & ~1 : 2;   // even: k_solve streams the gradient entries in 16-byte units
   c->maxPO = max_point_obs > 0 ? max_point_obs : 1;
   c->maxL = max_lines > 0 ? max_lines : 1;
   c->maxLO = max_line_obs > 0 ? max_line_obs : 1;
