@@ -275,7 +275,8 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   {
     const int wvi = tid >> 6, nwv = T >> 6;
     const int* plist = B.ps_list + (size_t)w * B.maxP;     // track ids sorted by start frame
-    const int nU = B.pu_cnt[w];
+    // the marginalisation pass linearises the tracks of start frame 0 only: their units come first in the table
+    const int nU = PRIOR_ONLY ? 0 : (MARG ? B.pu_cnt0[w] : B.pu_cnt[w]);
     const int* pu = B.pu_tab + (size_t)w * B.maxPU * 4;    // (s, first index in plist, tracks, k) per unit
     double* stg = imuJ + wvi * (32 * STG_LD);              // this wave's staging tile: 32 rows x 20 (stride STG_LD)
     const int m16 = lane & 15, kk = lane >> 4;
@@ -583,6 +584,8 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   __syncthreads();   // the staging region goes to the IMU phase
   VPL_STAMP(B, w, 25);
   // ---- IMU factors: raw residual / Jacobian per factor, then cooperative whitening ------
+  for (int i = tid; i < 4650; i += T) imuJ[i] = 0.0;   // [imuJ | imur]: by everybody, not 450 stores by each of the ten lanes below
+  __syncthreads();
   if (tid < 10) {
     const int j = tid + 1;
     const DevPreint& dp = B.pre[(size_t)w * NF + j];
@@ -590,14 +593,11 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     if (PRIOR_ONLY) act = false;
     imuact[tid] = act ? 1 : 0;
     double* J = imuJ + 450 * tid;
-    for (int k = 0; k < 450; ++k) J[k] = 0.0;
     if (act) {
       PreInt p = load_preint(dp);
       imu_residual_raw(p, xp + 7 * (j - 1), xs + 9 * (j - 1), xp + 7 * j, xs + 9 * j, B.opt.g_norm, imur + 15 * tid);
       ImuJac JB = imu_jacobian_raw(p, xp + 7 * (j - 1), xs + 9 * (j - 1), xp + 7 * j, xs + 9 * j, B.opt.g_norm);
       imu_jac_dense(JB, J);
-    } else {
-      for (int k = 0; k < 15; ++k) imur[15 * tid + k] = 0.0;
     }
   }
   __syncthreads();

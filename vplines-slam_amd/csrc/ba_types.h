@@ -79,6 +79,7 @@ struct DevBatch {
   double *pt_obs;                                // [W][maxPO][3]
   int *ps_list, *ps_cnt;                         // [W][maxP] track ids sorted by start frame ; [W][12] prefix offsets
   int *pu_tab, *pu_cnt;                          // [W][maxPU][4] point work units (s, first index in ps_list, tracks <= 16, k) ; [W]
+  int *pu_cnt0;                                  // [W] units of start frame 0 (they come first): all the MARGIN_OLD pass needs
   int maxPU;
   int *ln_start, *ln_nobs, *ln_off;              // [W][maxL]
   double *ln_obs;                                // [W][maxLO][8]

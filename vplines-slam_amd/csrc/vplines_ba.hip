@@ -199,7 +199,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(plk, W * B.maxL * 6); AL(gauge, W * 4); AL(fail_ref, W * 13); AL(orth_in, W);
   AL(nP, W); AL(nL, W);
   AL(pt_start, W * B.maxP); AL(pt_nobs, W * B.maxP); AL(pt_off, W * B.maxP); AL(pt_obs, W * B.maxPO * 3);
-  AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1)); AL(pu_tab, W * B.maxPU * 4); AL(pu_cnt, W);
+  AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1)); AL(pu_tab, W * B.maxPU * 4); AL(pu_cnt, W); AL(pu_cnt0, W);
   AL(ln_start, W * B.maxL); AL(ln_nobs, W * B.maxL); AL(ln_off, W * B.maxL); AL(ln_obs, W * B.maxLO * 8);
   AL(nLO, W); AL(lo_ln, W * B.maxLO);
   B.llSlots = 512 * ((B.maxL + 8 * (64 / NF) - 1) / (8 * (64 / NF)));   // worst case: 11-frame tracks, 5 lines per wave
@@ -417,7 +417,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   std::vector<double> pose(W * 77), sb(W * 99), ex(W * 7), invd(W * B.maxP, 1.0), plk(W * B.maxL * 6, 0.0);
   std::vector<int> nP(W), nL(W), pt_start(W * B.maxP, 0), pt_nobs(W * B.maxP, 0), pt_off(W * B.maxP, 0);
   std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0), ln_tri(W * B.maxL, 1);
-  std::vector<int> pu_tab(W * B.maxPU * 4, 0), pu_cnt(W, 0);
+  std::vector<int> pu_tab(W * B.maxPU * 4, 0), pu_cnt(W, 0), pu_cnt0(W, 0);
   std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0), ll_tab(W * B.llSlots, -1), ll_np(W, 0);
   std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
@@ -506,6 +506,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
           }
       }
       pu_cnt[w] = nu;
+      for (int q = 0; q < nu; ++q) if (pu_tab[(w * B.maxPU + q) * 4] == 0) pu_cnt0[w] = q + 1;
     }
     off = 0;
     int woff = 0, nl = 0;
@@ -608,7 +609,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.pt_start, pt_start)); HIPCHK(c, up(c, B.pt_nobs, pt_nobs)); HIPCHK(c, up(c, B.pt_off, pt_off));
   HIPCHK(c, up(c, B.pt_obs, pt_obs));
   HIPCHK(c, up(c, B.ps_list, ps_list)); HIPCHK(c, up(c, B.ps_cnt, ps_cnt));
-  HIPCHK(c, up(c, B.pu_tab, pu_tab)); HIPCHK(c, up(c, B.pu_cnt, pu_cnt));
+  HIPCHK(c, up(c, B.pu_tab, pu_tab)); HIPCHK(c, up(c, B.pu_cnt, pu_cnt)); HIPCHK(c, up(c, B.pu_cnt0, pu_cnt0));
   HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
   HIPCHK(c, up(c, B.ln_obs, ln_obs)); HIPCHK(c, up(c, B.ln_tri, ln_tri));
   HIPCHK(c, up(c, B.nLO, nLO)); HIPCHK(c, up(c, B.lo_ln, lo_ln));
