@@ -323,6 +323,18 @@ def main():
     gathered = v.shard.gather_states(dist, v.shard.pack_states(strong.B), total, dev)
     stats = step_stats(reports, n_local)
 
+    # ---- the same batch with the host round trip (upload of the caller's windows + solve + download): never `value` ----
+    pcie = None
+    if rank == 0 and not args.no_extras:
+        hostw = [[b.copy() for b in strong.pristine] for _ in range(4)]    # fresh inputs per repetition (results come back in place)
+        ctx.solve_windows(hostw[0], opt)
+        tp = time.perf_counter()
+        for r in range(1, 4):
+            ctx.solve_windows(hostw[r], opt)
+        pcie = n_local * 3 / (time.perf_counter() - tp)
+        strong.B = [b.copy() for b in strong.pristine]     # back to the resident batch of the timed region
+        ctx.upload(strong.B, opt)
+
     # ---- per-launch profile (separate, un-timed pass) ----
     prof, kms = launch_profile(torch, dev, strong, max(3, min(args.steps, 10)))
     ab = algorithmic_bytes(P, L, strong.n_prior, P * TL, L * TL)
@@ -348,6 +360,9 @@ def main():
             "device_ms_per_step": sum(kms.values()),
             "launches": [{"kernel": n, "ms": round(ms, 5), "active": [round(a, 1) for a in act]} for n, ms, act in prof],
             "setup_s": strong.setup_s,
+            "host_round_trip": None if pcie is None else {
+                "value": pcie, "unit": "solves/s",
+                "what": "vpl_ba_solve_windows on host windows: pack + PCIe upload + solve + download + unpack, single host thread"},
         }
 
     # ---- parity of the gathered result set + CPU baseline on a bounded sample (rank 0) ----
