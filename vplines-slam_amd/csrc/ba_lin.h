@@ -488,6 +488,8 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #pragma unroll
             for (int q = 0; q < 12; ++q) Je[q] = 0.0;
           }
+          // the VP factor has no translation columns (Jp[0..2] = Je[0..2] = 0 in both rows): its zero products are skipped
+          const int c0 = fct == 0 ? 0 : 3;
           int t = 0;
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
@@ -495,7 +497,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #pragma unroll
             for (int c2 = 0; c2 <= a; ++c2, ++t) lds_add(&la[t], Jo[a] * Jo[c2] + Jo[4 + a] * Jo[4 + c2]);
 #pragma unroll
-            for (int c2 = 0; c2 < 6; ++c2) {
+            for (int c2 = c0; c2 < 6; ++c2) {
               Wj[6 * a + c2] += Jo[a] * Jp[c2] + Jo[4 + a] * Jp[6 + c2];
               lds_add(&la[14 + 6 * a + c2], Jo[a] * Je[c2] + Jo[4 + a] * Je[6 + c2]);
             }
@@ -505,9 +507,11 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
 #pragma unroll
-            for (int c2 = 0; c2 <= a; ++c2, ++t) lds_add(&Hf[t], Jp[a] * Jp[c2] + Jp[6 + a] * Jp[6 + c2]);
+            for (int c2 = 0; c2 <= a; ++c2, ++t)
+              if (a >= c0 && c2 >= c0) lds_add(&Hf[t], Jp[a] * Jp[c2] + Jp[6 + a] * Jp[6 + c2]);
+            if (a < c0) continue;
 #pragma unroll
-            for (int c2 = 0; c2 < 6; ++c2) lds_add(&Hf[21 + 6 * a + c2], Je[a] * Jp[c2] + Je[6 + a] * Jp[6 + c2]);
+            for (int c2 = c0; c2 < 6; ++c2) lds_add(&Hf[21 + 6 * a + c2], Je[a] * Jp[c2] + Je[6 + a] * Jp[6 + c2]);
             lds_add(&Hf[57 + a], Jp[a] * r[0] + Jp[6 + a] * r[1]);
           }
         }
@@ -515,13 +519,17 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
         // row leaders add to the wave's partial sums
         {
           const bool leader = (lane & 15) == 15;
+          const int c0 = fct == 0 ? 0 : 3;
           int t = 0;
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
-            const double gev = row_sum16(Je[a] * r[0] + Je[6 + a] * r[1]);
-            if (leader) lds_add(&Hw[714 + a], gev);
+            if (a >= c0) {
+              const double gev = row_sum16(Je[a] * r[0] + Je[6 + a] * r[1]);
+              if (leader) lds_add(&Hw[714 + a], gev);
+            }
 #pragma unroll
             for (int c2 = 0; c2 <= a; ++c2, ++t) {
+              if (a < c0 || c2 < c0) continue;
               const double v = row_sum16(Je[a] * Je[c2] + Je[6 + a] * Je[6 + c2]);
               if (leader) lds_add(&Hw[693 + t], v);
             }
