@@ -43,6 +43,16 @@ __device__ __forceinline__ double row_sum16(double v) {
   return v;
 }
 
+// sum over the wave without LDS traffic: DPP row sums, then the four row leaders through the scalar unit (uniform result)
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v = row_sum16(v);
+  double t = 0.0;
+#pragma unroll
+  for (int l = 15; l < 64; l += 16)
+    t += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+  return t;
+}
+
 // sum over the whole workgroup; `red` is LDS scratch of >= 17 doubles; result broadcast
 __device__ __forceinline__ double block_sum(double v, double* red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -63,7 +73,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 // cam index -> vis index or -1
-__device__ __forceinline__ int cam2vis(int c) {
+__host__ __device__ __forceinline__ int cam2vis(int c) {
   if (c >= 165) return 66 + (c - 165);
   int o = c % 15;
   return o < 6 ? 6 * (c / 15) + o : -1;

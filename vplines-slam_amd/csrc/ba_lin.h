@@ -14,6 +14,7 @@ typedef double v4d_lin __attribute__((ext_vector_type(4)));
 constexpr int LIN_THREADS = 512;
 constexpr int STG_LD = 21;                // row stride of the MFMA staging tiles (odd: the 16 writer lanes spread over the banks)
 constexpr int LIN_STAGE = 8 * 32 * STG_LD;   // MFMA staging of the point phase (doubles)
+constexpr int PRH_N = 76;                 // priors up to this size keep J0^T J0 in LDS for the assembly (ex + speed/bias + 10 poses = 75)
 constexpr int LIN_HW = 720;               // wave-private partial sums of the line phase: 11 x (21 + 36 + 6) + 21 + 6 doubles
 constexpr int PREP_NMAX = 112;            // prior dims staged in LDS by k_prep (larger priors read HBM/L2); 10 x 675 + 112^2 doubles = 151 KB
 __host__ __device__ constexpr int lin_stage_doubles(int maxL) {   // MFMA staging | line partial sums + per-track sums | IMU
@@ -150,9 +151,26 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(DevBatch B, int nstage) {
 // The vis Hessian in LDS: lower block triangle of 12 x 12 blocks of 6 x 6 (frames 0..10, extrinsic), every block stored
 // full -- 78 blocks = 2808 doubles instead of the 72 x 72 square.  Entry (r, c), r >= c in vis indices:
 constexpr int HV_DOUBLES = 78 * 36;
-__device__ __forceinline__ int hvi(int r, int c) {
+__host__ __device__ __forceinline__ int hvi(int r, int c) {
   const int br = r / 6, bc = c / 6;
   return 36 * (br * (br + 1) / 2 + bc) + 6 * (r - 6 * br) + (c - 6 * bc);
+}
+
+// Static description of packed cam-Hessian entry (r, c), r >= c, for the assembly pass of k_lin (the same for every
+// window; built once per context):  x = (index into the LDS vis Hessian + 1) | (index into the LDS IMU blocks + 1) << 16,
+// 0 meaning "no such source";  y = r | c << 8.  IMU blocks: 11 diagonal 15x15 lower triangles (120 each), then 10
+// sub-diagonal full blocks (225 each).
+inline void lin_asm_entry(int r, int c, int* out) {
+  int hv = 0, im = 0;
+  const int vr = cam2vis(r), vc = cam2vis(c);
+  if (vr >= 0 && vc >= 0) hv = hvi(vr, vc) + 1;
+  if (r < 165) {
+    const int fr = r / 15, ar = r - 15 * fr, fc = c / 15, bc = c - 15 * fc;
+    if (fc == fr) im = 120 * fr + ar * (ar + 1) / 2 + bc + 1;
+    else if (fc == fr - 1) im = 11 * 120 + 225 * (fr - 1) + 15 * ar + bc + 1;
+  }
+  out[0] = hv | im << 16;
+  out[1] = r | c << 8;
 }
 
 // MODE 0: solve linearisation; 1: MARGIN_OLD assembly (prior + IMU(0,1) + landmarks that start in frame 0);
@@ -182,16 +200,16 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   double* prdx = prr + MAXPN;      // MAXPN
   double* prg = prdx + MAXPN;      // MAXPN  J0^T r
   double* red = prg + MAXPN;       // 18
-  double* pacc = red + 18;         // maxP x 14: per-track sums over its factors  H_ll | g_l | W_s (6) | W_ext (6)
-  int* invmap = (int*)(pacc + 14 * B.maxP);  // NC
+  double* ptab = red + 18;         // 55 x PROJ_PAIR pair parts of the projection Jacobians | ric (9)
+  double* prH = ptab + 55 * PROJ_PAIR + 9;   // packed lower triangle of the prior's J0^T J0 (priors of up to PRH_N dims)
+  int* invmap = (int*)(prH + PRH_N * (PRH_N + 1) / 2);  // NC
   int* imuact = invmap + NC;       // 10
-  int* tick = imuact + 10;         // 3 ticket counters of the point phase's ordered LDS commits
+  int* tick = imuact + 10;         // ticket counters of the point phase's ordered LDS commits (1, 2: the two chains)
 
   const int nP = B.nP[w], nL = B.nL[w];
   // the marginalisation evaluates every block, constant or not (marginalization_factor.cpp:3-69)
   const bool ex_free = MARG || B.opt.estimate_extrinsic != 0;
   for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] = 0.0;
-  for (int i = tid; i < 14 * nP; i += T) pacc[i] = 0.0;
   for (int i = tid; i < 84; i += T) xp[i] = i < 77 ? B.pose[(size_t)w * 77 + i] : B.ex[(size_t)w * 7 + (i - 77)];
   for (int i = tid; i < 99; i += T) xs[i] = B.sb[(size_t)w * 99 + i];
   for (int i = tid; i < NC; i += T) invmap[i] = -1;
@@ -226,8 +244,10 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #pragma unroll 4
       for (int c = sub; c < n; c += 8) {
         const double dxc = prdx[c];
+        const double hrc = Hp[(size_t)r * n + c];
         s += J0[(size_t)r * n + c] * dxc;
-        sg += Hp[(size_t)r * n + c] * dxc;
+        sg += hrc * dxc;
+        if (n <= PRH_N && c <= r) prH[r * (r + 1) / 2 + c] = hrc;   // kept for the assembly
       }
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
       sg += __shfl_xor(sg, 1, 64); sg += __shfl_xor(sg, 2, 64); sg += __shfl_xor(sg, 4, 64);
@@ -261,35 +281,42 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     for (int i = tid; i < nL * 4 * WS; i += T)
       if (!MARG || B.ln_start[(size_t)w * B.maxL + i / (4 * WS)] == 0) Wl0[i] = 0.0;
   }
+  if (!PRIOR_ONLY) {   // pair parts of the projection Jacobians (the marginalisation pass needs the pairs of frame 0 only)
+    const int npair = MARG ? 10 : 55;
+    if (tid < npair) {
+      int i = 0, rem = tid;
+      while (rem >= 10 - i) { rem -= 10 - i; ++i; }
+      projection_pair_setup(xp + 7 * i, xp + 7 * (i + 1 + rem), xe, ptab + PROJ_PAIR * tid);
+    } else if (tid == 64) {
+      const M3 ric = qmat(qpose(xe));
+      for (int k2 = 0; k2 < 9; ++k2) ptab[55 * PROJ_PAIR + k2] = ric.m[k2];
+    }
+  }
   __syncthreads();
 
   VPL_STAMP(B, w, 23);
-  // points: the work unit is (start frame s, chunk of <= 16 tracks that start there, observation index k) -- one QUARTER
-  // of a wave.  Inside a quarter every lane works on the same pair of frames (s, j = s + k), so the six 6x6 blocks a
-  // point factor touches are uniform over its 16 lanes and the sum of J^T [J | r] (19 x 19, J = [J_s J_j J_e]) over them
-  // is a rank-32 update: the lanes stage their two Jacobian rows in LDS and the FP64 matrix cores reduce them (3 tiles of
-  // 16x16, K = 4 per instruction), one pass per quarter; each lane then adds its accumulator entries to the LDS Hessian.
-  // The factor math of the four quarters of a wave runs concurrently (different (s, j) per quarter), so a window of 200
-  // tracks x 5 factors takes 3 rounds of the 8 waves.  Per-track sums over k (H_ll, g_l, W_s, W_ext) are LDS atomics into
-  // pacc, written out once at the end of the phase.
+  // points: the work unit is (start frame s, observation index k, <= 16 of the tracks that start in s and are seen at k).
+  // Inside a unit every lane works on the same pair of frames (s, j = s + k), so the six 6x6 blocks a point factor
+  // touches are uniform over its lanes and the sum of J^T [J | r] (19 x 19, J = [J_s J_j J_e]) over them is a rank-2n
+  // update: the lanes stage their two Jacobian rows in LDS and the FP64 matrix cores reduce them (2 tiles of 16x16, K = 4
+  // per instruction; the corner of the last two extrinsic columns and the residual is one sum over the wave), each lane then
+  // adds its accumulator entries to the LDS Hessian.  The host packs the units into quarter-wave slots (pu_lane / pu_sub):
+  // a full unit takes a slot, small ones share one -- 200 tracks x 5 factors are 60 full units + 30 of two tracks = 64
+  // slots = 2 rounds of the 8 waves.
   {
     const int wvi = tid >> 6, nwv = T >> 6;
-    const int* plist = B.ps_list + (size_t)w * B.maxP;     // track ids sorted by start frame
-    // the marginalisation pass linearises the tracks of start frame 0 only: their units come first in the table
-    const int nU = PRIOR_ONLY ? 0 : (MARG ? B.pu_cnt0[w] : B.pu_cnt[w]);
-    const int* pu = B.pu_tab + (size_t)w * B.maxPU * 4;    // (s, first index in plist, tracks, k) per unit
+    const int nRounds = PRIOR_ONLY ? 0 : (MARG ? B.pu_cnt0[w] : B.pu_cnt[w]);
+    const int2* plane = (const int2*)B.pu_lane + (size_t)w * B.maxPR * 512;
+    const int* psub = B.pu_sub + (size_t)w * B.maxPR * 512;
     double* stg = imuJ + wvi * (32 * STG_LD);              // this wave's staging tile: 32 rows x 20 (stride STG_LD)
     const int m16 = lane & 15, kk = lane >> 4;
     // Every accumulator of this phase is shared by all waves, and floating-point addition does not associate: the adds are
-    // therefore committed IN WAVE ORDER: wave v of (round, quarter) waits for its ticket (tick[1]), adds its Hessian tile
-    // (and, in the first quarter, the per-track sums of its four units), passes the ticket on.  The factor math and the
-    // matrix-core reductions of the other waves go on meanwhile; what is serialised is ~25 LDS instructions per quarter.
-    // All waves run the same number of rounds (empty units included) so that the ticket sequence is complete.
-    const int nRounds = (nU + 4 * nwv - 1) / (4 * nwv);
+    // therefore committed IN A FIXED ORDER: every unit carries a ticket number from the host; its wave waits for the
+    // ticket, adds its Hessian tile, passes the ticket on.  The factor math and the matrix-core reductions of the other
+    // waves go on meanwhile; what is serialised is ~20 LDS instructions per unit.
     // Two commit chains run side by side: waves 0..3 add into Hv / gv, waves 4..7 into a second copy that lives in the
-    // part of the staging region the MFMA tiles leave free; the copy is folded into Hv after the phase.  The per-track
-    // sums have one chain over all eight waves (tick[0]).
-    const int half = wvi >= nwv / 2 ? 1 : 0, wih = wvi - half * (nwv / 2);
+    // part of the staging region the MFMA tiles leave free; the copy is folded into Hv after the phase.
+    const int half = wvi >= nwv / 2 ? 1 : 0;
     double* HvC = half ? imuJ + LIN_STAGE : Hv;
     double* gvC = half ? imuJ + LIN_STAGE + HV_DOUBLES : gv;
     if (half) for (int i = tid - T / 2; i < HV_DOUBLES + NV; i += T / 2) imuJ[LIN_STAGE + i] = 0.0;
@@ -302,16 +329,31 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_store(&tick[which], seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+#ifdef VPL_STAMPS
+    long long pt_t[6] = {0, 0, 0, 0, 0, 0};     // factor math | per-track chain | staging | MFMA | ticket wait | commit
+    long long pt_c = __builtin_readcyclecounter();
+#define PT_LAP(i) do { const long long t_ = __builtin_readcyclecounter(); pt_t[i] += t_ - pt_c; pt_c = t_; } while (0)
+#else
+#define PT_LAP(i) do {} while (0)
+#endif
+    // A global round trip costs ~3 us when all CUs are in this phase together: the lane records (track, k, start frame,
+    // observation offset -- everything the loads of the factor need) and the unit table of round r + 1 are fetched while
+    // round r is worked on, so that a round starts one round trip deep, not three.
+    int2 rec_n = nRounds > 0 ? plane[tid] : int2{-1, 0};
+    int subv_n = nRounds > 0 ? psub[(wvi * 4) * 16 + lane] : 0;
     for (int round = 0; round < nRounds; ++round) {
-      const int u0 = 4 * nwv * round + 4 * wvi;
-      const int u = u0 + kk;
-      const bool has = u < nU;
-      const int s = has ? pu[4 * u] : 0, k = has ? pu[4 * u + 3] : 1, ucnt = has ? pu[4 * u + 2] : 0;
-      const bool live = has && m16 < ucnt && !(MARG && s != 0) && !PRIOR_ONLY;
-      const int p = live ? plist[pu[4 * u + 1] + m16] : 0;
+      const int2 rec = rec_n;
+      // the wave's unit table of this round is 4 slots x 8 x (descriptor, ticket) = one int per lane, read with v_readlane
+      const int subv = subv_n;
+      if (round + 1 < nRounds) {
+        rec_n = plane[(round + 1) * 512 + tid];
+        subv_n = psub[((round + 1) * 32 + wvi * 4) * 16 + lane];
+      }
+      const bool has = rec.x >= 0;
+      const int p = has ? rec.x & 0xffff : 0, k = has ? (rec.x >> 16) & 15 : 1, s = has ? rec.x >> 20 : 0;
       const size_t pi = (size_t)w * B.maxP + p;
-      const int no = live ? B.pt_nobs[pi] : 0, off = live ? B.pt_off[pi] : 0;
-      const bool act = live && k < no;
+      const bool act = has && !(MARG && s != 0);     // (the table lists observed factors only: k < pt_nobs)
+      const int off = rec.y;
       const int j = s + k;
       double* Wrow = B.Wp + pi * WS;
       double r[2] = {0, 0}, Ji[12], Jj[12], Je[12], pv[14];
@@ -322,8 +364,8 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
         const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + off) * 3;
         const double* oj = o0 + 3 * k;
         double Jl[2] = {0, 0};
-        projection_factor(xp + 7 * s, xp + 7 * j, xe, lam, V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]},
-                          B.opt.sqrt_info_point, r, true, Ji, Jj, Je, Jl);
+        projection_factor_pair(xp + 7 * s, xp + 7 * j, xe, ptab + PROJ_PAIR * proj_pair_index(s, j), ptab + 55 * PROJ_PAIR, lam,
+                               V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]}, B.opt.sqrt_info_point, r, Ji, Jj, Je, Jl);
         double sc;
         cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
         r[0] *= sc; r[1] *= sc; Jl[0] *= sc; Jl[1] *= sc;
@@ -342,30 +384,33 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
           Wrow[6 * k + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];   // this (track, frame) entry has one writer
         }
       }
-      // ---- per quarter: reduction of [Js Jj Je r]^T [Js Jj Je r] over its 16 lanes on the matrix cores ----
+      // corner of the unit's 19 x 19 sum that the two matrix-core tiles do not cover: (e4, e5, r) x (e4, e5)
+      const double cnr[5] = {Je[4] * Je[4] + Je[10] * Je[10], Je[5] * Je[4] + Je[11] * Je[10], Je[5] * Je[5] + Je[11] * Je[11],
+                             Je[4] * r[0] + Je[10] * r[1], Je[5] * r[0] + Je[11] * r[1]};
       const unsigned long long actmask = __ballot(act);
+      // per-track sums over k: a track's factors sit in different units, i.e. in different waves -- one chain over all
+      // waves; two lanes of a wave may hold the same track with different k: atomic adds, lane order
+      // The extrinsic corner is the same five entries for every unit: one sum over the wave, added with its first tile
+      double cs[5];
+#pragma unroll
+      for (int a = 0; a < 5; ++a) cs[a] = wave_sum_dpp(cnr[a]);
+      bool cs_pending = true;
+      PT_LAP(0);
+      // Per-track sums over k (H_ll, g_l, W_s, W_ext): a track's factors sit in different units, i.e. in different waves.
+      // Every factor stores its 14 terms next to its observation (pfac, 112 contiguous bytes per lane); after the phase
+      // one thread per track adds them up in k order -- no shared accumulator, no ordering between the waves.
+      if (act) {
+        double* pf = B.pfac + ((size_t)w * B.maxPO + off + k) * 14;
+#pragma unroll
+        for (int a = 0; a < 14; a += 2) *(double2*)(pf + a) = double2{pv[a], pv[a + 1]};
+      }
+      PT_LAP(1);
 #pragma unroll 1
       for (int qq = 0; qq < 4; ++qq) {
+        if (__builtin_amdgcn_readlane(subv, 16 * qq) == 0) continue;      // empty slot (uniform)
         const unsigned qmask = (unsigned)((actmask >> (16 * qq)) & 0xffffull);
-        const int seq = (round * 4 + qq) * (nwv / 2) + wih;
-        if (qq == 0) {              // per-track sums over k of the wave's four units (a track's factors sit in different
-          ticket_wait(0, round * nwv + wvi);   // units, i.e. in different waves): one chain over all waves
-          if (act) {
-            double* pa = pacc + 14 * p;        // (two quarters of a wave may hold the same track with different k: atomic adds)
-#pragma unroll
-            for (int a = 0; a < 14; ++a) lds_add(&pa[a], pv[a]);
-          }
-          ticket_pass(0, round * nwv + wvi);
-        }
-        if (qmask == 0) {           // uniform: no tile to add, the ticket still goes round
-          ticket_wait(1 + half, seq);
-          ticket_pass(1 + half, seq);
-          continue;
-        }
-        const int sq = __builtin_amdgcn_readlane(s, 16 * qq), jq = __builtin_amdgcn_readlane(j, 16 * qq);
-        const int rows = 2 * (32 - __builtin_clz(qmask));   // staged rows that can be non-zero
         __builtin_amdgcn_wave_barrier();
-        if (kk == qq) {
+        if (kk == qq && qmask != 0) {
           double* d0 = stg + (2 * m16) * STG_LD;
 #pragma unroll
           for (int rr = 0; rr < 2; ++rr) {
@@ -380,52 +425,126 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
           }
         }
         __builtin_amdgcn_wave_barrier();
-        v4d_lin c00 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
-        const int ksmax = (rows + 3) >> 2;
-#pragma unroll 2
-        for (int ks = 0; ks < ksmax; ++ks) {
-          const double* row = stg + (4 * ks + kk) * STG_LD;
-          const double lo = row[m16];
-          const double hi = m16 < 4 ? row[16 + m16] : 0.0;
-          c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, c00, 0, 0, 0);
-          c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, c10, 0, 0, 0);
-          c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, c11, 0, 0, 0);
-        }
-        // accumulator entry (row a = kk + 4 v (+16), col b = m16 (+16)) -> LDS Hessian / gradient, in wave order
-        ticket_wait(1 + half, seq);
-        {
-          const double v00[4] = {c00.x, c00.y, c00.z, c00.w}, v10[4] = {c10.x, c10.y, c10.z, c10.w},
-                       v11[4] = {c11.x, c11.y, c11.z, c11.w};
-          auto visof = [&](int a) { return a < 6 ? 6 * sq + a : (a < 12 ? 6 * jq + (a - 6) : 66 + (a - 12)); };
+        PT_LAP(2);
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+          const int desc = __builtin_amdgcn_readlane(subv, 16 * qq + 2 * i);
+          if (desc == 0) break;
+          const int seq = __builtin_amdgcn_readlane(subv, 16 * qq + 2 * i + 1);
+          const int sq = desc & 15, jq = (desc >> 4) & 15, ks0 = (desc >> 8) & 15, ks1 = (desc >> 12) & 15;
+          const unsigned smask = ((1u << (2 * (ks1 - ks0))) - 1u) << (2 * ks0);
+          if ((qmask & smask) == 0) {       // uniform: nothing to add (units of later start frames in the marginalisation
+            ticket_wait(1 + half, seq);     // pass), the ticket still goes round
+            ticket_pass(1 + half, seq);
+            continue;
+          }
+          v4d_lin c00 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0};
+          // operands of four steps are read before the first of their MFMAs issues (one LDS latency per group)
+#pragma unroll 1
+          for (int kb = ks0; kb < ks1; kb += 4) {
+            double lo[4], hi[4];
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int a0 = kk + 4 * v, bcol = m16;
-            if (a0 >= bcol) lds_add(&HvC[hvi(visof(a0), visof(bcol))], v00[v]);
-            const int a1 = 16 + kk + 4 * v;
-            if (a1 < 18) lds_add(&HvC[hvi(visof(a1), visof(bcol))], v10[v]);
-            else if (a1 == 18) lds_add(&gvC[visof(bcol)], v10[v]);
-            const int b1c = 16 + m16;
-            if (b1c < 18) {
-              if (a1 < 18 && a1 >= b1c) lds_add(&HvC[hvi(visof(a1), visof(b1c))], v11[v]);
-              else if (a1 == 18) lds_add(&gvC[visof(b1c)], v11[v]);
+            for (int q = 0; q < 4; ++q)
+              if (kb + q < ks1) {
+                const double* row = stg + (4 * (kb + q) + kk) * STG_LD;
+                lo[q] = row[m16];
+                hi[q] = m16 < 4 ? row[16 + m16] : 0.0;
+              }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (kb + q < ks1) {
+                c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[q], lo[q], c00, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi[q], lo[q], c10, 0, 0, 0);
+              }
+          }
+          // accumulator entry (row a = kk + 4 v (+16), col b = m16) -> LDS Hessian / gradient, in ticket order
+          PT_LAP(3);
+          ticket_wait(1 + half, seq);
+          PT_LAP(4);
+          {
+            const double v00[4] = {c00.x, c00.y, c00.z, c00.w}, v10[4] = {c10.x, c10.y, c10.z, c10.w};
+            auto visof = [&](int a) { return a < 6 ? 6 * sq + a : (a < 12 ? 6 * jq + (a - 6) : 66 + (a - 12)); };
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int a0 = kk + 4 * v, bcol = m16;
+              if (a0 >= bcol) lds_add(&HvC[hvi(visof(a0), visof(bcol))], v00[v]);
+              const int a1 = 16 + kk + 4 * v;
+              if (a1 < 18) lds_add(&HvC[hvi(visof(a1), visof(bcol))], v10[v]);
+              else if (a1 == 18) lds_add(&gvC[visof(bcol)], v10[v]);
+            }
+            if (cs_pending) {      // uniform
+              cs_pending = false;
+              if (lane == 0) {
+                lds_add(&HvC[hvi(70, 70)], cs[0]);
+                lds_add(&HvC[hvi(71, 70)], cs[1]);
+                lds_add(&HvC[hvi(71, 71)], cs[2]);
+                lds_add(&gvC[70], cs[3]);
+                lds_add(&gvC[71], cs[4]);
+              }
             }
           }
+          ticket_pass(1 + half, seq);
+          PT_LAP(5);
         }
-        ticket_pass(1 + half, seq);
+      }
+    }
+#ifdef VPL_STAMPS
+    if (lane == 0) B.dbg[(size_t)w * 64 + 56 + wvi] = __builtin_readcyclecounter() - B.dbg[(size_t)w * 64 + 23];
+    if (lane == 0 && wvi == 0)
+      for (int a = 0; a < 6; ++a) B.dbg[(size_t)w * 64 + 44 + a] = pt_t[a];
+#endif
+  }
+  __syncthreads();
+  VPL_STAMP(B, w, 51);
+  for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] += imuJ[LIN_STAGE + i];   // second commit chain's copy (Hv | gv are contiguous)
+  VPL_STAMP(B, w, 50);
+  // per-track sums over the factors' terms, in k order: one thread per (track, pair of terms), three items per thread and
+  // pass.  A global round trip costs ~3 us here, so the pass is exactly two of them deep: the track metadata of all
+  // items, then every term of all items (uniform loop bound, unconditional clamped loads), then sums and stores.
+  for (int it0 = 0; it0 < 7 * nP; it0 += 3 * T) {
+    int no[3], itv[3];
+    const double* pf[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int it = it0 + u * T + tid;
+      const bool on = it < 7 * nP;
+      const int p = on ? it / 7 : 0;
+      const size_t pi = (size_t)w * B.maxP + p;
+      itv[u] = on ? it : -1;
+      no[u] = (!on || PRIOR_ONLY || (MARG && B.pt_start[pi] != 0)) ? 0 : B.pt_nobs[pi];
+      pf[u] = B.pfac + ((size_t)w * B.maxPO + B.pt_off[pi]) * 14 + 2 * (it - 7 * p);
+    }
+    const int nmax = max(no[0], max(no[1], no[2]));
+    double2 acc[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+    // two blocks of five observation indices: 15 loads in flight each
+#pragma unroll 1
+    for (int kb = 1; kb < NF; kb += 5) {
+      if (__ballot(kb < nmax) == 0) break;
+      double2 t[3][5];
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) t[u][q] = *(const double2*)(pf[u] + 14 * (kb + q < no[u] ? kb + q : 0));
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          if (kb + q < no[u]) { acc[u].x += t[u][q].x; acc[u].y += t[u][q].y; }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (itv[u] < 0) continue;
+      const int p = itv[u] / 7, a2 = itv[u] - 7 * p;
+      const size_t pi = (size_t)w * B.maxP + p;
+      double* Wrow = B.Wp + pi * WS;
+      if (a2 == 0) { B.Hpp[pi] = acc[u].x; B.gp[pi] = acc[u].y; }
+      else {
+        double* d = a2 < 4 ? Wrow + 2 * (a2 - 1) : Wrow + WS - 6 + 2 * (a2 - 4);
+        d[0] = acc[u].x; d[1] = acc[u].y;
       }
     }
   }
-  __syncthreads();
-  for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] += imuJ[LIN_STAGE + i];   // second commit chain's copy (Hv | gv are contiguous)
-  for (int p = tid; p < nP; p += T) {   // per-track sums out of LDS
-    const size_t pi = (size_t)w * B.maxP + p;
-    const double* pa = pacc + 14 * p;
-    double* Wrow = B.Wp + pi * WS;
-    B.Hpp[pi] = pa[0];
-    B.gp[pi] = pa[1];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) { Wrow[a] = pa[2 + a]; Wrow[WS - 6 + a] = pa[8 + a]; }
-  }
+  VPL_STAMP(B, w, 55);
   __syncthreads();   // staging space is handed over to the IMU / line phases
   VPL_STAMP(B, w, 24);
   VPL_STAMP(B, w, 22);
@@ -642,28 +761,22 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   // ---- assemble the packed cam Hessian and gradient in HBM -----------------------------------
   double* Hout = B.Hcc + (size_t)w * NCP;
   const double* pH = B.pr_H + (size_t)w * B.prS;
-  // Three passes over the packed lower triangle instead of one that decodes every index and asks every entry for all
-  // three sources: (A) rows to waves, columns to lanes -- the visual block, coalesced stores, no index decoding;
-  // (B) the 3570 entries the IMU factors touch (11 diagonal 15x15 blocks, 10 sub-diagonal ones), each summing its one or
-  // two J^T J terms; (C) the n (n + 1) / 2 entries of the prior, all of its loads in one batch.  (B) and (C) add to what
-  // (A) stored: same workgroup, a barrier in between.
-  {
-    const int lane2 = tid & 63, wv2 = tid >> 6;
-    for (int r = wv2; r < NC; r += T >> 6) {
-      const int vr = cam2vis(r);
-      const bool dead = !ex_free && r >= 165;
-      double* row = Hout + (size_t)r * (r + 1) / 2;
-      for (int c = lane2; c <= r; c += 64) {
-        double v = 0.0;
-        if (vr >= 0 && !dead) {
-          const int vc = cam2vis(c);
-          if (vc >= 0) v = Hv[hvi(vr, vc)];
-        }
-        row[c] = v;
-      }
-    }
+  // Every entry is stored ONCE, with its three sources summed in registers: adding to what an earlier pass had stored
+  // is a global read-modify-write, i.e. a full round trip (~3 us with all CUs in this phase) behind every store.
+  // (1) the 3570 entries the IMU factors touch (11 diagonal 15x15 blocks, 10 sub-diagonal ones), each summing its one or
+  // two J^T J terms, go to LDS; (2) rows to waves, columns to lanes: visual block + IMU block + prior (J0^T J0 staged in LDS
+  // by the prior phase), coalesced stores, no index decoding beyond c / 15.  Priors larger than PRH_N (none in the
+  // reference's windows) take a third pass that adds their entries in HBM.
+  double* imuH = imuJ + 4650;
+  // the static table entries of this thread's packed entries (e = u T + tid): one batch of loads, all in flight while the
+  // IMU blocks are worked out
+  constexpr int ASM_PER_THREAD = (NCP + LIN_THREADS - 1) / LIN_THREADS;
+  int2 asmd[ASM_PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < ASM_PER_THREAD; ++u) {
+    const int e = u * T + tid;
+    asmd[u] = ((const int2*)B.asm_tab)[e < NCP ? e : 0];
   }
-  __syncthreads();
   for (int item = tid; item < 11 * 120 + 10 * 225; item += T) {
     int fr, a, b;   // entry (15 fr + a, 15 fc + b)
     bool diag;
@@ -695,10 +808,34 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
       for (int k = 0; k < 15; ++k) s2 += J[k * 30 + a] * J[k * 30 + b];
       v += s2;
     }
-    const int r = 15 * fr + a, c = diag ? 15 * fr + b : 15 * (fr - 1) + b;
-    if (v != 0.0) Hout[(size_t)r * (r + 1) / 2 + c] += v;
+    imuH[item] = v;
   }
-  if (n > 0) {
+  __syncthreads();
+  VPL_STAMP(B, w, 26);
+  const bool prior_lds = n > 0 && n <= PRH_N;
+  {
+    // flat over the packed triangle: fully coalesced stores; the table entries were requested before the IMU blocks
+#pragma unroll
+    for (int u = 0; u < ASM_PER_THREAD; ++u) {
+      const int e = u * T + tid;
+      if (e >= NCP) continue;
+      const int hv = asmd[u].x & 0xffff, im = asmd[u].x >> 16, r = asmd[u].y & 255, c = asmd[u].y >> 8;
+      // branch-free: every source is read (clamped index) and selected, so that the LDS reads of many entries overlap
+      const double vh = Hv[hv ? hv - 1 : 0], vi = imuH[im ? im - 1 : 0];
+      const int ir = prior_lds ? invmap[r] : -1, ic = prior_lds ? invmap[c] : -1;
+      const bool hp = ir >= 0 && ic >= 0;
+      const int hi_ = ic > ir ? ic : ir, lo_ = ic > ir ? ir : ic;
+      const double vp = prH[hp ? hi_ * (hi_ + 1) / 2 + lo_ : 0];
+      double v = hv ? vh : 0.0;
+      v += im ? vi : 0.0;
+      v += hp ? vp : 0.0;
+      if (!ex_free && r >= 165) v = 0.0;
+      Hout[e] = v;
+    }
+  }
+  VPL_STAMP(B, w, 27);
+  if (n > PRH_N) {
+    __syncthreads();
     const int np = n * (n + 1) / 2;
     for (int base = 0; base < np; base += 4 * T) {
       double ph[4];
@@ -716,7 +853,6 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
           tc_[u] = ri > rj ? rj : ri;
         }
       }
-      __syncthreads();   // (uniform trip count) the IMU pass has finished with the entries the prior shares
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (tr_[u] >= 0 && (ex_free || tr_[u] < 165)) Hout[(size_t)tr_[u] * (tr_[u] + 1) / 2 + tc_[u]] += ph[u];
@@ -766,7 +902,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
 }
 
 inline size_t lin_smem(int maxP, int maxL) {
-  return (size_t)(HV_DOUBLES + NV + 84 + 99 + lin_stage_doubles(maxL) + 3 * MAXPN + 18 + 14 * maxP) * sizeof(double) + (size_t)(NC + 16) * sizeof(int);
+  return (size_t)(HV_DOUBLES + NV + 84 + 99 + lin_stage_doubles(maxL) + 3 * MAXPN + 18 + 55 * PROJ_PAIR + 9 + PRH_N * (PRH_N + 1) / 2) * sizeof(double) + (size_t)(NC + 16) * sizeof(int);
 }
 
 }  // namespace vpl

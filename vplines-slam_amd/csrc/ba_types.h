@@ -78,9 +78,14 @@ struct DevBatch {
   int *pt_start, *pt_nobs, *pt_off;              // [W][maxP]
   double *pt_obs;                                // [W][maxPO][3]
   int *ps_list, *ps_cnt;                         // [W][maxP] track ids sorted by start frame ; [W][12] prefix offsets
-  int *pu_tab, *pu_cnt;                          // [W][maxPU][4] point work units (s, first index in ps_list, tracks <= 16, k) ; [W]
-  int *pu_cnt0;                                  // [W] units of start frame 0 (they come first): all the MARGIN_OLD pass needs
-  int maxPU;
+  // point phase of k_lin: rounds of 512 lanes = 32 quarter-wave slots; a slot holds up to 8 work units (start frame, k,
+  // tracks) packed on even lane boundaries.  pu_lane: (track | k << 16 | s << 20, observation offset) of every lane (-1: idle).  pu_sub: per slot 8 x
+  // (descriptor s | j << 4 | ks0 << 8 | ks1 << 12 | 1 << 16, commit ticket), descriptor 0 ends the list.  Slot r of a round
+  // belongs to wave r % 8, quarter r / 8.
+  int *pu_lane, *pu_sub;                         // [W][maxPR][512][2] ; [W][maxPR][32][8][2]
+  double *pfac;                                  // [W][maxPO][14] per-factor terms of the per-track sums (H_ll g_l W_s W_ext), summed in k order
+  int *pu_cnt, *pu_cnt0;                         // [W] rounds ; [W] rounds that hold the units of start frame 0 (they come first)
+  int maxPR;
   int *ln_start, *ln_nobs, *ln_off;              // [W][maxL]
   double *ln_obs;                                // [W][maxLO][8]
   int *nLO, *lo_ln;                              // [W] line observation count ; [W][maxLO] observation -> line
@@ -107,6 +112,7 @@ struct DevBatch {
 
   // ---- linearisation (one buffer set; written by k_lin at the current x) ----
   double *Hcc, *gc;                              // [W][NCP] [W][NC]
+  int *asm_tab;                                  // [NCP][2] static: sources of every packed cam-Hessian entry, see lin_asm_entry()
   double *Hpp, *gp, *Wp;                         // [W][maxP] [W][maxP] [W][maxP][WS]
   double *Hll, *gl, *Wl;                         // [W][maxL][16] [W][maxL][4] [W][maxL][4][WS]
   // W rows are stored compact: the 6 x 6 blocks of the frames start .. start + maxTrack - 1 of the track, then the 6

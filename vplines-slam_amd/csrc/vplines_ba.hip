@@ -188,7 +188,8 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   std::memset(&B, 0, sizeof(B));
   B.maxP = c->maxP; B.maxPO = c->maxPO; B.maxL = c->maxL; B.maxLO = c->maxLO;
   B.nfull = NC + B.maxP + 4 * B.maxL;
-  B.maxPU = (B.maxP / 16 + NF) * (NF - 1);   // point work units of k_lin: (start frame, chunk of 16 tracks, observation)
+  // point work units of k_lin: (start frame, chunk of <= 16 tracks, observation); a unit needs at most one quarter-wave slot
+  B.maxPR = ((B.maxP / 16 + NF) * (NF - 1) + 31) / 32;
   const size_t W = max_windows;
   hipError_t e = hipSuccess;
 #define AL(ptr, n) if (e == hipSuccess) e = dalloc(c, &B.ptr, (size_t)(n))
@@ -199,7 +200,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(plk, W * B.maxL * 6); AL(gauge, W * 4); AL(fail_ref, W * 13); AL(orth_in, W);
   AL(nP, W); AL(nL, W);
   AL(pt_start, W * B.maxP); AL(pt_nobs, W * B.maxP); AL(pt_off, W * B.maxP); AL(pt_obs, W * B.maxPO * 3);
-  AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1)); AL(pu_tab, W * B.maxPU * 4); AL(pu_cnt, W); AL(pu_cnt0, W);
+  AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1)); AL(pu_lane, W * B.maxPR * 1024); AL(pu_sub, W * B.maxPR * 512); AL(pu_cnt, W); AL(pu_cnt0, W); AL(pfac, W * B.maxPO * 14);
   AL(ln_start, W * B.maxL); AL(ln_nobs, W * B.maxL); AL(ln_off, W * B.maxL); AL(ln_obs, W * B.maxLO * 8);
   AL(nLO, W); AL(lo_ln, W * B.maxLO);
   B.llSlots = 512 * ((B.maxL + 8 * (64 / NF) - 1) / (8 * (64 / NF)));   // worst case: 11-frame tracks, 5 lines per wave
@@ -208,7 +209,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(pr_n, W); AL(pr_nb, W); AL(pr_kind, W * MAXPB); AL(pr_frame, W * MAXPB); AL(pr_idx, W * MAXPB);
   AL(pr_x0, W * MAXPB * 9); AL(pr_J0, W * MAXPN * MAXPN); AL(pr_r0, W * MAXPN); AL(pr_H, W * MAXPN * MAXPN); AL(pr_g0, W * MAXPN);
   AL(pr_map, W * MAXPN);
-  AL(Hcc, W * NCP); AL(gc, W * NC); AL(Hpp, W * B.maxP); AL(gp, W * B.maxP); AL(Wp, W * B.maxP * NV);
+  AL(Hcc, W * NCP); AL(gc, W * NC); AL(asm_tab, 2 * NCP); AL(Hpp, W * B.maxP); AL(gp, W * B.maxP); AL(Wp, W * B.maxP * NV);
   AL(Hll, W * B.maxL * 16); AL(gl, W * B.maxL * 4); AL(Wl, W * B.maxL * 4 * NV); AL(lchol, W * B.maxL * 10);
   AL(tr, W);
   AL(scale, W * B.nfull); AL(diag, W * B.nfull); AL(grad, W * B.nfull); AL(gn, W * B.nfull); AL(delta, W * B.nfull);
@@ -224,6 +225,16 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
     return VPL_E_HIP;
   }
   if (lin_smem(c->maxP, c->maxL) > 158 * 1024) { for (void* p : c->allocs) hipFree(p); delete c; return VPL_E_CAPACITY; }
+  {   // static table of the assembly pass of k_lin
+    std::vector<int> tab(2 * NCP);
+    for (int r = 0, e2 = 0; r < NC; ++r)
+      for (int cc = 0; cc <= r; ++cc, ++e2) lin_asm_entry(r, cc, &tab[2 * e2]);
+    if (hipMemcpy(B.asm_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      for (void* p : c->allocs) hipFree(p);
+      delete c;
+      return VPL_E_HIP;
+    }
+  }
   // the attribute is per kernel, not per context: never lower what a larger context of this process has asked for
   static size_t lin_max = 0, solve_max = 0;
   lin_max = std::max(lin_max, lin_smem(c->maxP, c->maxL));
@@ -417,7 +428,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   std::vector<double> pose(W * 77), sb(W * 99), ex(W * 7), invd(W * B.maxP, 1.0), plk(W * B.maxL * 6, 0.0);
   std::vector<int> nP(W), nL(W), pt_start(W * B.maxP, 0), pt_nobs(W * B.maxP, 0), pt_off(W * B.maxP, 0);
   std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0), ln_tri(W * B.maxL, 1);
-  std::vector<int> pu_tab(W * B.maxPU * 4, 0), pu_cnt(W, 0), pu_cnt0(W, 0);
+  std::vector<int> pu_lane(W * B.maxPR * 1024, -1), pu_sub(W * B.maxPR * 512, 0), pu_cnt(W, 0), pu_cnt0(W, 0);
   std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0), ll_tab(W * B.llSlots, -1), ll_np(W, 0);
   std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
@@ -492,21 +503,103 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       int pos[NF + 1];
       for (int f = 0; f <= NF; ++f) pos[f] = cnt[f];
       for (int p = 0; p < v.n_points; ++p) ps_list[w * B.maxP + pos[v.point_start[p]]++] = p;
-      // work units of the point phase of k_lin: (start frame, <= 16 tracks, observation index k >= 1)
-      int nu = 0;
+      // inside a start frame the longer tracks come first: the tracks observed at index k are then a prefix of the list
+      for (int f = 0; f < NF; ++f)
+        std::stable_sort(&ps_list[w * B.maxP + cnt[f]], &ps_list[w * B.maxP + cnt[f + 1]],
+                         [&](int a, int b) { return v.point_nobs[a] > v.point_nobs[b]; });
+      // work units of the point phase of k_lin: (start frame f, observation index k >= 1, <= 16 of the tracks seen at k),
+      // packed first-fit into quarter-wave slots (full units take a slot, small ones share one on even lane boundaries)
+      struct Slot { int used, nsub, desc[8], first[8], cnt[8], lane0[8], k[8]; };
+      std::vector<Slot> slots;
+      std::vector<int> open;
+      int slots0 = 0;
       for (int f = 0; f < NF; ++f) {
         const int c0 = cnt[f], c1 = cnt[f + 1];
-        int maxno = 0;
-        for (int q = c0; q < c1; ++q) maxno = std::max(maxno, v.point_nobs[ps_list[w * B.maxP + q]]);
-        for (int k = 1; k < maxno; ++k)
-          for (int q = c0; q < c1; q += 16) {
-            int* t = &pu_tab[(w * B.maxPU + nu) * 4];
-            t[0] = f; t[1] = q; t[2] = std::min(16, c1 - q); t[3] = k;
-            ++nu;
+        const int maxno = c1 > c0 ? v.point_nobs[ps_list[w * B.maxP + c0]] : 0;
+        for (int k = 1; k < maxno; ++k) {
+          int ck = 0;
+          while (c0 + ck < c1 && v.point_nobs[ps_list[w * B.maxP + c0 + ck]] > k) ++ck;
+          for (int q = 0; q < ck; q += 16) {
+            const int n = std::min(16, ck - q), need = (n + 1) & ~1;
+            int si = -1;
+            for (size_t o = 0; o < open.size() && si < 0; ++o)
+              if (16 - slots[open[o]].used >= need) si = open[o];
+            if (si < 0) {
+              si = (int)slots.size();
+              slots.push_back(Slot{});
+              open.push_back(si);
+            }
+            Slot& S = slots[si];
+            const int i = S.nsub++;
+            S.lane0[i] = S.used; S.first[i] = c0 + q; S.cnt[i] = n; S.k[i] = k;
+            S.desc[i] = f | (f + k) << 4 | (S.used / 2) << 8 | ((S.used + need) / 2) << 12 | 1 << 16;
+            S.used += need;
+            if (S.used == 16) open.erase(std::find(open.begin(), open.end(), si));
+            if (f == 0) slots0 = std::max(slots0, si + 1);
           }
+        }
       }
-      pu_cnt[w] = nu;
-      for (int q = 0; q < nu; ++q) if (pu_tab[(w * B.maxPU + q) * 4] == 0) pu_cnt0[w] = q + 1;
+      const int rounds = ((int)slots.size() + 31) / 32;
+      if (rounds > B.maxPR) return fail(c, VPL_E_CAPACITY, "point work-unit table too small");
+      pu_cnt[w] = rounds;
+      pu_cnt0[w] = (slots0 + 31) / 32;
+      int* lt = &pu_lane[w * B.maxPR * 1024];
+      int* st = &pu_sub[w * B.maxPR * 512];
+      for (size_t si = 0; si < slots.size(); ++si) {
+        const int rnd = (int)si / 32, r = (int)si % 32, wave = r % 8, qq = r / 8;
+        const Slot& S = slots[si];
+        for (int i = 0; i < S.nsub; ++i) {
+          for (int m = 0; m < S.cnt[i]; ++m) {
+            const int p = ps_list[w * B.maxP + S.first[i] + m];
+            int* e = &lt[(rnd * 512 + wave * 64 + qq * 16 + S.lane0[i] + m) * 2];
+            e[0] = p | S.k[i] << 16 | (S.desc[i] & 15) << 20;
+            e[1] = pt_off[w * B.maxP + p];
+          }
+          st[((rnd * 32 + wave * 4 + qq) * 8 + i) * 2] = S.desc[i];
+        }
+      }
+      // commit tickets: two chains (waves 0..3 / 4..7).  A wave reaches its units in (round, quarter, unit) order; the
+      // chain serves, among the four waves' next units, the one a rough cycle model expects to be ready first, so that a
+      // slot packed with many small units does not hold up the waves whose slots are full ones
+      for (int hf = 0; hf < 2; ++hf) {
+        const int F = 12000, STAGE = 300, KS = 160, SUB = 250, COMMIT = 450;   // factor math, staging, per MFMA step, per unit, per commit
+        int pos[4] = {0, 0, 0, 0};          // next item of each wave: round * 32 + qq * 8 + i
+        long clk[4] = {F, F, F, F}, chain = 0;
+        bool staged[4] = {false, false, false, false};
+        int seq = 0;
+        auto entry = [&](int wv, int ps) { return &st[(((ps / 32) * 32 + (hf * 4 + wv) * 4 + (ps % 32) / 8) * 8 + ps % 8) * 2]; };
+        auto advance = [&](int wv) {        // skip to the wave's next existing unit, charging round starts and staging
+          while (pos[wv] < rounds * 32 && entry(wv, pos[wv])[0] == 0) {
+            pos[wv] = (pos[wv] / 8 + 1) * 8;           // descriptor 0 ends a slot's list
+            if (pos[wv] % 32 == 0 && pos[wv] < rounds * 32) clk[wv] += F;
+            staged[wv] = false;
+          }
+        };
+        for (int wv = 0; wv < 4; ++wv) advance(wv);
+        for (;;) {
+          int best = -1;
+          long bt = 0;
+          for (int wv = 0; wv < 4; ++wv) {
+            if (pos[wv] >= rounds * 32) continue;
+            const int d = entry(wv, pos[wv])[0];
+            const long t = clk[wv] + (staged[wv] ? 0 : STAGE) + SUB + KS * (((d >> 12) & 15) - ((d >> 8) & 15));
+            if (best < 0 || t < bt) { best = wv; bt = t; }
+          }
+          if (best < 0) break;
+          entry(best, pos[best])[1] = seq++;
+          chain = std::max(chain, bt) + COMMIT;
+          clk[best] = chain;
+          staged[best] = true;
+          const int before = pos[best];
+          ++pos[best];
+          if (pos[best] % 8 == 0) {
+            staged[best] = false;
+            if (pos[best] % 32 == 0 && pos[best] < rounds * 32) clk[best] += F;
+          }
+          (void)before;
+          advance(best);
+        }
+      }
     }
     off = 0;
     int woff = 0, nl = 0;
@@ -609,7 +702,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.pt_start, pt_start)); HIPCHK(c, up(c, B.pt_nobs, pt_nobs)); HIPCHK(c, up(c, B.pt_off, pt_off));
   HIPCHK(c, up(c, B.pt_obs, pt_obs));
   HIPCHK(c, up(c, B.ps_list, ps_list)); HIPCHK(c, up(c, B.ps_cnt, ps_cnt));
-  HIPCHK(c, up(c, B.pu_tab, pu_tab)); HIPCHK(c, up(c, B.pu_cnt, pu_cnt)); HIPCHK(c, up(c, B.pu_cnt0, pu_cnt0));
+  HIPCHK(c, up(c, B.pu_lane, pu_lane)); HIPCHK(c, up(c, B.pu_sub, pu_sub)); HIPCHK(c, up(c, B.pu_cnt, pu_cnt)); HIPCHK(c, up(c, B.pu_cnt0, pu_cnt0));
   HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
   HIPCHK(c, up(c, B.ln_obs, ln_obs)); HIPCHK(c, up(c, B.ln_tri, ln_tri));
   HIPCHK(c, up(c, B.nLO, nLO)); HIPCHK(c, up(c, B.lo_ln, lo_ln));
