@@ -712,40 +712,139 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   VPL_STAMP(B, w, 25);
   // ---- IMU factors: raw residual / Jacobian per factor, then cooperative whitening ------
   for (int i = tid; i < 4650; i += T) imuJ[i] = 0.0;   // [imuJ | imur]: by everybody, not 450 stores by each of the ten lanes below
-  __syncthreads();
-  if (tid < 10) {
-    const int j = tid + 1;
-    const DevPreint& dp = B.pre[(size_t)w * NF + j];
-    bool act = MARG ? (j == 1 && dp.sum_dt < 10.0) : !(dp.sum_dt > 10.0);   // estimator.cpp:1088, :1261
-    if (PRIOR_ONLY) act = false;
-    imuact[tid] = act ? 1 : 0;
-    double* J = imuJ + 450 * tid;
-    if (act) {
-      PreInt p = load_preint(dp);
-      imu_residual_raw(p, xp + 7 * (j - 1), xs + 9 * (j - 1), xp + 7 * j, xs + 9 * j, B.opt.g_norm, imur + 15 * tid);
-      ImuJac JB = imu_jacobian_raw(p, xp + 7 * (j - 1), xs + 9 * (j - 1), xp + 7 * j, xs + 9 * j, B.opt.g_norm);
-      imu_jac_dense(JB, J);
+  // S^T of this wave's factors as the A operand of the whitening (A[k][i] = S[i][k]), requested before the raw evaluation
+  double sa[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int f = (tid >> 6) + 8 * q;
+    const double* S = B.pre[(size_t)w * NF + (f < 10 ? f : 0) + 1].sqrt_info;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int k = 4 * ks + (lane >> 4), i = lane & 15;
+      sa[q][ks] = (f < 10 && i < 15 && k < 15 && k >= i) ? S[i * 15 + k] : 0.0;
     }
   }
   __syncthreads();
-  // whiten in place: column-wise, rows ascending (S upper triangular)
-  for (int it = tid; it < 10 * 31; it += T) {
-    const int f = it / 31, c = it % 31;
-    if (!imuact[f]) continue;
-    const double* S = B.pre[(size_t)w * NF + f + 1].sqrt_info;
-    if (c < 30) {
-      double* J = imuJ + 450 * f;
-      for (int r = 0; r < 15; ++r) {
-        double s = 0;
-        for (int k = r; k < 15; ++k) s += S[r * 15 + k] * J[k * 30 + c];
-        J[r * 30 + c] = s;
+  // raw residual by ten lanes of wave 0, raw Jacobian by ten lanes of wave 1 (each is one long dependent chain)
+  if ((tid & 63) < 10 && tid < 128) {
+    const int f = tid & 63, j = f + 1;
+    const DevPreint& dp = B.pre[(size_t)w * NF + j];
+    bool act = MARG ? (j == 1 && dp.sum_dt < 10.0) : !(dp.sum_dt > 10.0);   // estimator.cpp:1088, :1261
+    if (PRIOR_ONLY) act = false;
+    if (tid < 64) imuact[f] = act ? 1 : 0;
+    if (act) {
+      PreInt p = load_preint(dp);
+      if (tid < 64) {
+        imu_residual_raw(p, xp + 7 * (j - 1), xs + 9 * (j - 1), xp + 7 * j, xs + 9 * j, B.opt.g_norm, imur + 15 * f);
+      } else {
+        ImuJac JB = imu_jacobian_raw(p, xp + 7 * (j - 1), xs + 9 * (j - 1), xp + 7 * j, xs + 9 * j, B.opt.g_norm);
+        imu_jac_dense(JB, imuJ + 450 * f);
       }
-    } else {
+    }
+  }
+  __syncthreads();
+  VPL_STAMP(B, w, 28);
+  // the static table entries of this thread's packed entries (e = u T + tid): one batch of loads, requested before the
+  // whitening
+  constexpr int ASM_PER_THREAD = (NCP + LIN_THREADS - 1) / LIN_THREADS;
+  int2 asmd[ASM_PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < ASM_PER_THREAD; ++u) {
+    const int e = u * T + tid;
+    asmd[u] = ((const int2*)B.asm_tab)[e < NCP ? e : 0];
+  }
+  // Whitening J <- S J (S upper triangular 15 x 15, [J | r] 15 x 31) and the factor's J^T J on the FP64 matrix cores: one
+  // wave per factor (waves 0 and 1 take two).  C[i][j] = sum_k A[k][i] B[k][j]: the A lane (kk, m) supplies A[4 ks + kk][m],
+  // the B lane B[4 ks + kk][m], the accumulator lane (kk, m) holds C[kk + 4 v][m].  The 3570 entries of the 11 diagonal
+  // 15 x 15 blocks (lower triangles) and 10 sub-diagonal blocks go to imuH for the assembly: a frame's diagonal block is
+  // (term of the factor that ends in it) + (term of the factor that starts in it), in that order -- stored, barrier, added.
+  double* imuH = imuJ + 4650;
+  {
+    const int wvi = tid >> 6, m16 = lane & 15, kk = lane >> 4;
+    v4d_lin cd[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};        // (0..14)^2 part of this wave's factors, added after the barrier
+    for (int i = tid; i < 120; i += T) imuH[i] = 0.0;    // frame 0 has no factor ending in it
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int f = wvi + 8 * q;
+      if (f >= 10) break;
+      double* J = imuJ + 450 * f;
       double* rr = imur + 15 * f;
-      for (int r = 0; r < 15; ++r) {
-        double s = 0;
-        for (int k = r; k < 15; ++k) s += S[r * 15 + k] * rr[k];
-        rr[r] = s;
+      const bool on = imuact[f] != 0;
+      v4d_lin jw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int c = 16 * ct + m16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int k = 4 * ks + kk;
+          const double bv = k < 15 ? (c < 30 ? J[k * 30 + c] : (c == 30 ? rr[k] : 0.0)) : 0.0;
+          jw[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(on ? sa[q][ks] : 0.0, bv, jw[ct], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (on) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const double vals[4] = {jw[ct].x, jw[ct].y, jw[ct].z, jw[ct].w};
+          const int c = 16 * ct + m16;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int r = kk + 4 * v;
+            if (r < 15) {
+              if (c < 30) J[r * 30 + c] = vals[v];
+              else if (c == 30) rr[r] = vals[v];
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      // J^T J: tiles (0,0), (1,0), (1,1) of the 30 x 30 product
+      v4d_lin c00 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int k = 4 * ks + kk;
+        const double lo = k < 15 ? J[k * 30 + m16] : 0.0;
+        const double hi = (k < 15 && m16 < 14) ? J[k * 30 + 16 + m16] : 0.0;
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, c11, 0, 0, 0);
+      }
+      // entry (i, j) of the product, i >= j: i, j < 15 -> diagonal block of frame f (held back); i >= 15 > j -> the
+      // sub-diagonal block (f + 1, f); both >= 15 -> diagonal block of frame f + 1 (stored now)
+      {
+        const double v00[4] = {c00.x, c00.y, c00.z, c00.w}, v10[4] = {c10.x, c10.y, c10.z, c10.w}, v11[4] = {c11.x, c11.y, c11.z, c11.w};
+        double keep[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int i0 = kk + 4 * v, j0 = m16;                  // tile (0,0)
+          if (i0 < 15 && j0 < 15) keep[v] = v00[v];             // (all of it is block (f, f); the row-15 entries go with tile (1,0))
+          const int i1 = 16 + kk + 4 * v;                       // tiles (1,0) and (1,1): product rows 16..31
+          if (i1 < 30) {
+            if (j0 < 15) imuH[11 * 120 + 225 * f + 15 * (i1 - 15) + j0] = v10[v];
+            else imuH[120 * (f + 1) + (i1 - 15) * (i1 - 14) / 2 + 0] = v10[v];                     // (i1, 15): column 0 of block (f+1, f+1)
+            const int j1 = 16 + m16;
+            if (j1 < 30 && j1 <= i1) imuH[120 * (f + 1) + (i1 - 15) * (i1 - 14) / 2 + (j1 - 15)] = v11[v];
+          }
+          if (i0 == 15) {                                       // product row 15 sits in tile (0,0) / its column 15
+            if (j0 < 15) imuH[11 * 120 + 225 * f + j0] = v00[v];
+            else imuH[120 * (f + 1)] = v00[v];                  // (15, 15)
+          }
+        }
+        cd[q] = v4d_lin{keep[0], keep[1], keep[2], keep[3]};
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int f = wvi + 8 * q;
+      if (f >= 10) break;
+      const double keep[4] = {cd[q].x, cd[q].y, cd[q].z, cd[q].w};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int i0 = kk + 4 * v, j0 = m16;
+        if (i0 < 15 && j0 <= i0) imuH[120 * f + i0 * (i0 + 1) / 2 + j0] += keep[v];
       }
     }
   }
@@ -767,50 +866,6 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   // two J^T J terms, go to LDS; (2) rows to waves, columns to lanes: visual block + IMU block + prior (J0^T J0 staged in LDS
   // by the prior phase), coalesced stores, no index decoding beyond c / 15.  Priors larger than PRH_N (none in the
   // reference's windows) take a third pass that adds their entries in HBM.
-  double* imuH = imuJ + 4650;
-  // the static table entries of this thread's packed entries (e = u T + tid): one batch of loads, all in flight while the
-  // IMU blocks are worked out
-  constexpr int ASM_PER_THREAD = (NCP + LIN_THREADS - 1) / LIN_THREADS;
-  int2 asmd[ASM_PER_THREAD];
-#pragma unroll
-  for (int u = 0; u < ASM_PER_THREAD; ++u) {
-    const int e = u * T + tid;
-    asmd[u] = ((const int2*)B.asm_tab)[e < NCP ? e : 0];
-  }
-  for (int item = tid; item < 11 * 120 + 10 * 225; item += T) {
-    int fr, a, b;   // entry (15 fr + a, 15 fc + b)
-    bool diag;
-    if (item < 11 * 120) {
-      fr = item / 120;
-      tri_decode(item - 120 * fr, a, b);
-      diag = true;
-    } else {
-      const int e = item - 11 * 120;
-      fr = 1 + e / 225;
-      const int q = e - 225 * (fr - 1);
-      a = q / 15; b = q - 15 * a;
-      diag = false;
-    }
-    double v = 0.0;
-    const int t0 = fr - 1;
-    if (t0 >= 0 && imuact[t0]) {           // factor (fr-1, fr): rows 15..29 of its 30 columns are frame fr
-      const double* J = imuJ + 450 * t0;
-      const int ja = 15 + a, jb = diag ? 15 + b : b;
-      double s2 = 0;
-#pragma unroll
-      for (int k = 0; k < 15; ++k) s2 += J[k * 30 + ja] * J[k * 30 + jb];
-      v += s2;
-    }
-    if (diag && fr < 10 && imuact[fr]) {   // factor (fr, fr+1): columns 0..14 are frame fr
-      const double* J = imuJ + 450 * fr;
-      double s2 = 0;
-#pragma unroll
-      for (int k = 0; k < 15; ++k) s2 += J[k * 30 + a] * J[k * 30 + b];
-      v += s2;
-    }
-    imuH[item] = v;
-  }
-  __syncthreads();
   VPL_STAMP(B, w, 26);
   const bool prior_lds = n > 0 && n <= PRH_N;
   {
