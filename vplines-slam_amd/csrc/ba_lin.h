@@ -14,7 +14,6 @@ typedef double v4d_lin __attribute__((ext_vector_type(4)));
 constexpr int LIN_THREADS = 512;
 constexpr int STG_LD = 21;                // row stride of the MFMA staging tiles (odd: the 16 writer lanes spread over the banks)
 constexpr int LIN_STAGE = 8 * 32 * STG_LD;   // MFMA staging of the point phase (doubles)
-constexpr int PRH_N = 76;                 // priors up to this size keep J0^T J0 in LDS for the assembly (ex + speed/bias + 10 poses = 75)
 constexpr int LIN_HW = 720;               // wave-private partial sums of the line phase: 11 x (21 + 36 + 6) + 21 + 6 doubles
 constexpr int PREP_NMAX = 112;            // prior dims staged in LDS by k_prep (larger priors read HBM/L2); 10 x 675 + 112^2 doubles = 151 KB
 __host__ __device__ constexpr int lin_stage_doubles(int maxL) {   // MFMA staging | line partial sums + per-track sums | IMU
@@ -200,20 +199,23 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   double* prdx = prr + MAXPN;      // MAXPN
   double* prg = prdx + MAXPN;      // MAXPN  J0^T r
   double* red = prg + MAXPN;       // 18
-  double* ptab = red + 18;         // 55 x PROJ_PAIR pair parts of the projection Jacobians | ric (9)
-  double* prH = ptab + 55 * PROJ_PAIR + 9;   // packed lower triangle of the prior's J0^T J0 (priors of up to PRH_N dims)
+  const int PST = B.maxP | 1;      // pacc is [14][PST]: lanes with different tracks hit different banks
+  double* pacc = red + 18;         // per-track sums over the factors: H_ll | g_l | W_s (6) | W_ext (6)
+  double* prH = pacc + 14 * PST;   // packed lower triangle of the prior's J0^T J0 (priors of up to PRH_N dims)
+  const int PRH_N = B.prhN;        // priors up to this size keep J0^T J0 in LDS for the assembly (what the context's LDS budget leaves)
   int* invmap = (int*)(prH + PRH_N * (PRH_N + 1) / 2);  // NC
   int* imuact = invmap + NC;       // 10
-  int* tick = imuact + 10;         // ticket counters of the point phase's ordered LDS commits (1, 2: the two chains)
+  int* tick = imuact + 10;         // ticket counters of the point phase (1, 2: Hessian tiles of the two halves; 3, 4: per-track sums)
 
   const int nP = B.nP[w], nL = B.nL[w];
   // the marginalisation evaluates every block, constant or not (marginalization_factor.cpp:3-69)
   const bool ex_free = MARG || B.opt.estimate_extrinsic != 0;
   for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] = 0.0;
+  for (int i = tid; i < 14 * PST; i += T) pacc[i] = 0.0;
   for (int i = tid; i < 84; i += T) xp[i] = i < 77 ? B.pose[(size_t)w * 77 + i] : B.ex[(size_t)w * 7 + (i - 77)];
   for (int i = tid; i < 99; i += T) xs[i] = B.sb[(size_t)w * 99 + i];
   for (int i = tid; i < NC; i += T) invmap[i] = -1;
-  if (tid < 3) tick[tid] = 0;
+  if (tid < 5) tick[tid] = 0;
   __syncthreads();
   double cost = 0.0;
   VPL_STAMP(B, w, 16);
@@ -281,17 +283,6 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     for (int i = tid; i < nL * 4 * WS; i += T)
       if (!MARG || B.ln_start[(size_t)w * B.maxL + i / (4 * WS)] == 0) Wl0[i] = 0.0;
   }
-  if (!PRIOR_ONLY) {   // pair parts of the projection Jacobians (the marginalisation pass needs the pairs of frame 0 only)
-    const int npair = MARG ? 10 : 55;
-    if (tid < npair) {
-      int i = 0, rem = tid;
-      while (rem >= 10 - i) { rem -= 10 - i; ++i; }
-      projection_pair_setup(xp + 7 * i, xp + 7 * (i + 1 + rem), xe, ptab + PROJ_PAIR * tid);
-    } else if (tid == 64) {
-      const M3 ric = qmat(qpose(xe));
-      for (int k2 = 0; k2 < 9; ++k2) ptab[55 * PROJ_PAIR + k2] = ric.m[k2];
-    }
-  }
   __syncthreads();
 
   VPL_STAMP(B, w, 23);
@@ -316,7 +307,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     // waves go on meanwhile; what is serialised is ~20 LDS instructions per unit.
     // Two commit chains run side by side: waves 0..3 add into Hv / gv, waves 4..7 into a second copy that lives in the
     // part of the staging region the MFMA tiles leave free; the copy is folded into Hv after the phase.
-    const int half = wvi >= nwv / 2 ? 1 : 0;
+    const int half = wvi >= nwv / 2 ? 1 : 0, wih = wvi - half * (nwv / 2);
     double* HvC = half ? imuJ + LIN_STAGE : Hv;
     double* gvC = half ? imuJ + LIN_STAGE + HV_DOUBLES : gv;
     if (half) for (int i = tid - T / 2; i < HV_DOUBLES + NV; i += T / 2) imuJ[LIN_STAGE + i] = 0.0;
@@ -364,8 +355,8 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
         const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + off) * 3;
         const double* oj = o0 + 3 * k;
         double Jl[2] = {0, 0};
-        projection_factor_pair(xp + 7 * s, xp + 7 * j, xe, ptab + PROJ_PAIR * proj_pair_index(s, j), ptab + 55 * PROJ_PAIR, lam,
-                               V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]}, B.opt.sqrt_info_point, r, Ji, Jj, Je, Jl);
+        projection_factor(xp + 7 * s, xp + 7 * j, xe, lam, V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]},
+                          B.opt.sqrt_info_point, r, true, Ji, Jj, Je, Jl);
         double sc;
         cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
         r[0] *= sc; r[1] *= sc; Jl[0] *= sc; Jl[1] *= sc;
@@ -396,14 +387,16 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
       for (int a = 0; a < 5; ++a) cs[a] = wave_sum_dpp(cnr[a]);
       bool cs_pending = true;
       PT_LAP(0);
-      // Per-track sums over k (H_ll, g_l, W_s, W_ext): a track's factors sit in different units, i.e. in different waves.
-      // Every factor stores its 14 terms next to its observation (pfac, 112 contiguous bytes per lane); after the phase
-      // one thread per track adds them up in k order -- no shared accumulator, no ordering between the waves.
+      // Per-track sums over k (H_ll, g_l, W_s, W_ext): a track's factors sit in different units, but (host packing) all in
+      // the same half of the work-group: one chain over the half's four waves orders the LDS adds (tick[3 + half]); two
+      // lanes of a wave may hold the same track with different k -- atomic adds, lane order.
+      ticket_wait(3 + half, round * (nwv / 2) + wih);
       if (act) {
-        double* pf = B.pfac + ((size_t)w * B.maxPO + off + k) * 14;
+        double* pa = pacc + p;
 #pragma unroll
-        for (int a = 0; a < 14; a += 2) *(double2*)(pf + a) = double2{pv[a], pv[a + 1]};
+        for (int a = 0; a < 14; ++a) lds_add(&pa[a * PST], pv[a]);
       }
+      ticket_pass(3 + half, round * (nwv / 2) + wih);
       PT_LAP(1);
 #pragma unroll 1
       for (int qq = 0; qq < 4; ++qq) {
@@ -498,51 +491,14 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   VPL_STAMP(B, w, 51);
   for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] += imuJ[LIN_STAGE + i];   // second commit chain's copy (Hv | gv are contiguous)
   VPL_STAMP(B, w, 50);
-  // per-track sums over the factors' terms, in k order: one thread per (track, pair of terms), three items per thread and
-  // pass.  A global round trip costs ~3 us here, so the pass is exactly two of them deep: the track metadata of all
-  // items, then every term of all items (uniform loop bound, unconditional clamped loads), then sums and stores.
-  for (int it0 = 0; it0 < 7 * nP; it0 += 3 * T) {
-    int no[3], itv[3];
-    const double* pf[3];
+  for (int p = tid; p < nP; p += T) {   // per-track sums out of LDS
+    const size_t pi = (size_t)w * B.maxP + p;
+    const double* pa = pacc + p;
+    double* Wrow = B.Wp + pi * WS;
+    B.Hpp[pi] = pa[0];
+    B.gp[pi] = pa[PST];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int it = it0 + u * T + tid;
-      const bool on = it < 7 * nP;
-      const int p = on ? it / 7 : 0;
-      const size_t pi = (size_t)w * B.maxP + p;
-      itv[u] = on ? it : -1;
-      no[u] = (!on || PRIOR_ONLY || (MARG && B.pt_start[pi] != 0)) ? 0 : B.pt_nobs[pi];
-      pf[u] = B.pfac + ((size_t)w * B.maxPO + B.pt_off[pi]) * 14 + 2 * (it - 7 * p);
-    }
-    const int nmax = max(no[0], max(no[1], no[2]));
-    double2 acc[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
-    // two blocks of five observation indices: 15 loads in flight each
-#pragma unroll 1
-    for (int kb = 1; kb < NF; kb += 5) {
-      if (__ballot(kb < nmax) == 0) break;
-      double2 t[3][5];
-#pragma unroll
-      for (int q = 0; q < 5; ++q)
-#pragma unroll
-        for (int u = 0; u < 3; ++u) t[u][q] = *(const double2*)(pf[u] + 14 * (kb + q < no[u] ? kb + q : 0));
-#pragma unroll
-      for (int q = 0; q < 5; ++q)
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-          if (kb + q < no[u]) { acc[u].x += t[u][q].x; acc[u].y += t[u][q].y; }
-    }
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      if (itv[u] < 0) continue;
-      const int p = itv[u] / 7, a2 = itv[u] - 7 * p;
-      const size_t pi = (size_t)w * B.maxP + p;
-      double* Wrow = B.Wp + pi * WS;
-      if (a2 == 0) { B.Hpp[pi] = acc[u].x; B.gp[pi] = acc[u].y; }
-      else {
-        double* d = a2 < 4 ? Wrow + 2 * (a2 - 1) : Wrow + WS - 6 + 2 * (a2 - 4);
-        d[0] = acc[u].x; d[1] = acc[u].y;
-      }
-    }
+    for (int a = 0; a < 6; ++a) { Wrow[a] = pa[(2 + a) * PST]; Wrow[WS - 6 + a] = pa[(8 + a) * PST]; }
   }
   VPL_STAMP(B, w, 55);
   __syncthreads();   // staging space is handed over to the IMU / line phases
@@ -956,8 +912,23 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   lin_body<MODE>(B, MODE == 0 ? ordered_window(B) : (int)blockIdx.x, sm);
 }
 
+// LDS of k_lin: the fixed part, then whatever is left of the budget holds the prior's J0^T J0 for the assembly (priors of up
+// to lin_prh_n dims; the reference's are 6 + 9 + 6 x frames <= 75; larger ones are added in HBM by a third pass)
+constexpr size_t LIN_LDS_BUDGET = 158 * 1024;
+inline size_t lin_smem_base(int maxP, int maxL) {
+  return (size_t)(HV_DOUBLES + NV + 84 + 99 + lin_stage_doubles(maxL) + 3 * MAXPN + 18 + 14 * (maxP | 1)) * sizeof(double) + (size_t)(NC + 16) * sizeof(int);
+}
+inline int lin_prh_n(int maxP, int maxL) {
+  const size_t base = lin_smem_base(maxP, maxL);
+  if (base >= LIN_LDS_BUDGET) return 0;
+  const size_t cap = (LIN_LDS_BUDGET - base) / sizeof(double);
+  int n = 0;
+  while (n < 96 && (size_t)(n + 1) * (n + 2) / 2 <= cap) ++n;
+  return n;
+}
 inline size_t lin_smem(int maxP, int maxL) {
-  return (size_t)(HV_DOUBLES + NV + 84 + 99 + lin_stage_doubles(maxL) + 3 * MAXPN + 18 + 55 * PROJ_PAIR + 9 + PRH_N * (PRH_N + 1) / 2) * sizeof(double) + (size_t)(NC + 16) * sizeof(int);
+  const int n = lin_prh_n(maxP, maxL);
+  return lin_smem_base(maxP, maxL) + (size_t)(n * (n + 1) / 2) * sizeof(double);
 }
 
 }  // namespace vpl

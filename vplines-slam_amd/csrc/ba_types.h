@@ -80,12 +80,12 @@ struct DevBatch {
   int *ps_list, *ps_cnt;                         // [W][maxP] track ids sorted by start frame ; [W][12] prefix offsets
   // point phase of k_lin: rounds of 512 lanes = 32 quarter-wave slots; a slot holds up to 8 work units (start frame, k,
   // tracks) packed on even lane boundaries.  pu_lane: (track | k << 16 | s << 20, observation offset) of every lane (-1: idle).  pu_sub: per slot 8 x
-  // (descriptor s | j << 4 | ks0 << 8 | ks1 << 12 | 1 << 16, commit ticket), descriptor 0 ends the list.  Slot r of a round
-  // belongs to wave r % 8, quarter r / 8.
+  // (descriptor s | j << 4 | ks0 << 8 | ks1 << 12 | 1 << 16, commit ticket), descriptor 0 ends the list.  All units of a
+  // chunk of tracks sit in the same half of the work-group (waves 0..3 / 4..7).
   int *pu_lane, *pu_sub;                         // [W][maxPR][512][2] ; [W][maxPR][32][8][2]
-  double *pfac;                                  // [W][maxPO][14] per-factor terms of the per-track sums (H_ll g_l W_s W_ext), summed in k order
   int *pu_cnt, *pu_cnt0;                         // [W] rounds ; [W] rounds that hold the units of start frame 0 (they come first)
   int maxPR;
+  int prhN;                                      // largest prior whose J0^T J0 k_lin keeps in LDS (lin_prh_n)
   int *ln_start, *ln_nobs, *ln_off;              // [W][maxL]
   double *ln_obs;                                // [W][maxLO][8]
   int *nLO, *lo_ln;                              // [W] line observation count ; [W][maxLO] observation -> line

@@ -346,84 +346,6 @@ VPL_HD void projection_factor(const double* pi, const double* pj, const double* 
   }
 }
 
-// The part of the projection factor's Jacobians that depends on the pair of frames (and the extrinsics) only, not on the
-// point: k_lin works it out once per pair (i < j) instead of once per factor.  Layout (PROJ_PAIR doubles):
-//   ric^T Rj^T (9) | A = ric^T Rj^T Ri (9) | Ce = ric^T (Rj^T Ri - I) (9) | T = A ric (9) | ric^T (Rj^T (Ri tic + Pi - Pj) - tic) (3)
-constexpr int PROJ_PAIR = 39;
-VPL_HD int proj_pair_index(int i, int j) { return 10 * i - i * (i - 1) / 2 + (j - i - 1); }   // i < j <= 10
-VPL_HD void projection_pair_setup(const double* pi, const double* pj, const double* ex, double* out) {
-  V3 Pi{pi[0], pi[1], pi[2]}, Pj{pj[0], pj[1], pj[2]}, tic{ex[0], ex[1], ex[2]};
-  M3 Ri = qmat(qpose(pi)), Rj = qmat(qpose(pj)), ric = qmat(qpose(ex));
-  M3 ricT_RjT = mulTA(ric, transpose(Rj));
-  M3 A = mul(ricT_RjT, Ri);
-  M3 RjT_Ri_mI = mulTA(Rj, Ri);
-  RjT_Ri_mI.m[0] -= 1.0; RjT_Ri_mI.m[4] -= 1.0; RjT_Ri_mI.m[8] -= 1.0;
-  M3 Ce = mulTA(ric, RjT_Ri_mI);
-  M3 T = mul(A, ric);
-  V3 inner = mulT(Rj, mul(Ri, tic) + Pi - Pj) - tic;
-  V3 s3 = mulT(ric, inner);
-  for (int k = 0; k < 9; ++k) { out[k] = ricT_RjT.m[k]; out[9 + k] = A.m[k]; out[18 + k] = Ce.m[k]; out[27 + k] = T.m[k]; }
-  out[36] = s3.x; out[37] = s3.y; out[38] = s3.z;
-}
-// projection_factor with the pair part read from `pr` (projection_pair_setup) and ric from `ricm` (row-major 3x3)
-VPL_HD void projection_factor_pair(const double* pi, const double* pj, const double* ex, const double* pr,
-                                   const double* ricm, double inv_dep, V3 pts_i, V3 pts_j, double sqrt_info, double* r,
-                                   double* Ji, double* Jj, double* Je, double* Jl) {
-  V3 Pi{pi[0], pi[1], pi[2]}, Pj{pj[0], pj[1], pj[2]}, tic{ex[0], ex[1], ex[2]};
-  Q4 Qi = qpose(pi), Qj = qpose(pj), qic = qpose(ex);
-  const double dep = 1.0 / inv_dep;
-  V3 pts_camera_i{pts_i.x * dep, pts_i.y * dep, pts_i.z * dep};
-  V3 pts_imu_i = qrot(qic, pts_camera_i) + tic;
-  V3 pts_w = qrot(Qi, pts_imu_i) + Pi;
-  V3 pts_imu_j = qrot(qinv(Qj), pts_w - Pj);
-  V3 pts_camera_j = qrot(qinv(qic), pts_imu_j - tic);
-  V3 b1, b2;
-  tangent_basis(pts_j, &b1, &b2);
-  const double ncj = norm(pts_camera_j), rncj = 1.0 / ncj, rnj = 1.0 / norm(pts_j);
-  V3 diff{pts_camera_j.x * rncj - pts_j.x * rnj, pts_camera_j.y * rncj - pts_j.y * rnj, pts_camera_j.z * rncj - pts_j.z * rnj};
-  r[0] = sqrt_info * dot(b1, diff);
-  r[1] = sqrt_info * dot(b2, diff);
-
-  const double rn3 = rncj * rncj * rncj;
-  const double x1 = pts_camera_j.x, x2 = pts_camera_j.y, x3 = pts_camera_j.z;
-  M3 nj_{{rncj - x1 * x1 * rn3, -x1 * x2 * rn3, -x1 * x3 * rn3,
-          -x1 * x2 * rn3, rncj - x2 * x2 * rn3, -x2 * x3 * rn3,
-          -x1 * x3 * rn3, -x2 * x3 * rn3, rncj - x3 * x3 * rn3}};
-  double red[6];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    red[c] = sqrt_info * (b1.x * nj_.m[c] + b1.y * nj_.m[3 + c] + b1.z * nj_.m[6 + c]);
-    red[3 + c] = sqrt_info * (b2.x * nj_.m[c] + b2.y * nj_.m[3 + c] + b2.z * nj_.m[6 + c]);
-  }
-  M3 ricT_RjT, A, Ce, T, ric;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) { ricT_RjT.m[k] = pr[k]; A.m[k] = pr[9 + k]; Ce.m[k] = pr[18 + k]; T.m[k] = pr[27 + k]; ric.m[k] = ricm[k]; }
-  M3 Bi = mul_skew(A, pts_imu_i);
-  M3 Bj = mulTA(ric, skew(pts_imu_j));
-  M3 TS = mul_skew(T, pts_camera_i);
-  M3 S2 = skew(mul(T, pts_camera_i));
-  M3 S3 = skew(V3{pr[36], pr[37], pr[38]});
-  M3 De;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) De.m[k] = -TS.m[k] + S2.m[k] + S3.m[k];
-  V3 tl = mul(T, pts_i);
-  const double sl = -(dep * dep);
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const double a0 = red[3 * rr], a1 = red[3 * rr + 1], a2 = red[3 * rr + 2];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      Ji[6 * rr + c] = a0 * ricT_RjT.m[c] + a1 * ricT_RjT.m[3 + c] + a2 * ricT_RjT.m[6 + c];
-      Ji[6 * rr + 3 + c] = -(a0 * Bi.m[c] + a1 * Bi.m[3 + c] + a2 * Bi.m[6 + c]);
-      Jj[6 * rr + c] = -(a0 * ricT_RjT.m[c] + a1 * ricT_RjT.m[3 + c] + a2 * ricT_RjT.m[6 + c]);
-      Jj[6 * rr + 3 + c] = a0 * Bj.m[c] + a1 * Bj.m[3 + c] + a2 * Bj.m[6 + c];
-      Je[6 * rr + c] = a0 * Ce.m[c] + a1 * Ce.m[3 + c] + a2 * Ce.m[6 + c];
-      Je[6 * rr + 3 + c] = a0 * De.m[c] + a1 * De.m[3 + c] + a2 * De.m[6 + c];
-    }
-    Jl[rr] = (a0 * tl.x + a1 * tl.y + a2 * tl.z) * sl;
-  }
-}
-
 // ---- line / VP factors --------------------------------------------------------
 // Shared transform chain.  jel (2x3) is d r / d nc for the line factor and the
 // reference's literal "jaco_e_l" for the VP factor; sel selects which half of the

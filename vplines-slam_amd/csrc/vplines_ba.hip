@@ -189,7 +189,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   B.maxP = c->maxP; B.maxPO = c->maxPO; B.maxL = c->maxL; B.maxLO = c->maxLO;
   B.nfull = NC + B.maxP + 4 * B.maxL;
   // point work units of k_lin: (start frame, chunk of <= 16 tracks, observation); a unit needs at most one quarter-wave slot
-  B.maxPR = ((B.maxP / 16 + NF) * (NF - 1) + 31) / 32;
+  B.maxPR = (B.maxP / 16 + NF) * (NF - 1) / 32 + 2;   // the halves of the work-group differ by less than one chunk's units
   const size_t W = max_windows;
   hipError_t e = hipSuccess;
 #define AL(ptr, n) if (e == hipSuccess) e = dalloc(c, &B.ptr, (size_t)(n))
@@ -200,7 +200,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(plk, W * B.maxL * 6); AL(gauge, W * 4); AL(fail_ref, W * 13); AL(orth_in, W);
   AL(nP, W); AL(nL, W);
   AL(pt_start, W * B.maxP); AL(pt_nobs, W * B.maxP); AL(pt_off, W * B.maxP); AL(pt_obs, W * B.maxPO * 3);
-  AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1)); AL(pu_lane, W * B.maxPR * 1024); AL(pu_sub, W * B.maxPR * 512); AL(pu_cnt, W); AL(pu_cnt0, W); AL(pfac, W * B.maxPO * 14);
+  AL(ps_list, W * B.maxP); AL(ps_cnt, W * (NF + 1)); AL(pu_lane, W * B.maxPR * 1024); AL(pu_sub, W * B.maxPR * 512); AL(pu_cnt, W); AL(pu_cnt0, W);
   AL(ln_start, W * B.maxL); AL(ln_nobs, W * B.maxL); AL(ln_off, W * B.maxL); AL(ln_obs, W * B.maxLO * 8);
   AL(nLO, W); AL(lo_ln, W * B.maxLO);
   B.llSlots = 512 * ((B.maxL + 8 * (64 / NF) - 1) / (8 * (64 / NF)));   // worst case: 11-frame tracks, 5 lines per wave
@@ -224,7 +224,8 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
     delete c;
     return VPL_E_HIP;
   }
-  if (lin_smem(c->maxP, c->maxL) > 158 * 1024) { for (void* p : c->allocs) hipFree(p); delete c; return VPL_E_CAPACITY; }
+  if (lin_smem_base(c->maxP, c->maxL) > LIN_LDS_BUDGET) { for (void* p : c->allocs) hipFree(p); delete c; return VPL_E_CAPACITY; }
+  B.prhN = lin_prh_n(c->maxP, c->maxL);
   {   // static table of the assembly pass of k_lin
     std::vector<int> tab(2 * NCP);
     for (int r = 0, e2 = 0; r < NC; ++r)
@@ -508,56 +509,67 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
         std::stable_sort(&ps_list[w * B.maxP + cnt[f]], &ps_list[w * B.maxP + cnt[f + 1]],
                          [&](int a, int b) { return v.point_nobs[a] > v.point_nobs[b]; });
       // work units of the point phase of k_lin: (start frame f, observation index k >= 1, <= 16 of the tracks seen at k),
-      // packed first-fit into quarter-wave slots (full units take a slot, small ones share one on even lane boundaries)
+      // packed first-fit into quarter-wave slots (full units take a slot, small ones share one on even lane boundaries).
+      // All units of a chunk of tracks go to the same HALF of the work-group (waves 0..3 or 4..7): the per-track sums over
+      // k are then ordered by one four-wave chain per half and need no second copy.
       struct Slot { int used, nsub, desc[8], first[8], cnt[8], lane0[8], k[8]; };
-      std::vector<Slot> slots;
-      std::vector<int> open;
-      int slots0 = 0;
+      std::vector<Slot> slots[2];
+      std::vector<int> open[2];
+      int slots0[2] = {0, 0}, load[2] = {0, 0};
       for (int f = 0; f < NF; ++f) {
         const int c0 = cnt[f], c1 = cnt[f + 1];
         const int maxno = c1 > c0 ? v.point_nobs[ps_list[w * B.maxP + c0]] : 0;
+        std::vector<int> half_of((c1 - c0 + 15) / 16, -1);
         for (int k = 1; k < maxno; ++k) {
           int ck = 0;
           while (c0 + ck < c1 && v.point_nobs[ps_list[w * B.maxP + c0 + ck]] > k) ++ck;
           for (int q = 0; q < ck; q += 16) {
             const int n = std::min(16, ck - q), need = (n + 1) & ~1;
-            int si = -1;
-            for (size_t o = 0; o < open.size() && si < 0; ++o)
-              if (16 - slots[open[o]].used >= need) si = open[o];
-            if (si < 0) {
-              si = (int)slots.size();
-              slots.push_back(Slot{});
-              open.push_back(si);
+            int& hf = half_of[q / 16];
+            if (hf < 0) {   // the chunk's lanes over all k go to the lighter half
+              hf = load[1] < load[0] ? 1 : 0;
+              for (int m = q; m < std::min(q + 16, c1 - c0); ++m) load[hf] += v.point_nobs[ps_list[w * B.maxP + c0 + m]] - 1;
             }
-            Slot& S = slots[si];
+            std::vector<Slot>& SL = slots[hf];
+            std::vector<int>& OP = open[hf];
+            int si = -1;
+            for (size_t o = 0; o < OP.size() && si < 0; ++o)
+              if (16 - SL[OP[o]].used >= need) si = OP[o];
+            if (si < 0) {
+              si = (int)SL.size();
+              SL.push_back(Slot{});
+              OP.push_back(si);
+            }
+            Slot& S = SL[si];
             const int i = S.nsub++;
             S.lane0[i] = S.used; S.first[i] = c0 + q; S.cnt[i] = n; S.k[i] = k;
             S.desc[i] = f | (f + k) << 4 | (S.used / 2) << 8 | ((S.used + need) / 2) << 12 | 1 << 16;
             S.used += need;
-            if (S.used == 16) open.erase(std::find(open.begin(), open.end(), si));
-            if (f == 0) slots0 = std::max(slots0, si + 1);
+            if (S.used == 16) OP.erase(std::find(OP.begin(), OP.end(), si));
+            if (f == 0) slots0[hf] = std::max(slots0[hf], si + 1);
           }
         }
       }
-      const int rounds = ((int)slots.size() + 31) / 32;
+      const int rounds = (int)(std::max(slots[0].size(), slots[1].size()) + 15) / 16;
       if (rounds > B.maxPR) return fail(c, VPL_E_CAPACITY, "point work-unit table too small");
       pu_cnt[w] = rounds;
-      pu_cnt0[w] = (slots0 + 31) / 32;
+      pu_cnt0[w] = (std::max(slots0[0], slots0[1]) + 15) / 16;
       int* lt = &pu_lane[w * B.maxPR * 1024];
       int* st = &pu_sub[w * B.maxPR * 512];
-      for (size_t si = 0; si < slots.size(); ++si) {
-        const int rnd = (int)si / 32, r = (int)si % 32, wave = r % 8, qq = r / 8;
-        const Slot& S = slots[si];
-        for (int i = 0; i < S.nsub; ++i) {
-          for (int m = 0; m < S.cnt[i]; ++m) {
-            const int p = ps_list[w * B.maxP + S.first[i] + m];
-            int* e = &lt[(rnd * 512 + wave * 64 + qq * 16 + S.lane0[i] + m) * 2];
-            e[0] = p | S.k[i] << 16 | (S.desc[i] & 15) << 20;
-            e[1] = pt_off[w * B.maxP + p];
+      for (int hf = 0; hf < 2; ++hf)
+        for (size_t si = 0; si < slots[hf].size(); ++si) {   // slot i of a half: round i / 16, wave 4 hf + i % 4, quarter (i % 16) / 4
+          const int rnd = (int)si / 16, wave = 4 * hf + (int)si % 4, qq = ((int)si % 16) / 4;
+          const Slot& S = slots[hf][si];
+          for (int i = 0; i < S.nsub; ++i) {
+            for (int m = 0; m < S.cnt[i]; ++m) {
+              const int p = ps_list[w * B.maxP + S.first[i] + m];
+              int* e = &lt[(rnd * 512 + wave * 64 + qq * 16 + S.lane0[i] + m) * 2];
+              e[0] = p | S.k[i] << 16 | (S.desc[i] & 15) << 20;
+              e[1] = pt_off[w * B.maxP + p];
+            }
+            st[((rnd * 32 + wave * 4 + qq) * 8 + i) * 2] = S.desc[i];
           }
-          st[((rnd * 32 + wave * 4 + qq) * 8 + i) * 2] = S.desc[i];
         }
-      }
       // commit tickets: two chains (waves 0..3 / 4..7).  A wave reaches its units in (round, quarter, unit) order; the
       // chain serves, among the four waves' next units, the one a rough cycle model expects to be ready first, so that a
       // slot packed with many small units does not hold up the waves whose slots are full ones
