@@ -22,6 +22,7 @@ for w in (0, 1, 300):
     ctx.lib.vpl_ba_debug_stamps(ctx.h, w, out)
     s = list(out)
     print("window", w, "k_solve phases (cycles):", [s[i + 1] - s[i] for i in range(0, 7)])
+    print("   back substitution of the landmarks: cams->uc %d points %d lines %d sums %d" % (s[8] - s[5], s[9] - s[8], s[10] - s[9], s[6] - s[10]))
     print("   cholesky split: update(a) %d diag(b) %d (16 steps alone: %d) trsm(c) %d" % (s[40], s[41], s[43], s[42]))
     print("   schur chunk loop (thread 0): stage %d mfma %d barrier wait %d" % (s[52], s[53], s[54]))
     print("   point phase (wave 0): factor math %d per-factor terms %d staging %d mfma %d ticket wait %d commit %d" % tuple(s[44:50]))

@@ -163,39 +163,10 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
     bool solved = false;
     double alpha = 0.0;
     while (mu < kMaxMu) {
-      // per-landmark regularised blocks: points A = s^2 H + mu d^2 -> row scale s/sqrt(A) (kept in ggn as
-      // scratch); lines A_l = S H S + mu D^2 = C C^T -> C kept in lch
-      for (int p = tid; p < nP; p += T) {
-        const size_t pi = (size_t)w * B.maxP + p;
-        const double s = gscale[LP + p], d = gdiag[LP + p];
-        const double Al = s * s * B.Hpp[pi] + mu * d * d;
-        if (!(Al > 0.0)) flag[0] = 1;
-        ggn[LP + p] = s / sqrt(Al);
-      }
-      for (int l = tid; l < nL; l += T) {
-        const size_t li = (size_t)w * B.maxL + l;
-        const double* Hl = B.Hll + li * 16;
-        double A[10];
-        int t = 0;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) if (b <= a) {
-            A[t] = gscale[LL + 4 * l + a] * gscale[LL + 4 * l + b] * Hl[4 * a + b];
-            if (a == b) { const double d = gdiag[LL + 4 * l + a]; A[t] += mu * d * d; }
-            ++t;
-          }
-        bool ok = true;
-        chol4(A, ok);
-        if (!ok) flag[0] = 1;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) lch[l * 10 + k] = A[k];
-      }
-      __syncthreads();
-      // ---- Schur accumulation on the matrix cores: Acc = X^T X over all landmark rows, where a row of
-      //      X is C^-1 S_l [W | g | e] (e chosen so that X^T e = W^T u: the Cauchy cross term).
-      //      Rows are streamed through two LDS buffers of CROWS x CW; 15 lower 16x16 tiles of the compact
-      //      80x80 result stay in accumulator registers (2 tiles per wave).
+      // Schur accumulation on the matrix cores: Acc = X^T X over all landmark rows, where a row of X is
+      // C^-1 S_l [W | g | e] (e chosen so that X^T e = W^T u: the Cauchy cross term).  Rows are streamed through two LDS
+      // buffers of CROWS x CW; 15 lower 16x16 tiles of the compact 80x80 result stay in accumulator registers (2 tiles
+      // per wave).
       v4d acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
       int ta0 = 0, tb0 = 0, ta1 = 0, tb1 = 0;
       tri_decode(wv, ta0, tb0);
@@ -205,35 +176,62 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       const int nch = nchP + nchL;
       double* buf0 = S;
       double* buf1 = S + CROWS * CW;
-      // Per-landmark constants of the row transform go to LDS once (behind the two staging buffers): row scale and
-      // e-value of the points, Cholesky factor / scale / e-vector of the lines.
+      // Per-landmark constants of the row transform, in LDS behind the two staging buffers: row scale and e-value of the
+      // points, Cholesky factor / scale / e-vector of the lines.
       double* pS = S + 2 * CROWS * CW;        // nP   s / sqrt(A)
       double* pE = pS + B.maxP;               // nP   e = u / (s / sqrt(A))
       double* lC = pE + B.maxP;               // nL x 10
       double* lS = lC + 10 * B.maxL;          // nL x 4   jacobi scale / diagonal of C: the row solve multiplies, never divides
       double* lE = lS + 4 * B.maxL;           // nL x 4   e = C^T (u ./ s),  u = s g~ / d  =>  u/s = g~/d
+      // per-landmark regularised blocks: points A = s^2 H + mu d^2 -> row scale s/sqrt(A); lines A_l = S H S + mu D^2 =
+      // C C^T -> C to lch (the back substitution reads it) and, pre-divided, to LDS.  ONE pass per landmark kind, every
+      // HBM operand requested before the arithmetic: as two passes with the row scale / factor handed over through HBM the
+      // second one waited for the first one's stores and then for its own loads.
       for (int p = tid; p < nP; p += T) {
-        const double smv = ggn[LP + p];
+        const size_t pi = (size_t)w * B.maxP + p;
+        const double s = gscale[LP + p], d = gdiag[LP + p], g = ggrad[LP + p], h = B.Hpp[pi];
+        const double Al = s * s * h + mu * d * d;
+        if (!(Al > 0.0)) flag[0] = 1;
+        const double smv = s / sqrt(Al);
         pS[p] = smv;
-        pE[p] = (gscale[LP + p] * ggrad[LP + p] / gdiag[LP + p]) / smv;
+        pE[p] = (s * g / d) / smv;
       }
       for (int l = tid; l < nL; l += T) {
-        double C[10], us[4];
+        const size_t li = (size_t)w * B.maxL + l;
+        double Hl[16], s4[4], d4[4], g4[4];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) { C[q] = lch[l * 10 + q]; lC[l * 10 + q] = C[q]; }
+        for (int k = 0; k < 16; ++k) Hl[k] = B.Hll[li * 16 + k];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { s4[a] = gscale[LL + 4 * l + a]; d4[a] = gdiag[LL + 4 * l + a]; g4[a] = ggrad[LL + 4 * l + a]; }
+        double A[10];
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) if (b <= a) {
+            A[t] = s4[a] * s4[b] * Hl[4 * a + b];
+            if (a == b) A[t] += mu * d4[a] * d4[a];
+            ++t;
+          }
+        bool ok = true;
+        chol4(A, ok);
+        if (!ok) flag[0] = 1;
+        double us[4];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { lch[l * 10 + k] = A[k]; lC[l * 10 + k] = A[k]; }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          const double rd = 1.0 / C[tri(a, a)];
-          lS[4 * l + a] = gscale[LL + 4 * l + a] * rd;   // x_a = (s_a w_a - sum_q C_aq x_q) / C_aa = lS_a w_a - sum_q (C_aq / C_aa) x_q
-          us[a] = ggrad[LL + 4 * l + a] / gdiag[LL + 4 * l + a];
+          const double rd = 1.0 / A[tri(a, a)];
+          lS[4 * l + a] = s4[a] * rd;   // x_a = (s_a w_a - sum_q C_aq x_q) / C_aa = lS_a w_a - sum_q (C_aq / C_aa) x_q
+          us[a] = g4[a] / d4[a];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) if (q < a) lC[l * 10 + tri(a, q)] = C[tri(a, q)] * rd;
+          for (int q = 0; q < 4; ++q) if (q < a) lC[l * 10 + tri(a, q)] = A[tri(a, q)] * rd;
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           double s2 = 0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) if (q >= a) s2 += C[tri(q, a)] * us[q];
+          for (int q = 0; q < 4; ++q) if (q >= a) s2 += A[tri(q, a)] * us[q];
           lE[4 * l + a] = s2;
         }
       }
@@ -604,6 +602,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       a3 += ggrad[c] * gnv;
     }
     __syncthreads();
+    VPL_STAMP(B, w, 8);
     // ---- landmark back substitution y_l = A_l^-1 S_l (g_l - W_l S_c y_c): 8 lanes per landmark row so
     //      that every 72-wide row of W is read as one contiguous 576-byte segment
     {
@@ -650,54 +649,73 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
           }
         }
       }
-      for (int r0 = 0; r0 < 4 * nL; r0 += T / 8) {
-        const int r = r0 + grp, l = r >> 2, a = r & 3;
-        double wy = 0.0;
-        size_t li = 0;
-        if (l < nL) {
-          li = (size_t)w * B.maxL + l;
-          const int s0 = lSt[l];
-          for (int blk = sub; blk < nblk; blk += 8) {
-            const bool exb = blk == nblk - 1;
-            const int vb = exb ? 66 : 6 * (s0 + blk);
-            if (!exb && vb >= 66) continue;
-            const double* Wr = B.Wl + (li * 4 + a) * WS + 6 * blk;
+      VPL_STAMP(B, w, 9);
+      // lines: NLH row groups per trip, each row's W entries and g_l requested together; the rows' right-hand sides
+      // s (g_l - W_l u_c) go to LDS (the reduced system's space is free by now) and ONE pass with a lane per line does the
+      // 4x4 triangular solves -- done by the leader lane of each group they were a chain of 8 divisions per 64 rows
+      double* lrhs = S;
+      constexpr int NLH = 3;
+      for (int r0 = 0; r0 < 4 * nL; r0 += NLH * (T / 8)) {
+        double wyv[NLH], glv[NLH];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) wy += Wr[k] * uc[vis2cam(vb + k)];
+        for (int h = 0; h < NLH; ++h) {
+          const int r = r0 + h * (T / 8) + grp, l = r >> 2, a = r & 3;
+          wyv[h] = 0.0; glv[h] = 0.0;
+          if (l < nL) {
+            const size_t li = (size_t)w * B.maxL + l;
+            const int s0 = lSt[l];
+            for (int blk = sub; blk < nblk; blk += 8) {
+              const bool exb = blk == nblk - 1;
+              const int vb = exb ? 66 : 6 * (s0 + blk);
+              if (!exb && vb >= 66) continue;
+              const double* Wr = B.Wl + (li * 4 + a) * WS + 6 * blk;
+#pragma unroll
+              for (int k = 0; k < 6; ++k) wyv[h] += Wr[k] * uc[vis2cam(vb + k)];
+            }
+            if (sub == 0) glv[h] = B.gl[li * 4 + a];
           }
         }
-        wy += __shfl_xor(wy, 1, 64); wy += __shfl_xor(wy, 2, 64); wy += __shfl_xor(wy, 4, 64);
-        // the 4 rows of a line sit in 4 adjacent 8-lane groups of the same wave: gather on the first
-        const double t1 = __shfl(wy, (lane & 32) + 8, 64), t2 = __shfl(wy, (lane & 32) + 16, 64), t3 = __shfl(wy, (lane & 32) + 24, 64);
-        if (l < nL && (lane & 31) == 0) {
-          const double* C = lch + l * 10;
-          double t4[4] = {wy, t1, t2, t3};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) t4[k] = gscale[LL + 4 * l + k] * (B.gl[li * 4 + k] - t4[k]);
+        for (int h = 0; h < NLH; ++h) {
+          const int r = r0 + h * (T / 8) + grp;
+          double wy = wyv[h];
+          wy += __shfl_xor(wy, 1, 64); wy += __shfl_xor(wy, 2, 64); wy += __shfl_xor(wy, 4, 64);
+          if (r < 4 * nL && sub == 0) lrhs[r] = gscale[LL + r] * (glv[h] - wy);
+        }
+      }
+      __syncthreads();
+      for (int l = tid; l < nL; l += T) {
+        double C[10], t4[4], gd4[4], gr4[4];   // the factor, diagonal and gradient come from HBM: one batch, before the chain
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            double s2 = t4[k];
+        for (int k = 0; k < 10; ++k) C[k] = lch[l * 10 + k];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (j < k) s2 -= C[tri(k, j)] * t4[j];
-            t4[k] = s2 / C[tri(k, k)];
-          }
+        for (int k = 0; k < 4; ++k) { gd4[k] = gdiag[LL + 4 * l + k]; gr4[k] = ggrad[LL + 4 * l + k]; }
 #pragma unroll
-          for (int k = 3; k >= 0; --k) {
-            double s2 = t4[k];
+        for (int k = 0; k < 4; ++k) t4[k] = lrhs[4 * l + k];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (j > k) s2 -= C[tri(j, k)] * t4[j];
-            t4[k] = s2 / C[tri(k, k)];
-          }
+        for (int k = 0; k < 4; ++k) {
+          double s2 = t4[k];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const double gnv = -gdiag[LL + 4 * l + k] * t4[k];
-            ggn[LL + 4 * l + k] = gnv;
-            a2 += gnv * gnv;
-            a3 += ggrad[LL + 4 * l + k] * gnv;
-          }
+          for (int j = 0; j < 4; ++j) if (j < k) s2 -= C[tri(k, j)] * t4[j];
+          t4[k] = s2 / C[tri(k, k)];
+        }
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+          double s2 = t4[k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (j > k) s2 -= C[tri(j, k)] * t4[j];
+          t4[k] = s2 / C[tri(k, k)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double gnv = -gd4[k] * t4[k];
+          ggn[LL + 4 * l + k] = gnv;
+          a2 += gnv * gnv;
+          a3 += gr4[k] * gnv;
         }
       }
     }
+    VPL_STAMP(B, w, 10);
     a2 = block_sum(a2, red);
     a3 = block_sum(a3, red);
     if (tid == 0) {

@@ -574,7 +574,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       // chain serves, among the four waves' next units, the one a rough cycle model expects to be ready first, so that a
       // slot packed with many small units does not hold up the waves whose slots are full ones
       for (int hf = 0; hf < 2; ++hf) {
-        const int F = 12000, STAGE = 300, KS = 160, SUB = 250, COMMIT = 450;   // factor math, staging, per MFMA step, per unit, per commit
+        const int F = 11000, STAGE = 1200, KS = 170, SUB = 200, COMMIT = 700;   // factor math, staging, per MFMA step, per unit, per commit
         int pos[4] = {0, 0, 0, 0};          // next item of each wave: round * 32 + qq * 8 + i
         long clk[4] = {F, F, F, F}, chain = 0;
         bool staged[4] = {false, false, false, false};
