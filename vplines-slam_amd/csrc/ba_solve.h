@@ -92,7 +92,6 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
   double* gdiag = B.diag + fb;
   double* ggrad = B.grad + fb;
   double* ggn = B.gn + fb;
-  double* gdelta = B.delta + fb;
   const double* Hcc = B.Hcc + (size_t)w * NCP;
   const double* gc = B.gc + (size_t)w * NC;
   double* lch = B.lchol + (size_t)w * B.maxL * 10;
@@ -100,8 +99,13 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
   if (tid == 0) { flag[0] = 0; flag[1] = 0; }
   __syncthreads();
 
+  // The Gauss-Newton step and the dogleg step also live in LDS (the reduced system's space is free when they are made): read
+  // back from HBM right after being stored, each cost the store's completion plus a load round trip (~3 us apiece)
+  double* lgn = S + 4 * B.maxL;    // nfull  Gauss-Newton step (scaled space), copy of ggn
+  double* gdelta = lgn + B.nfull;  // nfull  step * jacobi scale
+  const bool reuse0 = tr->reuse != 0;
   VPL_STAMP(B, w, 0);
-  if (!tr->reuse) {
+  if (!reuse0) {
     // ---- jacobi scaling (iteration 0 only), diagonal_, gradient_ --------------------------
     const bool first = (tr->iter == 0);
     double a1 = 0.0, q = 0.0;
@@ -597,7 +601,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       const double y = yv[c];
       uc[c] = sc[c] * y;
       const double gnv = -dg[c] * y;
-      ggn[c] = gnv;
+      ggn[c] = gnv; lgn[c] = gnv;
       a2 += gnv * gnv;
       a3 += ggrad[c] * gnv;
     }
@@ -643,7 +647,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
             const double Al = s * s * hv[h] + mu * d * d;
             const double y = s * (gv2[h] - wy) / Al;
             const double gnv = -d * y;
-            ggn[LP + p] = gnv;
+            ggn[LP + p] = gnv; lgn[LP + p] = gnv;
             a2 += gnv * gnv;
             a3 += grv[h] * gnv;
           }
@@ -709,7 +713,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const double gnv = -gd4[k] * t4[k];
-          ggn[LL + 4 * l + k] = gnv;
+          ggn[LL + 4 * l + k] = gnv; lgn[LL + 4 * l + k] = gnv;
           a2 += gnv * gnv;
           a3 += gr4[k] * gnv;
         }
@@ -773,7 +777,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
   const int nfull_used = NC + B.maxP + 4 * nL;
   for (int k = tid; k < nfull_used; k += T) {
     const bool live = k < NC || (k >= LP && k < LP + nP) || k >= LL;
-    if (live) gdelta[k] = gscale[k] * (-c1 * ggrad[k] + c2 * ggn[k]) / gdiag[k];
+    if (live) gdelta[k] = gscale[k] * (-c1 * ggrad[k] + c2 * (reuse0 ? ggn[k] : lgn[k])) / gdiag[k];   // (a re-used step comes from HBM)
   }
   __syncthreads();
   double sn = 0.0, xn = 0.0;

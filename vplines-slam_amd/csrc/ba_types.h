@@ -131,7 +131,7 @@ struct DevBatch {
 
   // ---- trust region vectors over the full index ----
   TrState *tr;                                   // [W]
-  double *scale, *diag, *grad, *gn, *delta;      // [W][nfull]
+  double *scale, *diag, *grad, *gn;              // [W][nfull]
 
   // ---- marginalisation ----
   int *mg_n, *mg_nb;                             // [W] new prior size / blocks

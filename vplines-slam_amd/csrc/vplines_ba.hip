@@ -212,7 +212,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(Hcc, W * NCP); AL(gc, W * NC); AL(asm_tab, 2 * NCP); AL(Hpp, W * B.maxP); AL(gp, W * B.maxP); AL(Wp, W * B.maxP * NV);
   AL(Hll, W * B.maxL * 16); AL(gl, W * B.maxL * 4); AL(Wl, W * B.maxL * 4 * NV); AL(lchol, W * B.maxL * 10);
   AL(tr, W);
-  AL(scale, W * B.nfull); AL(diag, W * B.nfull); AL(grad, W * B.nfull); AL(gn, W * B.nfull); AL(delta, W * B.nfull);
+  AL(scale, W * B.nfull); AL(diag, W * B.nfull); AL(grad, W * B.nfull); AL(gn, W * B.nfull);
   AL(mg_n, W); AL(mg_nb, W); AL(mg_kind, W * MAXPB); AL(mg_frame, W * MAXPB); AL(mg_idx, W * MAXPB);
   AL(mg_cam, W * MAXPB); AL(mg_x0, W * MAXPB * 9); AL(mg_J0, W * MAXKEEP * MAXKEEP); AL(mg_r0, W * MAXKEEP);
   AL(mg_A, W * MAXKEEP * MAXKEEP); AL(mg_b, W * MAXKEEP); AL(mg_m, W); AL(dbg, W * 64); AL(ln_removed, W * B.maxL); AL(ln_tri, W * B.maxL);
