@@ -327,7 +327,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #else
 #define PT_LAP(i) do {} while (0)
 #endif
-    // A global round trip costs ~3 us when all CUs are in this phase together: the lane records (track, k, start frame,
+    // A global round trip costs ~3 k cycles (1.3 us) when all CUs are in this phase together: the lane records (track, k, start frame,
     // observation offset -- everything the loads of the factor need) and the unit table of round r + 1 are fetched while
     // round r is worked on, so that a round starts one round trip deep, not three.
     int2 rec_n = nRounds > 0 ? plane[tid] : int2{-1, 0};
@@ -817,7 +817,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   double* Hout = B.Hcc + (size_t)w * NCP;
   const double* pH = B.pr_H + (size_t)w * B.prS;
   // Every entry is stored ONCE, with its three sources summed in registers: adding to what an earlier pass had stored
-  // is a global read-modify-write, i.e. a full round trip (~3 us with all CUs in this phase) behind every store.
+  // is a global read-modify-write, i.e. a full round trip (~3 k cycles with all CUs in this phase) behind every store.
   // (1) the 3570 entries the IMU factors touch (11 diagonal 15x15 blocks, 10 sub-diagonal ones), each summing its one or
   // two J^T J terms, go to LDS; (2) rows to waves, columns to lanes: visual block + IMU block + prior (J0^T J0 staged in LDS
   // by the prior phase), coalesced stores, no index decoding beyond c / 15.  Priors larger than PRH_N (none in the

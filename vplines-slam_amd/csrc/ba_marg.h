@@ -217,10 +217,97 @@ __device__ int psd_pivoted_cholesky(double* A, int n, int ld, int* perm, double*
   return rank;
 }
 
+// The same factorisation (same arithmetic per entry, same pivots, same bits) by ONE wave for n <= NMAX <= 48, the matrix
+// in registers: lane j owns column j (a[i] = A(i, j), static indices only), its diagonal entry and its rhs entry.  A pivot
+// step is: arg-max of the live diagonals by shuffles; the pivot lane writes its scaled column to an LDS vector (col); every
+// lane reads its own entry l_j and, broadcast, every l_i, and updates its column -- no work-group barrier and no swaps
+// (the permutation is applied once at the end).  The work-group version above pays five barriers per pivot step
+// (~3.9 k cycles; 175 k for the 45 x 45 kept block).  All threads of the block must call it; Lo is n x ld scratch.
+template <int NMAX>
+__device__ int psd_pivoted_cholesky_wave(double* A, int n, int ld, int* perm, int* iflag, double rel_tol, double abs_tol,
+                                         double* c, double* Lo /* n x ld + NMAX doubles */) {
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
+  double* col = Lo + n * ld;             // NMAX: the pivot column, zero beyond n -- the loops over it have no bounds checks
+  if (tid < 64) {
+    double a[NMAX];
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) a[i] = (i < n && lane < n) ? A[i * ld + lane] : 0.0;
+    double diag = lane < n ? A[lane * ld + lane] : -1.0;
+    double cj = (c && lane < n) ? c[lane] : 0.0;
+    bool alive = lane < n;
+    unsigned long long mask = __ballot(alive);
+    int rank = n;
+    double tol = 0.0;
+    for (int k = 0; k < n; ++k) {
+      // pivot: the largest live diagonal, first index on ties -- maximum by DPP row steps + four readlanes (VALU only; a
+      // shuffle butterfly over (value, index) is six dependent LDS-path round trips), index from the ballot of the lanes
+      // that hold it.  Dead lanes and the DPP fill value count as 0: no live diagonal above 0 ends the factorisation.
+      const double best = alive ? diag : 0.0;
+      double mx = best;
+      mx = fmax(mx, dpp_shr_f64<0x111>(mx));
+      mx = fmax(mx, dpp_shr_f64<0x112>(mx));
+      mx = fmax(mx, dpp_shr_f64<0x114>(mx));
+      mx = fmax(mx, dpp_shr_f64<0x118>(mx));
+      const double piv = fmax(fmax(readlane_f64(mx, 15), readlane_f64(mx, 31)), fmax(readlane_f64(mx, 47), readlane_f64(mx, 63)));
+      const unsigned long long hit = __ballot(alive && diag == piv);
+      const int p = hit ? __builtin_ctzll(hit) : 0;
+      if (k == 0) tol = fmax(abs_tol, fmax((double)n * 2.220446049250313e-16, rel_tol) * piv);
+      if (!(piv > tol)) { rank = k; break; }
+      const double lkk = sqrt(piv);
+      const double inv = 1.0 / lkk;
+      if (lane == p) {
+        // (rows that are already eliminated get a meaningless entry: it only ever touches their own dead rows and the
+        //  part of Lo above the diagonal, which the final pass never reads)
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) col[i] = a[i] * inv;
+        col[p] = lkk;
+        perm[k] = p;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double lj = lane < n ? col[lane] : 0.0;
+      const bool upd = alive && lane != p;
+      const double ljm = upd ? lj : 0.0;
+#pragma unroll
+      for (int i = 0; i < NMAX; ++i) a[i] -= col[i] * ljm;     // (uniform addresses: broadcast reads, all in flight)
+      if (upd) diag -= lj * lj;
+      if (lane < n) Lo[lane * ld + k] = lj;
+      if (c) {
+        const double yk = readlane_f64(cj, p) * inv;
+        if (upd) cj -= lj * yk;
+        if (lane == p) cj = yk;          // lane p keeps y_k: stored at position k below
+      }
+      if (lane == p) alive = false;
+      mask &= ~(1ull << p);
+      __builtin_amdgcn_wave_barrier();   // col is rewritten by the next pivot lane
+    }
+    // positions rank..n-1: the indices that were never pivots, ascending
+    {
+      const int before = __popcll(mask & ((1ull << lane) - 1ull));
+      if (alive) perm[rank + before] = lane;
+    }
+    if (c && lane < n) col[lane] = cj;   // y_k sits in lane perm[k]
+    if (lane == 0) iflag[0] = rank;
+  }
+  __syncthreads();
+  const int rank = iflag[0];
+  // L(t, k) = Lo(perm[t], k), t >= k, k < rank; everything else zero
+  for (int it = tid; it < n * n; it += T) {
+    const int t = it / n, k = it - t * n;
+    A[t * ld + k] = (k < rank && t >= k) ? Lo[perm[t] * ld + k] : 0.0;
+  }
+  if (c)
+    for (int k = tid; k < n; k += T) c[k] = k < rank ? col[perm[k]] : 0.0;
+  __syncthreads();
+  return rank;
+}
+
 __device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* lam, double* red, int* iflag,
-                                   double rel_tol) {
+                                   double rel_tol, double* Lo /* n x ld scratch */) {
   const int tid = threadIdx.x, T = blockDim.x;
-  const int rank = psd_pivoted_cholesky(A, n, ld, perm, red, iflag, rel_tol, 0.0, nullptr, lam);
+  const int rank = n <= 16 ? psd_pivoted_cholesky_wave<16>(A, n, ld, perm, iflag, rel_tol, 0.0, nullptr, Lo)
+                           : psd_pivoted_cholesky(A, n, ld, perm, red, iflag, rel_tol, 0.0, nullptr, lam);
   // ---- one-sided Jacobi on the rank columns ----
   const int m = (rank + 1) & ~1, half = m / 2;
   const int P = tid >> 3, sub = tid & 7;
@@ -280,12 +367,13 @@ __device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* 
 constexpr int MARG_THREADS = 512;
 constexpr double kMargEps = 1e-8;   // marginalization_factor.h:67
 constexpr double kMargNoiseRel = 1e-9;   // pivots of the kept block below this fraction of its largest diagonal are noise
-constexpr int MTROWS = 32;          // landmark rows staged per elimination pass
+constexpr int MTROWS_MAX = 96;      // landmark rows staged per elimination pass: 96 where the prior leaves the LDS for it (every pass
+                                    // costs two global round trips and three barriers), 64 or 32 for large priors
 static_assert(MAXKEEP <= 80, "psd_spectral_factor keeps 10 rows per lane (8 lanes per column pair)");
 
 // LDS layout of k_marg (doubles), shared by host (size) and device (offsets)
 struct MargLayout {
-  int ldm, EB, nd, ldd, total;
+  int ldm, EB, nd, ldd, total, mtrows;
 };
 __host__ __device__ inline MargLayout marg_layout(int n) {
   MargLayout L;
@@ -295,7 +383,10 @@ __host__ __device__ inline MargLayout marg_layout(int n) {
   L.nd = 15 + n;
   L.ldd = L.nd | 1;
   // G (kept block) | Ad (nd x ldd) | tile | E15 (15 x 17) | bv(nd) | tmp(nd*16) | lam(nn) | red(24) | ints
-  L.total = L.EB + L.nd * L.ldd + MTROWS * 74 + 16 * 17 + L.nd + L.nd * 16 + nn + 16 + 24 + (nn + L.nd + 2048 + 16) / 2 + 4;
+  const int fixed = L.EB + L.nd * L.ldd + 16 * 17 + L.nd + (L.nd * 16 < 640 ? 640 : L.nd * 16) + nn + 16 + 24 + (nn + L.nd + 2048 + 16) / 2 + 4;
+  L.mtrows = MTROWS_MAX;
+  while (L.mtrows > 32 && (size_t)(fixed + L.mtrows * 74) * sizeof(double) > 150 * 1024) L.mtrows -= 32;
+  L.total = fixed + L.mtrows * 74;
   return L;
 }
 
@@ -311,11 +402,12 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   const int nd = md + n, ldd = L.ldd, ldm = L.ldm;
   double* G = sm;                        // n x ldm : kept block -> spectral factor
   double* Ad = G + L.EB;                 // nd x ldd dense pre-marginalisation matrix
+  const int MTROWS = L.mtrows;
   double* tile = Ad + nd * ldd;          // MTROWS x 74
   double* E15 = tile + MTROWS * 74;      // 15 x 17: Amm -> its spectral factor
   double* bv = E15 + 16 * 17;            // nd
-  double* tmp = bv + nd;                 // nd * 16
-  double* lam = tmp + nd * 16;           // max(n, 15) + 1
+  double* tmp = bv + nd;                 // max(nd * 16, 640)
+  double* lam = tmp + (nd * 16 < 640 ? 640 : nd * 16);   // max(n, 15) + 1
   double* red = lam + (n < 2 ? 2 : n) + 16;   // 24
   int* perm = (int*)(red + 24);          // max(n, 15)
   int* dmap = perm + (n < 16 ? 16 : n) + (n & 1);   // nd
@@ -396,8 +488,8 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
     // one global load each, four in flight per lane.  Loading them per element put two dependent global latencies into
     // every trip of the element loop and repeated the 4x4 Cholesky of a line 73 times.
     double* rs = tmp + 128;              // MTROWS point scales
-    double* lineC = tmp + 160;           // (MTROWS / 4) x 10 line factors
-    int* rstart = (int*)(tmp + 240);     // MTROWS start frames
+    double* lineC = tmp + 128 + MTROWS_MAX;                  // (MTROWS / 4) x 10 line factors
+    int* rstart = (int*)(tmp + 128 + MTROWS_MAX + 10 * (MTROWS_MAX / 4));   // MTROWS start frames
     int* rland = rstart + MTROWS;        // MTROWS landmark indices
     if (base < np0) {
       const int cnt = min(MTROWS, np0 - base);
@@ -516,7 +608,7 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   double* Y = tile;   // n x 16 scratch (tile is free now)
   for (int it = tid; it < md * md; it += T) Y[it] = E15[(it / md) * 17 + it % md];   // keep a copy for the fallback
   __syncthreads();
-  const int rank_mm = psd_pivoted_cholesky(E15, md, 17, perm, red, s_flag, 0.0, kMargEps, nullptr, lam);
+  const int rank_mm = psd_pivoted_cholesky_wave<16>(E15, md, 17, perm, s_flag, 0.0, kMargEps, nullptr, tile);
   if (rank_mm == md) {
     VPL_STAMP(B, w, 34);
     for (int i = tid; i < n; i += T) {   // tmp(i, :) = Arm(i, :) Amm^-1 :  L L^T x = P a
@@ -537,7 +629,7 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   } else {
     for (int it = tid; it < md * md; it += T) E15[(it / md) * 17 + it % md] = Y[it];
     __syncthreads();
-    psd_spectral_factor(E15, md, 17, perm, lam, red, s_flag, 0.0);
+    psd_spectral_factor(E15, md, 17, perm, lam, red, s_flag, 0.0, tile);
     VPL_STAMP(B, w, 34);
     // tmp(n x md) = Arm * Amm^+ :  first Y = Arm * B (n x md), then tmp = (Y ./ lambda^2) * B^T
     for (int it = tid; it < n * md; it += T) {
@@ -594,7 +686,9 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   // sign (it keeps the positive part above 1e-8 with a negligible weight).  Pivots below max(1e-8, 1e-9 max diagonal)
   // end the factorisation; the trailing block is treated as zero.
   VPL_STAMP(B, w, 35);
-  const int rank = psd_pivoted_cholesky(G, n, ldm, perm, red, s_flag, kMargNoiseRel, kMargEps, bv, lam);
+  // (the dense pre-marginalisation matrix is not needed any more: its space is the one-wave version's scratch)
+  const int rank = n <= 48 ? psd_pivoted_cholesky_wave<48>(G, n, ldm, perm, s_flag, kMargNoiseRel, kMargEps, bv, Ad)
+                           : psd_pivoted_cholesky(G, n, ldm, perm, red, s_flag, kMargNoiseRel, kMargEps, bv, lam);
   VPL_STAMP(B, w, 36);
   double* J0 = B.mg_J0 + (size_t)w * MAXKEEP * MAXKEEP;
   double* r0 = B.mg_r0 + (size_t)w * MAXKEEP;

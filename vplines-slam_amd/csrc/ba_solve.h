@@ -100,7 +100,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
   __syncthreads();
 
   // The Gauss-Newton step and the dogleg step also live in LDS (the reduced system's space is free when they are made): read
-  // back from HBM right after being stored, each cost the store's completion plus a load round trip (~3 us apiece)
+  // back from HBM right after being stored, each cost the store's completion plus a load round trip (~3 k cycles apiece)
   double* lgn = S + 4 * B.maxL;    // nfull  Gauss-Newton step (scaled space), copy of ggn
   double* gdelta = lgn + B.nfull;  // nfull  step * jacobi scale
   const bool reuse0 = tr->reuse != 0;
