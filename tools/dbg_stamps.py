@@ -28,4 +28,5 @@ for w in (0, 1, 300):
     print("   point phase (wave 0): factor math %d per-factor terms %d staging %d mfma %d ticket wait %d commit %d" % tuple(s[44:50]))
     print("   point phase: rounds of the 8 waves end at", s[56:64], "all joined at", s[51] - s[23], "folded at", s[50] - s[23], "sums stored at", s[55] - s[23], "phase end", s[24] - s[23])
     print("   k_lin: prior %d zero %d points %d lines+fold %d imu %d (raw %d) assemble %d (table wait %d, rows %d, gradient %d)" % (s[18]-s[16], s[23]-s[18], s[24]-s[23], s[25]-s[22], s[20]-s[25], s[28]-s[25], s[21]-s[20], s[26]-s[20], s[27]-s[26], s[21]-s[27]))
+    print("   k_marg elimination: gather %d list %d points staged %d (+product) lines staged %d end %d" % (s[38]-s[32], s[39]-s[38], s[29]-s[39], s[30]-s[29], s[33]-s[30]))
     print("   k_marg: setup+Ad %d landmark-elim %d E15 %d schur %d G-factor %d out %d" % (s[33]-s[32], 0, s[34]-s[33], s[35]-s[34], s[36]-s[35], s[37]-s[36]))

@@ -470,18 +470,32 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
     for (int u = 0; u < 8; ++u)
       if (dst[u] >= 0) Ad[dst[u]] = hv[u];
   }
+  VPL_STAMP(B, w, 38);
   for (int i = tid; i < nd; i += T) bv[i] = gc[dmap[i]];
   // list of the dense dims with a visual index (tmp is free until the Schur complement of the marginalised block)
   int* vlist = (int*)tmp;
-  if (tid == 0) {
-    int k = 0;
-    for (int i = 0; i < nd; ++i)
-      if (cam2vis(dmap[i]) >= 0) vlist[k++] = i;
-    s_flag[2] = k;
+  int* vinv = vlist + 96;   // 72: visual column -> dense index or -1 (nd <= 95 entries of vlist in front of it)
+  if (tid < 64) {   // (wave 0: ballots and prefix counts; one thread walking the nd entries cost 17 k cycles)
+    const int lane = tid;
+    const bool f0 = lane < nd && cam2vis(dmap[lane]) >= 0;
+    const bool f1 = lane + 64 < nd && cam2vis(dmap[lane + 64]) >= 0;
+    const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (f0) vlist[__popcll(m0 & below)] = lane;
+    if (f1) vlist[__popcll(m0) + __popcll(m1 & below)] = lane + 64;
+    if (lane == 0) s_flag[2] = __popcll(m0) + __popcll(m1);
+  } else if (tid < 64 + 72) {
+    vinv[tid - 64] = -1;
+  }
+  __syncthreads();
+  for (int i = tid; i < nd; i += T) {
+    const int vi = cam2vis(dmap[i]);
+    if (vi >= 0) vinv[vi] = i;
   }
   __syncthreads();
   const int nv = s_flag[2];
   const int np0 = s_np0, nl0 = s_nl0;
+  VPL_STAMP(B, w, 39);
   for (int base = 0; base < np0 + nl0; ) {
     int nrows;
     // Per-row constants first (one lane per landmark: its scale or 4x4 factor, its start frame), then the elements with
@@ -574,21 +588,41 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
       base += cnt;
     }
     __syncthreads();
-    // only the dense dims that are visual (pose / extrinsic) dims couple to the landmarks: nv x nv entries, not nd x nd
-    for (int it = tid; it < nv * nv; it += T) {
-      const int a = it / nv, b2 = it - a * nv;
-      const int i = vlist[a], j = vlist[b2];
-      const int vi = cam2vis(dmap[i]), vj = cam2vis(dmap[j]);
-      double s = 0.0;
-      for (int r = 0; r < nrows; ++r) s += tile[r * 74 + vi] * tile[r * 74 + vj];
-      Ad[i * ldd + j] -= s;
-    }
-    for (int i = tid; i < nd; i += T) {
-      const int vi = cam2vis(dmap[i]);
-      if (vi >= 0) {
-        double s = 0.0;
-        for (int r = 0; r < nrows; ++r) s += tile[r * 74 + vi] * tile[r * 74 + 72];
-        bv[i] -= s;
+    VPL_STAMP(B, w, base <= np0 ? 29 : 30);
+    // X^T X of the staged rows on the FP64 matrix cores: 73 columns (72 visual dims + the rhs) = 5 x 5 tiles of 16, the 15
+    // lower ones over the 8 waves; C[a][b] = sum_r X[r][a] X[r][b] with the A lane (kk, m) supplying X[4 ks + kk][16 ta + m].
+    // Only the dense dims with a visual index couple to the landmarks: vinv maps a visual column to its dense index.
+    {
+      const int lane = tid & 63, wv = tid >> 6, m = lane & 15, kk = lane >> 4;
+      const int ksteps = (nrows + 3) >> 2;
+#pragma unroll 1
+      for (int q = 0; q < 2; ++q) {
+        const int tix2 = wv + 8 * q;
+        if (tix2 >= 15) break;
+        int ta, tb;
+        tri_decode(tix2, ta, tb);
+        const int ca = 16 * ta + m, cb = 16 * tb + m;
+        typedef double v4dm __attribute__((ext_vector_type(4)));
+        v4dm acc = {0, 0, 0, 0};
+        for (int ks = 0; ks < ksteps; ++ks) {
+          const int r = 4 * ks + kk;
+          const double av = (r < nrows && ca < 73) ? tile[r * 74 + ca] : 0.0;
+          const double bw = (r < nrows && cb < 73) ? tile[r * 74 + cb] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bw, acc, 0, 0, 0);
+        }
+        const double vals[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int a2 = 16 * ta + kk + 4 * v, b2 = cb;
+          if (b2 >= 72 || a2 > 72) continue;
+          const int j = vinv[b2];
+          if (j < 0) continue;
+          if (a2 == 72) { bv[j] -= vals[v]; continue; }
+          const int i = vinv[a2];
+          if (i < 0) continue;
+          Ad[i * ldd + j] -= vals[v];
+          if (ta != tb) Ad[j * ldd + i] -= vals[v];   // (inside a diagonal tile the mirror entry has a lane of its own)
+        }
       }
     }
     __syncthreads();
@@ -658,13 +692,15 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
     Aout[i * n + j] = v;
     G[i * ldm + j] = v;
   }
-  for (int i = tid; i < n; i += T) {
+  double bkeep = 0.0;   // (n <= MAXKEEP < T: one entry per thread; read back from HBM it cost a store completion + a round trip)
+  if (tid < n) {
     double s = 0;
-    for (int k = 0; k < md; ++k) s += tmp[i * 16 + k] * bv[k];
-    bout[i] = bv[md + i] - s;
+    for (int k = 0; k < md; ++k) s += tmp[tid * 16 + k] * bv[k];
+    bkeep = bv[md + tid] - s;
+    bout[tid] = bkeep;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += T) bv[i] = bout[i];
+  if (tid < n) bv[tid] = bkeep;
   // the reference eigen-decomposes A as it is; symmetrise the copy the factorisation works on
   for (int it = tid; it < n * n; it += T) {
     const int i = it / n, j = it % n;
