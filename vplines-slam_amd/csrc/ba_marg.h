@@ -645,19 +645,35 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   const int rank_mm = psd_pivoted_cholesky_wave<16>(E15, md, 17, perm, s_flag, 0.0, kMargEps, nullptr, tile);
   if (rank_mm == md) {
     VPL_STAMP(B, w, 34);
-    for (int i = tid; i < n; i += T) {   // tmp(i, :) = Arm(i, :) Amm^-1 :  L L^T x = P a
+    // tmp(i, :) = Arm(i, :) Amm^-1 :  L L^T x = P a, one lane per row.  Compile-time loop bounds (md <= 15 guards) keep x in
+    // registers and the reads of L broadcast and pipelined; reciprocal diagonals from LDS: with run-time bounds x lived in
+    // scratch and every step paid an LDS round trip and a division (30 k cycles for 45 rows).
+    double* rdiag = lam;   // md reciprocals of the diagonal of L (lam is free between the factorisations)
+    if (tid < md) rdiag[tid] = 1.0 / E15[tid * 17 + tid];
+    __syncthreads();
+    for (int i = tid; i < n; i += T) {
       double x[15];
-      for (int t = 0; t < md; ++t) {
-        double s2 = Ad[(md + i) * ldd + perm[t]];
-        for (int k = 0; k < t; ++k) s2 -= E15[t * 17 + k] * x[k];
-        x[t] = s2 / E15[t * 17 + t];
+#pragma unroll
+      for (int t = 0; t < 15; ++t) {
+        x[t] = 0.0;
+        if (t < md) {
+          double s2 = Ad[(md + i) * ldd + perm[t]];
+#pragma unroll
+          for (int k = 0; k < t; ++k) s2 -= E15[t * 17 + k] * x[k];
+          x[t] = s2 * rdiag[t];
+        }
       }
-      for (int t = md - 1; t >= 0; --t) {
-        double s2 = x[t];
-        for (int k = t + 1; k < md; ++k) s2 -= E15[k * 17 + t] * x[k];
-        x[t] = s2 / E15[t * 17 + t];
+#pragma unroll
+      for (int t = 14; t >= 0; --t) {
+        if (t < md) {
+          double s2 = x[t];
+#pragma unroll
+          for (int k = t + 1; k < 15; ++k) if (k < md) s2 -= E15[k * 17 + t] * x[k];
+          x[t] = s2 * rdiag[t];
+        }
       }
-      for (int t = 0; t < md; ++t) tmp[i * 16 + perm[t]] = x[t];
+#pragma unroll
+      for (int t = 0; t < 15; ++t) if (t < md) tmp[i * 16 + perm[t]] = x[t];
     }
     __syncthreads();
   } else {
