@@ -274,7 +274,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   // zero the W rows first where some slot is not written by a factor (shorter tracks, erased lines, the start-frame
   // slot of the lines in the marginalisation pass); uniform track lengths need no fill in the solve
   const int WS = B.WS;
-  if (MARG || B.wfill) {
+  if (B.wfill) {
     // (the marginalisation pass only ever reads the rows of the tracks that start in frame 0)
     double* Wp0 = B.Wp + (size_t)w * B.maxP * WS;
     for (int i = tid; i < nP * WS; i += T)
@@ -282,6 +282,14 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     double* Wl0 = B.Wl + (size_t)w * B.maxL * 4 * WS;
     for (int i = tid; i < nL * 4 * WS; i += T)
       if (!MARG || B.ln_start[(size_t)w * B.maxL + i / (4 * WS)] == 0) Wl0[i] = 0.0;
+  } else if (MARG) {
+    // uniform tracks: the one slot no factor writes is the start-frame block of the lines (their start observation is
+    // skipped in this pass) -- 24 entries per line, not the 13 k entries of all rows
+    double* Wl0 = B.Wl + (size_t)w * B.maxL * 4 * WS;
+    for (int i = tid; i < nL * 24; i += T) {
+      const int l = i / 24, e = i - 24 * l;
+      if (B.ln_start[(size_t)w * B.maxL + l] == 0) Wl0[(l * 4 + e / 6) * WS + e % 6] = 0.0;
+    }
   }
   __syncthreads();
 
