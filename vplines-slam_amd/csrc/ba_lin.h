@@ -38,6 +38,13 @@ __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double
   const int NWV = blockDim.x >> 6;       // 10 waves stand-alone (one IMU factor each), 8 inside k_window
   double* wsc = psm + wv * 675;          // per-wave scratch: G (225) | X = G^-1 (225) | P = cov^-1 (225)
   double* Jl = psm + NWV * 675;          // prior J0 staged (n * n), room for nstage x nstage
+  // the prior's J0 is requested first: its round trip runs under the whitening below
+  const int n = B.pr_n[w];
+  const bool fits = n > 0 && n <= nstage;
+  if (fits) {
+    const double* J0g = B.pr_J0 + (size_t)w * B.prS;
+    for (int idx = tid; idx < n * n; idx += blockDim.x) Jl[idx] = J0g[idx];
+  }
   // (a) IMU: sqrt_info = LLT(cov^-1).matrixL().transpose()  (imu_factor.h:68).  cov is SPD: its inverse
   //     is formed from its Cholesky factor (cov = G G^T, cov^-1 = G^-T G^-1), then factored again.
   for (int j = 1 + wv; j < NF; j += NWV) {
@@ -82,14 +89,17 @@ __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double
       }
     }
     x[3] = q.x; x[4] = q.y; x[5] = q.z; x[6] = q.w;
+    // the lines below read the states from LDS (wave 0's scratch is free now), not back from HBM behind the stores
+    double* xq = psm + 7 * tid;
+    xq[0] = x[0]; xq[1] = x[1]; xq[2] = x[2]; xq[3] = q.x; xq[4] = q.y; xq[5] = q.z; xq[6] = q.w;
   }
   __syncthreads();
   // (c) lines: world orth from the start-camera-frame Pluecker (getLineOrthVector, feature_manager.cpp:341-365)
   const int nL = B.orth_in[w] ? 0 : B.nL[w];
   for (int l = tid; l < nL; l += blockDim.x) {
     const int s = B.ln_start[(size_t)w * B.maxL + l];
-    const double* ps = B.pose + ((size_t)w * NF + s) * 7;
-    const double* ex = B.ex + (size_t)w * 7;
+    const double* ps = psm + 7 * s;
+    const double* ex = psm + 7 * NF;
     M3 Rs = qmat(qpose(ps)), ric = qmat(qpose(ex));
     V3 P{ps[0], ps[1], ps[2]}, tic{ex[0], ex[1], ex[2]};
     V3 twc = P + mul(Rs, tic);
@@ -100,16 +110,10 @@ __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double
     plk_to_orth(Lw, B.orth + ((size_t)w * B.maxL + l) * 4);
   }
   // (d) prior: H = J0^T J0 (J0 staged in LDS) and the column map
-  const int n = B.pr_n[w];
   if (n > 0) {
     const double* J0 = B.pr_J0 + (size_t)w * B.prS;
     double* H = B.pr_H + (size_t)w * B.prS;
-    const bool fits = n <= nstage;
-    if (fits) {
-      for (int idx = tid; idx < n * n; idx += blockDim.x) Jl[idx] = J0[idx];
-      __syncthreads();
-    }
-    const double* Js = fits ? Jl : J0;
+    const double* Js = fits ? Jl : J0;   // (staged at the top; the barrier after the states made it visible)
     for (int idx = tid; idx < n * n; idx += blockDim.x) {
       int a = idx / n, b = idx % n;
       double s = 0;
@@ -120,7 +124,9 @@ __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double
     // wait for the residual
     for (int c2 = tid; c2 < n; c2 += blockDim.x) {
       double s = 0;
-      for (int k = 0; k < n; ++k) s += Js[(size_t)k * n + c2] * B.pr_r0[(size_t)w * MAXPN + k];
+      const double* r0g = B.pr_r0 + (size_t)w * MAXPN;
+#pragma unroll 8
+      for (int k = 0; k < n; ++k) s += Js[(size_t)k * n + c2] * r0g[k];
       B.pr_g0[(size_t)w * MAXPN + c2] = s;
     }
     if (tid < B.pr_nb[w]) {
