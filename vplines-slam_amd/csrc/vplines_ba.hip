@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -189,7 +190,8 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   B.maxP = c->maxP; B.maxPO = c->maxPO; B.maxL = c->maxL; B.maxLO = c->maxLO;
   B.nfull = NC + B.maxP + 4 * B.maxL;
   // point work units of k_lin: (start frame, chunk of <= 16 tracks, observation); a unit needs at most one quarter-wave slot
-  B.maxPR = (B.maxP / 16 + NF) * (NF - 1) / 32 + 2;   // the halves of the work-group differ by less than one chunk's units
+  // slots <= factor lanes / 16 + one partial unit per (start, k) pair; the halves of the work-group differ by less than one chunk
+  B.maxPR = std::min((B.maxP / 16 + NF) * (NF - 1), B.maxPO / 16 + NF * (NF - 1) / 2) / 32 + 2;
   const size_t W = max_windows;
   hipError_t e = hipSuccess;
 #define AL(ptr, n) if (e == hipSuccess) e = dalloc(c, &B.ptr, (size_t)(n))
@@ -429,7 +431,9 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   std::vector<double> pose(W * 77), sb(W * 99), ex(W * 7), invd(W * B.maxP, 1.0), plk(W * B.maxL * 6, 0.0);
   std::vector<int> nP(W), nL(W), pt_start(W * B.maxP, 0), pt_nobs(W * B.maxP, 0), pt_off(W * B.maxP, 0);
   std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0), ln_tri(W * B.maxL, 1);
-  std::vector<int> pu_lane(W * B.maxPR * 1024, -1), pu_sub(W * B.maxPR * 512, 0), pu_cnt(W, 0), pu_cnt0(W, 0);
+  // (no value-initialisation: only the rounds a window uses are filled and uploaded)
+  std::unique_ptr<int[]> pu_lane(new int[W * B.maxPR * 1024]), pu_sub(new int[W * B.maxPR * 512]);
+  std::vector<int> pu_cnt(W, 0), pu_cnt0(W, 0);
   std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0), ll_tab(W * B.llSlots, -1), ll_np(W, 0);
   std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
@@ -556,6 +560,8 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       pu_cnt0[w] = (std::max(slots0[0], slots0[1]) + 15) / 16;
       int* lt = &pu_lane[w * B.maxPR * 1024];
       int* st = &pu_sub[w * B.maxPR * 512];
+      std::fill(lt, lt + (size_t)rounds * 1024, -1);
+      std::fill(st, st + (size_t)rounds * 512, 0);
       for (int hf = 0; hf < 2; ++hf)
         for (size_t si = 0; si < slots[hf].size(); ++si) {   // slot i of a half: round i / 16, wave 4 hf + i % 4, quarter (i % 16) / 4
           const int rnd = (int)si / 16, wave = 4 * hf + (int)si % 4, qq = ((int)si % 16) / 4;
@@ -714,7 +720,16 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.pt_start, pt_start)); HIPCHK(c, up(c, B.pt_nobs, pt_nobs)); HIPCHK(c, up(c, B.pt_off, pt_off));
   HIPCHK(c, up(c, B.pt_obs, pt_obs));
   HIPCHK(c, up(c, B.ps_list, ps_list)); HIPCHK(c, up(c, B.ps_cnt, ps_cnt));
-  HIPCHK(c, up(c, B.pu_lane, pu_lane)); HIPCHK(c, up(c, B.pu_sub, pu_sub)); HIPCHK(c, up(c, B.pu_cnt, pu_cnt)); HIPCHK(c, up(c, B.pu_cnt0, pu_cnt0));
+  {   // the first max-over-the-batch rounds of every window
+    int rmax = 0;
+    for (size_t q = 0; q < W; ++q) rmax = std::max(rmax, pu_cnt[q]);
+    if (rmax > 0) {
+      HIPCHK(c, hipMemcpy2DAsync(B.pu_lane, (size_t)B.maxPR * 4096, pu_lane.get(), (size_t)B.maxPR * 4096, (size_t)rmax * 4096, W,
+                                 hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpy2DAsync(B.pu_sub, (size_t)B.maxPR * 2048, pu_sub.get(), (size_t)B.maxPR * 2048, (size_t)rmax * 2048, W,
+                                 hipMemcpyHostToDevice, c->stream));
+    }
+  } HIPCHK(c, up(c, B.pu_cnt, pu_cnt)); HIPCHK(c, up(c, B.pu_cnt0, pu_cnt0));
   HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
   HIPCHK(c, up(c, B.ln_obs, ln_obs)); HIPCHK(c, up(c, B.ln_tri, ln_tri));
   HIPCHK(c, up(c, B.nLO, nLO)); HIPCHK(c, up(c, B.lo_ln, lo_ln));
