@@ -30,12 +30,11 @@ inline size_t prep_smem(int max_prior_n) {
 }
 constexpr size_t PREP_SMEM = (size_t)((PREP_THREADS / 64) * 675 + PREP_NMAX * PREP_NMAX) * sizeof(double);
 
-// Every kernel of the solve is a `*_body` device function of (batch, window, dynamic LDS) plus a thin __global__ wrapper:
-// the bodies are also called back to back by the one-kernel-per-solve k_window (ba_window.h).
+// Every kernel of the solve is a `*_body` device function of (batch, window, dynamic LDS) plus a thin __global__ wrapper.
 __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double* psm, int nstage) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
-  const int NWV = blockDim.x >> 6;       // 10 waves stand-alone (one IMU factor each), 8 inside k_window
+  const int NWV = blockDim.x >> 6;       // 10 waves: one IMU factor each
   double* wsc = psm + wv * 675;          // per-wave scratch: G (225) | X = G^-1 (225) | P = cov^-1 (225)
   double* Jl = psm + NWV * 675;          // prior J0 staged (n * n), room for nstage x nstage
   // the prior's J0 is requested first: its round trip runs under the whitening below
