@@ -885,21 +885,22 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
       }
     }
   }
-  // IMU (one lane per factor; cost only)
+  // IMU, cost only: the raw residuals by one lane per factor, to LDS; their whitening S r by one lane per (factor, row) after
+  // the visual factors.  (One lane doing both read the 120 entries of S from HBM in a dependent loop while the other 63
+  // lanes of its wave -- and the block sum -- waited.)
+  __shared__ double imu_raw[10 * 15];
+  __shared__ int imu_on[10];
   if (tid >= 64 && tid < 74) {
     const int j = tid - 64 + 1;
     const DevPreint& dp = B.pre[(size_t)w * NF + j];
-    if (!(dp.sum_dt > 10.0)) {
+    const bool on = !(dp.sum_dt > 10.0);
+    imu_on[j - 1] = on ? 1 : 0;
+    if (on) {
       PreInt p = load_preint(dp);
       double r[15];
       imu_residual_raw(p, xp + 7 * (j - 1), xs + 9 * (j - 1), xp + 7 * j, xs + 9 * j, B.opt.g_norm, r);
-      double s = 0;
-      for (int a = 0; a < 15; ++a) {
-        double v = 0;
-        for (int k = a; k < 15; ++k) v += dp.sqrt_info[a * 15 + k] * r[k];
-        s += v * v;
-      }
-      cost += 0.5 * s;
+#pragma unroll
+      for (int a = 0; a < 15; ++a) imu_raw[15 * (j - 1) + a] = r[a];
     }
   }
   const double hub = B.opt.huber_delta;
@@ -935,6 +936,20 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
         vp_factor_res(c, ob + 4, B.opt.sqrt_info_vp, r, nullptr);
         cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
       }
+    }
+  }
+  __syncthreads();
+  if (tid < 150) {
+    const int f = tid / 15, a = tid - 15 * f;
+    if (imu_on[f]) {
+      const double* S = B.pre[(size_t)w * NF + f + 1].sqrt_info + a * 15;
+      double sv[15];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) sv[k] = k >= a ? S[k] : 0.0;
+      double v = 0;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) if (k >= a) v += sv[k] * imu_raw[15 * f + k];   // (same order of the terms as before)
+      cost += 0.5 * v * v;
     }
   }
   cost = block_sum(cost, red);
