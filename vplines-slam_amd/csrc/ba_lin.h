@@ -936,7 +936,7 @@ inline int lin_prh_n(int maxP, int maxL) {
   if (base >= LIN_LDS_BUDGET) return 0;
   const size_t cap = (LIN_LDS_BUDGET - base) / sizeof(double);
   int n = 0;
-  while (n < 96 && (size_t)(n + 1) * (n + 2) / 2 <= cap) ++n;
+  while (n < 76 && (size_t)(n + 1) * (n + 2) / 2 <= cap) ++n;   // (75 is the largest prior of the reference)
   return n;
 }
 inline size_t lin_smem(int maxP, int maxL) {

@@ -427,9 +427,10 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       long long ta = 0, tb = 0, tc = 0, td = 0, t0 = __builtin_readcyclecounter();
 #endif
       for (int K = 0; K < NT16; ++K) {
-        // C(I,K) -= sum_{J<K} L(I,J) L(K,J)^T is applied in two parts: the terms J < K-1 were already subtracted by the
-        // idle waves while wave 0 factored the previous diagonal tile (look-ahead, below); only J = K-1 is left here.
-        // The order of the terms, and therefore every bit of the result, is the one of a single pass.
+        // C(I,K) -= sum_{J<K} L(I,J) L(K,J)^T is applied in parts: the terms J < K-1 by the idle waves while wave 0 factored
+        // the previous diagonal tile (look-ahead); the term J = K-1 of the diagonal tile by wave 0 at the end of the previous
+        // solve phase, of the tiles below it by the idle waves while wave 0 factors this diagonal tile.  Two barriers per
+        // tile column.  The order of the terms, and therefore every bit of the result, is the one of a single pass.
         auto rank_update = [&](int col, int I, int J0, int J1) {
           const int m = lane & 15, kk = lane >> 4;
           double* Ct = S + ((I * (I + 1) / 2 + col) << 8);
@@ -447,10 +448,6 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
           }
           Ct[tsw(kk, m)] = c.x; Ct[tsw(kk + 4, m)] = c.y; Ct[tsw(kk + 8, m)] = c.z; Ct[tsw(kk + 12, m)] = c.w;
         };
-        if (K > 0) {
-          for (int I = K + wv; I < NT16; I += SOLVE_THREADS / 64) rank_update(K, I, K - 1, K);
-          __syncthreads();
-        }
 #ifdef VPL_STAMPS
         { const long long t1 = __builtin_readcyclecounter(); ta += t1 - t0; t0 = t1; }
 #endif
@@ -503,9 +500,13 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
               }
             }
           }
-        } else if (K >= 1 && K + 1 < NT16) {
-          // look-ahead: the other waves subtract the finished columns J < K from tile column K+1 meanwhile
-          for (int I = K + 1 + (wv - 1); I < NT16; I += SOLVE_THREADS / 64 - 1) rank_update(K + 1, I, 0, K);
+        } else if (K >= 1) {
+          // Meanwhile the other waves (i) finish tile column K below the diagonal tile with its last term J = K-1 (the
+          // diagonal tile itself got that term from wave 0 in the previous solve phase, below) and (ii) look ahead: the
+          // finished columns J < K are subtracted from tile column K+1.
+          for (int I = K + 1 + (wv - 1); I < NT16; I += SOLVE_THREADS / 64 - 1) rank_update(K, I, K - 1, K);
+          if (K + 1 < NT16)
+            for (int I = K + 1 + (wv - 1); I < NT16; I += SOLVE_THREADS / 64 - 1) rank_update(K + 1, I, 0, K);
         }
         __syncthreads();
 #ifdef VPL_STAMPS
@@ -524,6 +525,14 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c, 0, 0, 0);
           At[tsw(kk, m)] = c.x; At[tsw(kk + 4, m)] = c.y; At[tsw(kk + 8, m)] = c.z; At[tsw(kk + 12, m)] = c.w;
+          if (I == K + 1) {
+            // wave 0 has just made L(K+1, K): it gives the next diagonal tile its last term right away, so that the
+            // factorisation of D(K+1) starts after this phase's barrier instead of after an update phase of its own
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            rank_update(K + 1, K + 1, K, K + 1);
+          }
         }
         __syncthreads();
 #ifdef VPL_STAMPS
