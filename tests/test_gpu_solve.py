@@ -452,3 +452,38 @@ def test_window_solve_parity_long_and_ragged_tracks(P, L, TL):
     for a, b in zip(wg, w2):
         assert np.array_equal(a.pose, b.pose) and np.array_equal(a.line_plk, b.line_plk)
     ctx.close()
+
+
+def test_large_prior_takes_the_fallback_paths():
+    """Tracks of 11 observations from frame 0 couple every pose to the marginalised frame: the new prior has 75 dims.
+    k_marg then factors the kept block with the work-group version of the pivoted Cholesky (the one-wave version holds 48
+    columns), and a context whose LDS budget leaves k_lin room for a smaller image of J0^T J0 than this prior adds the
+    prior's entries to the assembled Hessian in a third pass through HBM.  Window A -> prior -> window B, both sides from
+    the oracle's prior, in a tight context (image holds the prior) and in a full-capacity one (it does not)."""
+    opt = v.default_options()
+    cfg = v.workload.config(48, 24, True)
+    cfg.track_len = 11
+    A = v.workload.generate(v.workload.seed_for(3, 5100), cfg, 0.3)
+    Bw = v.workload.generate(v.workload.seed_for(3, 5101), cfg, 0.3 + cfg.kf_dt)
+    o.preintegrate_windows([A, Bw], opt)
+    ac = A.copy()
+    prior_c, _ = o.solve_window(ac, opt)
+    assert prior_c.n > 60
+    bc = Bw.copy()
+    bc.prior = prior_c
+    pri_c, rep_c = o.solve_window(bc, opt)
+    for big in (False, True):
+        ctx = v.Context(device=0, max_windows=2, max_points=256 if big else 48, max_point_obs=256 * 11 if big else 48 * 11,
+                        max_lines=128 if big else 24, max_line_obs=128 * 11 if big else 24 * 11)
+        ag = A.copy()
+        pri_a, _ = ctx.solve_windows([ag], opt)
+        assert pri_a[0].n == prior_c.n          # (k_marg, n > 48)
+        _compare_prior(pri_a[0], prior_c)
+        bg = Bw.copy()
+        bg.prior = prior_c
+        pri_g, rep_g = ctx.solve_windows([bg], opt)
+        assert rep_g[0].iterations == rep_c.iterations and rep_g[0].num_successful_steps == rep_c.num_successful_steps, big
+        dp, dr = pose_err(bg, bc)
+        assert dp <= POS_TOL and dr <= ROT_TOL, (big, dp, dr)
+        _compare_prior(pri_g[0], pri_c)
+        ctx.close()
