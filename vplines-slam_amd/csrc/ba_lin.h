@@ -14,6 +14,7 @@ typedef double v4d_lin __attribute__((ext_vector_type(4)));
 constexpr int LIN_THREADS = 512;
 constexpr int STG_LD = 21;                // row stride of the MFMA staging tiles (odd: the 16 writer lanes spread over the banks)
 constexpr int LIN_STAGE = 8 * 32 * STG_LD;   // MFMA staging of the point phase (doubles)
+constexpr int PRE_LDS = 62;               // leading doubles of DevPreint: sum_dt, dp, dq, dv, lba, lbg, the five 3x3 Jacobian blocks
 constexpr int LIN_HW = 720;               // wave-private partial sums of the line phase: 11 x (21 + 36 + 6) + 21 + 6 doubles
 constexpr int PREP_NMAX = 112;            // prior dims staged in LDS by k_prep (larger priors read HBM/L2); 10 x 675 + 112^2 doubles = 151 KB
 __host__ __device__ constexpr int lin_stage_doubles(int maxL) {   // MFMA staging | line partial sums + per-track sums | IMU
@@ -208,7 +209,8 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   double* pacc = red + 18;         // per-track sums over the factors: H_ll | g_l | W_s (6) | W_ext (6)
   double* prH = pacc + 14 * PST;   // packed lower triangle of the prior's J0^T J0 (priors of up to PRH_N dims)
   const int PRH_N = B.prhN;        // priors up to this size keep J0^T J0 in LDS for the assembly (what the context's LDS budget leaves)
-  int* invmap = (int*)(prH + PRH_N * (PRH_N + 1) / 2);  // NC
+  double* plds = prH + PRH_N * (PRH_N + 1) / 2;   // 10 x PRE_LDS: the part of the pre-integrations the IMU factors read, staged at the start
+  int* invmap = (int*)(plds + 10 * PRE_LDS);  // NC
   int* imuact = invmap + NC;       // 10
   int* tick = imuact + 10;         // ticket counters of the point phase (1, 2: Hessian tiles of the two halves; 3, 4: per-track sums)
 
@@ -219,6 +221,10 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   for (int i = tid; i < 14 * PST; i += T) pacc[i] = 0.0;
   for (int i = tid; i < 84; i += T) xp[i] = i < 77 ? B.pose[(size_t)w * 77 + i] : B.ex[(size_t)w * 7 + (i - 77)];
   for (int i = tid; i < 99; i += T) xs[i] = B.sb[(size_t)w * 99 + i];
+  for (int i = tid; i < 10 * PRE_LDS; i += T) {   // (the IMU phase is then free of global round trips)
+    const int f = i / PRE_LDS;
+    plds[i] = ((const double*)&B.pre[(size_t)w * NF + f + 1])[i - PRE_LDS * f];
+  }
   for (int i = tid; i < NC; i += T) invmap[i] = -1;
   if (tid < 5) tick[tid] = 0;
   __syncthreads();
@@ -247,8 +253,10 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     const double* Hp = B.pr_H + (size_t)w * B.prS;
     for (int r = tid >> 3; r < n; r += T >> 3) {
       const int sub = tid & 7;
+      // (r0 and g0 of the row are requested with the row, not after the shuffles; eight columns per lane in one batch)
+      const double r0r = sub == 0 ? B.pr_r0[(size_t)w * MAXPN + r] : 0.0, g0r = sub == 0 ? B.pr_g0[(size_t)w * MAXPN + r] : 0.0;
       double s = 0, sg = 0;
-#pragma unroll 4
+#pragma unroll 8
       for (int c = sub; c < n; c += 8) {
         const double dxc = prdx[c];
         const double hrc = Hp[(size_t)r * n + c];
@@ -259,9 +267,9 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
       sg += __shfl_xor(sg, 1, 64); sg += __shfl_xor(sg, 2, 64); sg += __shfl_xor(sg, 4, 64);
       if (sub == 0) {
-        s += B.pr_r0[(size_t)w * MAXPN + r];
+        s += r0r;
         prr[r] = s;
-        prg[r] = sg + B.pr_g0[(size_t)w * MAXPN + r];
+        prg[r] = sg + g0r;
         cost += 0.5 * s * s;
       }
     }
@@ -697,7 +705,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   // raw residual by ten lanes of wave 0, raw Jacobian by ten lanes of wave 1 (each is one long dependent chain)
   if ((tid & 63) < 10 && tid < 128) {
     const int f = tid & 63, j = f + 1;
-    const DevPreint& dp = B.pre[(size_t)w * NF + j];
+    const DevPreint& dp = *(const DevPreint*)(plds + PRE_LDS * f);   // (only the staged leading part is read)
     bool act = MARG ? (j == 1 && dp.sum_dt < 10.0) : !(dp.sum_dt > 10.0);   // estimator.cpp:1088, :1261
     if (PRIOR_ONLY) act = false;
     if (tid < 64) imuact[f] = act ? 1 : 0;
@@ -929,7 +937,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
 // to lin_prh_n dims; the reference's are 6 + 9 + 6 x frames <= 75; larger ones are added in HBM by a third pass)
 constexpr size_t LIN_LDS_BUDGET = 158 * 1024;
 inline size_t lin_smem_base(int maxP, int maxL) {
-  return (size_t)(HV_DOUBLES + NV + 84 + 99 + lin_stage_doubles(maxL) + 3 * MAXPN + 18 + 14 * (maxP | 1)) * sizeof(double) + (size_t)(NC + 16) * sizeof(int);
+  return (size_t)(HV_DOUBLES + NV + 84 + 99 + lin_stage_doubles(maxL) + 3 * MAXPN + 18 + 14 * (maxP | 1) + 10 * PRE_LDS) * sizeof(double) + (size_t)(NC + 16) * sizeof(int);
 }
 inline int lin_prh_n(int maxP, int maxL) {
   const size_t base = lin_smem_base(maxP, maxL);
