@@ -109,6 +109,29 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
     // ---- jacobi scaling (iteration 0 only), diagonal_, gradient_ --------------------------
     const bool first = (tr->iter == 0);
     double a1 = 0.0, q = 0.0;
+    // The inputs of this thread's first point and first line are requested BEFORE the camera entries are worked out and
+    // stored: the three loops below otherwise pay three global round trips back to back (the compiler may not move the
+    // later loops' loads above the earlier loops' stores).  Same arithmetic, same order.
+    double pre_hp = 0.0, pre_sp = 0.0, pre_gp = 0.0, pre_Hl[16], pre_sl[4], pre_gl[4];
+    if (tid < nP) {
+      const size_t pi = (size_t)w * B.maxP + tid;
+      pre_hp = B.Hpp[pi]; pre_gp = B.gp[pi];
+      if (!first) pre_sp = gscale[LP + tid];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pre_Hl[k] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { pre_sl[a] = 0.0; pre_gl[a] = 0.0; }
+    if (tid < nL) {
+      const size_t li = (size_t)w * B.maxL + tid;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pre_Hl[k] = B.Hll[li * 16 + k];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        pre_gl[a] = B.gl[li * 4 + a];
+        if (!first) pre_sl[a] = gscale[LL + 4 * tid + a];
+      }
+    }
     for (int c = tid; c < 176; c += T) {
       double s = 0.0, d = 1.0, g = 0.0;
       if (c < NC) {
@@ -125,11 +148,12 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
     }
     for (int p = tid; p < nP; p += T) {
       const size_t pi = (size_t)w * B.maxP + p;
-      const double h = B.Hpp[pi];
-      const double s = first ? 1.0 / (1.0 + sqrt(h)) : gscale[LP + p];
+      const bool pre = p == tid;   // this thread's first point was requested together with its camera entry (above)
+      const double h = pre ? pre_hp : B.Hpp[pi];
+      const double s = first ? 1.0 / (1.0 + sqrt(h)) : (pre ? pre_sp : gscale[LP + p]);
       if (first) gscale[LP + p] = s;
       const double d = sqrt(fmin(fmax(s * s * h, kMinDiag), kMaxDiag));
-      const double g = s * B.gp[pi] / d;
+      const double g = s * (pre ? pre_gp : B.gp[pi]) / d;
       gdiag[LP + p] = d; ggrad[LP + p] = g;
       a1 += g * g;
       const double u = s * g / d;
@@ -137,15 +161,23 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
     }
     for (int l = tid; l < nL; l += T) {
       const size_t li = (size_t)w * B.maxL + l;
-      const double* Hl = B.Hll + li * 16;
+      const bool pre = l == tid;
+      double Hl[16], sl4[4], gl4[4];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) Hl[k] = pre ? pre_Hl[k] : B.Hll[li * 16 + k];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        sl4[a] = first ? 0.0 : (pre ? pre_sl[a] : gscale[LL + 4 * l + a]);
+        gl4[a] = pre ? pre_gl[a] : B.gl[li * 4 + a];
+      }
       double u[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const double h = Hl[5 * a];
-        const double s = first ? 1.0 / (1.0 + sqrt(h)) : gscale[LL + 4 * l + a];
+        const double s = first ? 1.0 / (1.0 + sqrt(h)) : sl4[a];
         if (first) gscale[LL + 4 * l + a] = s;
         const double d = sqrt(fmin(fmax(s * s * h, kMinDiag), kMaxDiag));
-        const double g = s * B.gl[li * 4 + a] / d;
+        const double g = s * gl4[a] / d;
         gdiag[LL + 4 * l + a] = d; ggrad[LL + 4 * l + a] = g;
         a1 += g * g;
         u[a] = s * g / d;
