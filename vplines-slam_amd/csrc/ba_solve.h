@@ -108,6 +108,11 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
   if (!reuse0) {
     // ---- jacobi scaling (iteration 0 only), diagonal_, gradient_ --------------------------
     const bool first = (tr->iter == 0);
+    // What the scaling works out for the landmarks (scale, diagonal, gradient, and their H blocks) is also left in LDS, in the
+    // space of the staging buffers (free until the first chunk is staged): the landmark constants of the first factorisation
+    // attempt read it there instead of loading back from HBM what was stored a moment ago.  A retry with a larger mu reloads.
+    double* kP = S;                          // nP x 4: s, d, g, H_pp
+    double* kL = S + 4 * B.maxP;             // nL x 28: s(4), d(4), g(4), H_ll(16)
     double a1 = 0.0, q = 0.0;
     // The inputs of this thread's first point and first line are requested BEFORE the camera entries are worked out and
     // stored: the three loops below otherwise pay three global round trips back to back (the compiler may not move the
@@ -155,6 +160,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       const double d = sqrt(fmin(fmax(s * s * h, kMinDiag), kMaxDiag));
       const double g = s * (pre ? pre_gp : B.gp[pi]) / d;
       gdiag[LP + p] = d; ggrad[LP + p] = g;
+      kP[4 * p] = s; kP[4 * p + 1] = d; kP[4 * p + 2] = g; kP[4 * p + 3] = h;
       a1 += g * g;
       const double u = s * g / d;
       q += u * h * u;
@@ -179,9 +185,12 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
         const double d = sqrt(fmin(fmax(s * s * h, kMinDiag), kMaxDiag));
         const double g = s * gl4[a] / d;
         gdiag[LL + 4 * l + a] = d; ggrad[LL + 4 * l + a] = g;
+        kL[28 * l + a] = s; kL[28 * l + 4 + a] = d; kL[28 * l + 8 + a] = g;
         a1 += g * g;
         u[a] = s * g / d;
       }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) kL[28 * l + 12 + k] = Hl[k];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         double hu = 0;
@@ -198,6 +207,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
     double mu = tr->mu;
     bool solved = false;
     double alpha = 0.0;
+    bool first_attempt = true;
     while (mu < kMaxMu) {
       // Schur accumulation on the matrix cores: Acc = X^T X over all landmark rows, where a row of X is
       // C^-1 S_l [W | g | e] (e chosen so that X^T e = W^T u: the Cauchy cross term).  Rows are streamed through two LDS
@@ -223,9 +233,13 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       // C C^T -> C to lch (the back substitution reads it) and, pre-divided, to LDS.  ONE pass per landmark kind, every
       // HBM operand requested before the arithmetic: as two passes with the row scale / factor handed over through HBM the
       // second one waited for the first one's stores and then for its own loads.
+      const double* kP = S;                  // (see the scaling phase)
+      const double* kL = S + 4 * B.maxP;
       for (int p = tid; p < nP; p += T) {
         const size_t pi = (size_t)w * B.maxP + p;
-        const double s = gscale[LP + p], d = gdiag[LP + p], g = ggrad[LP + p], h = B.Hpp[pi];
+        double s, d, g, h;
+        if (first_attempt) { s = kP[4 * p]; d = kP[4 * p + 1]; g = kP[4 * p + 2]; h = kP[4 * p + 3]; }
+        else { s = gscale[LP + p]; d = gdiag[LP + p]; g = ggrad[LP + p]; h = B.Hpp[pi]; }
         const double Al = s * s * h + mu * d * d;
         if (!(Al > 0.0)) flag[0] = 1;
         const double smv = s / sqrt(Al);
@@ -235,10 +249,17 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       for (int l = tid; l < nL; l += T) {
         const size_t li = (size_t)w * B.maxL + l;
         double Hl[16], s4[4], d4[4], g4[4];
+        if (first_attempt) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) Hl[k] = B.Hll[li * 16 + k];
+          for (int a = 0; a < 4; ++a) { s4[a] = kL[28 * l + a]; d4[a] = kL[28 * l + 4 + a]; g4[a] = kL[28 * l + 8 + a]; }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { s4[a] = gscale[LL + 4 * l + a]; d4[a] = gdiag[LL + 4 * l + a]; g4[a] = ggrad[LL + 4 * l + a]; }
+          for (int k = 0; k < 16; ++k) Hl[k] = kL[28 * l + 12 + k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) Hl[k] = B.Hll[li * 16 + k];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) { s4[a] = gscale[LL + 4 * l + a]; d4[a] = gdiag[LL + 4 * l + a]; g4[a] = ggrad[LL + 4 * l + a]; }
+        }
         double A[10];
         int t = 0;
 #pragma unroll
@@ -577,6 +598,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       __syncthreads();
       if (flag[0]) {   // LINEAR_SOLVER_FAILURE: raise mu and retry from the stored linearisation
         mu *= kMuIncrease;
+        first_attempt = false;
         __syncthreads();
         if (tid == 0) flag[0] = 0;
         __syncthreads();

@@ -184,6 +184,8 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   c->maxLO = max_line_obs > 0 ? max_line_obs : 1;
   // k_solve keeps 2 doubles per point and 18 per line in the LDS space behind its two staging buffers
   if (2 * c->maxP + 18 * c->maxL > NAP - 2 * CROWS * CW) { delete c; return VPL_E_CAPACITY; }
+  // ... and 4 doubles per point and 28 per line in the staging buffers' space between the scaling and the first chunk
+  if (4 * c->maxP + 28 * c->maxL > 2 * CROWS * CW) { delete c; return VPL_E_CAPACITY; }
   if (solve_smem(c->maxP, c->maxL) > 159 * 1024) { delete c; return VPL_E_CAPACITY; }
   DevBatch& B = c->B;
   std::memset(&B, 0, sizeof(B));
