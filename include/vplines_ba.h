@@ -293,6 +293,16 @@ int vpl_ba_kernel_times(vpl_ctx* ctx, int* count, const char** names, double* to
  * rejected iteration, candidate evaluated).  Arrays of length *count on input; count updated. */
 int vpl_ba_launch_profile(vpl_ctx* ctx, int* count, const char** names, double* ms, int* active);
 
+/* ---- layout self-check (host only, no device call; tests/test_point_units.py) ---------------------------------- *
+ * The point factors of a window are packed into work units whose Hessian tiles are committed in a host-assigned ticket
+ * order (csrc/ba_pack.h).  vpl_ba_debug_point_units builds the tables exactly as vpl_ba_upload does:
+ * lane_table [max_rounds][512][2], unit_table [max_rounds][32][8][2] (descriptor, seq | seq0 << 16).
+ * vpl_ba_debug_point_chains replays the commit chains of the solve pass (marg_pass = 0) or of the MARGIN_OLD pass
+ * (marg_pass = 1, first rounds0 rounds) wave by wave: 1 = every wave finishes, 0 = a wave would wait forever. */
+int vpl_ba_debug_point_units(int n_points, const int* point_start, const int* point_nobs, int max_rounds,
+                             int* lane_table, int* unit_table, int* rounds, int* rounds0);
+int vpl_ba_debug_point_chains(const int* unit_table, int rounds, int rounds0, int marg_pass);
+
 #ifdef __cplusplus
 }
 #endif

@@ -487,3 +487,72 @@ def test_large_prior_takes_the_fallback_paths():
         assert dp <= POS_TOL and dr <= ROT_TOL, (big, dp, dr)
         _compare_prior(pri_g[0], pri_c)
         ctx.close()
+
+
+def _quat_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _relayout_points(w, start, nobs):
+    """the window (all point tracks generated from frame 0 with 11 observations) with track p cut to the observations
+    start[p] .. start[p] + nobs[p] - 1; the inverse depth is carried to the new start frame through the window's own
+    (initial) poses, the way removeBackShiftDepth does (feature_manager.cpp:800-874)"""
+    P = len(start)
+    ric, tic = _quat_R(w.ex_pose[3:]), w.ex_pose[:3]
+    obs, invd = [], np.zeros(P)
+    for p in range(P):
+        o11 = w.point_obs[11 * p:11 * p + 11]
+        s = int(start[p])
+        obs.append(o11[s:s + int(nobs[p])])
+        pc = o11[0] / w.inv_depth[p]
+        pw = _quat_R(w.pose[0, 3:]) @ (ric @ pc + tic) + w.pose[0, :3]
+        pj = ric.T @ (_quat_R(w.pose[s, 3:]).T @ (pw - w.pose[s, :3]) - tic)
+        invd[p] = 1.0 / pj[2]
+    r = v.capi.Window(w.pose, w.speed_bias, w.ex_pose, np.asarray(start, np.int32), np.asarray(nobs, np.int32),
+                      np.concatenate(obs), invd, w.line_start, w.line_nobs, w.line_obs, w.line_plk, w.preint, w.prior)
+    r.extra = dict(w.extra)
+    return r
+
+
+def test_skewed_ragged_windows_marginalisation_pass_terminates():
+    """~100 points, most tracks starting in frame 0, lengths 2..11.  The MARGIN_OLD pass of k_lin runs only
+    the rounds that hold start-frame-0 units; with one ticket sequence over all rounds (round 2) some of these layouts left a
+    round-0 unit waiting for a ticket owned by a unit of a round the pass never runs -- an endless spin.  The layouts used
+    here are ones on which the old rule provably stalls (host replay of the commit chains); the solve must finish and match
+    the oracle, prior included."""
+    import test_point_units as tpu
+    rng = np.random.default_rng(11)
+    layouts = []
+    for trial in range(1500):
+        start, nobs = tpu._random_window(rng, 100, 0.6)
+        lt, st, R, R0 = tpu._tables(start, nobs)
+        if R > R0 >= 1 and not tpu._replay(st, R0, 0):
+            layouts.append((start, nobs))
+        if len(layouts) == 3:
+            break
+    assert len(layouts) == 3
+    opt = v.default_options()
+    cfg = v.workload.config(100, 12, True)
+    cfg.track_len = 11
+    base = [v.workload.generate(v.workload.seed_for(3, 6100 + i), cfg, 0.37 * i) for i in range(3)]
+    o.preintegrate_windows(base, opt)
+    ws = [_relayout_points(b, s, n) for b, (s, n) in zip(base, layouts)]
+    ctx = v.Context(device=0, max_windows=3, max_points=100, max_point_obs=1100, max_lines=12, max_line_obs=132)
+    wg = [w.copy() for w in ws]
+    wc = [w.copy() for w in ws]
+    pri_g, rep_g = ctx.solve_windows(wg, opt)
+    for i in range(3):
+        pri_c, rep_c = o.solve_window(wc[i], opt)
+        assert rep_g[i].iterations == rep_c.iterations and rep_g[i].num_successful_steps == rep_c.num_successful_steps, i
+        dp, dr = pose_err(wg[i], wc[i])
+        assert dp <= POS_TOL and dr <= ROT_TOL, (i, dp, dr)
+        assert rep_g[i].prior_n == rep_c.prior_n and rep_g[i].prior_m == rep_c.prior_m
+        _compare_prior(pri_g[i], pri_c)
+    # the marginalisation on its own takes the same pass
+    pm, mm, nn = ctx.marginalize([w.copy() for w in wg], opt, v.capi.MARGIN_OLD)
+    for i in range(3):
+        assert nn[i] == rep_g[i].prior_n
+    ctx.close()

@@ -444,7 +444,9 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
         for (int i = 0; i < 8; ++i) {
           const int desc = __builtin_amdgcn_readlane(subv, 16 * qq + 2 * i);
           if (desc == 0) break;
-          const int seq = __builtin_amdgcn_readlane(subv, 16 * qq + 2 * i + 1);
+          // tickets of the two passes: the marginalisation pass numbers only the units of the rounds it runs (ba_pack.h)
+          const int tk = __builtin_amdgcn_readlane(subv, 16 * qq + 2 * i + 1);
+          const int seq = MARG ? (tk >> 16) & 0xffff : tk & 0xffff;
           const int sq = desc & 15, jq = (desc >> 4) & 15, ks0 = (desc >> 8) & 15, ks1 = (desc >> 12) & 15;
           const unsigned smask = ((1u << (2 * (ks1 - ks0))) - 1u) << (2 * ks0);
           if ((qmask & smask) == 0) {       // uniform: nothing to add (units of later start frames in the marginalisation

@@ -1,0 +1,171 @@
+// Host-side layout tables of k_lin's point phase (pure C++: no device call, so the packing rules are testable without a GPU).
+//
+// Work unit = (start frame f, observation index k >= 1, <= 16 of the tracks that start in f and are seen at k), packed
+// first-fit into quarter-wave slots (full units take a slot, small ones share one on even lane boundaries).  All units of
+// a chunk of tracks go to the same HALF of the work-group (waves 0..3 or 4..7): the per-track sums over k are then ordered
+// by one four-wave chain per half and need no second copy.
+//
+//   lane table  lt[round][512][2]      : (track | k << 16 | f << 20, observation offset) of every lane, -1 = idle
+//   unit table  st[round][32][8][2]    : per quarter-wave slot up to 8 x (descriptor, tickets); descriptor 0 ends the list
+//       descriptor = f | (f + k) << 4 | ks0 << 8 | ks1 << 12 | 1 << 16   (ks0..ks1: range of MFMA K-steps = lane pairs)
+//       tickets    = seq | seq0 << 16
+//          seq  : position of the unit in the commit chain of its half in the solve pass (every round)
+//          seq0 : position in the chain of the MARGIN_OLD pass, which runs the first `rounds0` rounds only (the units of
+//                 start frame 0 sit there); 0xffff for units of later rounds.
+// A wave waits for its unit's ticket before it adds the unit's Hessian tile, so BOTH sequences must be consistent with the
+// order in which each wave reaches its own units (round, quarter, unit) and each must number exactly the units its pass
+// executes: a pass that waits for a ticket owned by a unit it never runs would spin forever.  seq0 is the rank of the
+// unit among the units of the first rounds0 rounds in seq order -- a sub-sequence of a consistent order is consistent.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "ba_types.h"
+
+namespace vpl {
+
+struct PointUnitLayout {
+  int rounds = 0, rounds0 = 0;
+};
+
+// ps_list / cnt: the window's tracks sorted by start frame (cnt[f] .. cnt[f+1]), inside a start frame by decreasing length.
+// lt / st must hold maxPR rounds.  Returns false when the table is too small.
+inline bool pack_point_units(const int* point_nobs, const int* pt_off, const int* ps_list, const int* cnt, int maxPR,
+                             int* lt, int* st, PointUnitLayout* out) {
+  struct Slot { int used, nsub, desc[8], first[8], cnt[8], lane0[8], k[8]; };
+  std::vector<Slot> slots[2];
+  std::vector<int> open[2];
+  int slots0[2] = {0, 0}, load[2] = {0, 0};
+  for (int f = 0; f < NF; ++f) {
+    const int c0 = cnt[f], c1 = cnt[f + 1];
+    const int maxno = c1 > c0 ? point_nobs[ps_list[c0]] : 0;
+    std::vector<int> half_of((c1 - c0 + 15) / 16, -1);
+    for (int k = 1; k < maxno; ++k) {
+      int ck = 0;
+      while (c0 + ck < c1 && point_nobs[ps_list[c0 + ck]] > k) ++ck;
+      for (int q = 0; q < ck; q += 16) {
+        const int n = std::min(16, ck - q), need = (n + 1) & ~1;
+        int& hf = half_of[q / 16];
+        if (hf < 0) {   // the chunk's lanes over all k go to the lighter half
+          hf = load[1] < load[0] ? 1 : 0;
+          for (int m = q; m < std::min(q + 16, c1 - c0); ++m) load[hf] += point_nobs[ps_list[c0 + m]] - 1;
+        }
+        std::vector<Slot>& SL = slots[hf];
+        std::vector<int>& OP = open[hf];
+        int si = -1;
+        for (size_t o = 0; o < OP.size() && si < 0; ++o)
+          if (16 - SL[OP[o]].used >= need) si = OP[o];
+        if (si < 0) {
+          si = (int)SL.size();
+          SL.push_back(Slot{});
+          OP.push_back(si);
+        }
+        Slot& S = SL[si];
+        const int i = S.nsub++;
+        S.lane0[i] = S.used; S.first[i] = c0 + q; S.cnt[i] = n; S.k[i] = k;
+        S.desc[i] = f | (f + k) << 4 | (S.used / 2) << 8 | ((S.used + need) / 2) << 12 | 1 << 16;
+        S.used += need;
+        if (S.used == 16 || S.nsub == 8) OP.erase(std::find(OP.begin(), OP.end(), si));
+        if (f == 0) slots0[hf] = std::max(slots0[hf], si + 1);
+      }
+    }
+  }
+  const int rounds = (int)(std::max(slots[0].size(), slots[1].size()) + 15) / 16;
+  if (rounds > maxPR) return false;
+  const int rounds0 = (std::max(slots0[0], slots0[1]) + 15) / 16;
+  out->rounds = rounds;
+  out->rounds0 = rounds0;
+  std::fill(lt, lt + (size_t)rounds * 1024, -1);
+  std::fill(st, st + (size_t)rounds * 512, 0);
+  for (int hf = 0; hf < 2; ++hf)
+    for (size_t si = 0; si < slots[hf].size(); ++si) {   // slot i of a half: round i / 16, wave 4 hf + i % 4, quarter (i % 16) / 4
+      const int rnd = (int)si / 16, wave = 4 * hf + (int)si % 4, qq = ((int)si % 16) / 4;
+      const Slot& S = slots[hf][si];
+      for (int i = 0; i < S.nsub; ++i) {
+        for (int m = 0; m < S.cnt[i]; ++m) {
+          const int p = ps_list[S.first[i] + m];
+          int* e = &lt[(rnd * 512 + wave * 64 + qq * 16 + S.lane0[i] + m) * 2];
+          e[0] = p | S.k[i] << 16 | (S.desc[i] & 15) << 20;
+          e[1] = pt_off[p];
+        }
+        st[((rnd * 32 + wave * 4 + qq) * 8 + i) * 2] = S.desc[i];
+      }
+    }
+  // commit tickets: two chains (waves 0..3 / 4..7).  A wave reaches its units in (round, quarter, unit) order; the
+  // chain serves, among the four waves' next units, the one a rough cycle model expects to be ready first, so that a
+  // slot packed with many small units does not hold up the waves whose slots are full ones
+  for (int hf = 0; hf < 2; ++hf) {
+    const int F = 11000, STAGE = 1200, KS = 170, SUB = 200, COMMIT = 700;   // factor math, staging, per MFMA step, per unit, per commit
+    int pos[4] = {0, 0, 0, 0};          // next item of each wave: round * 32 + qq * 8 + i
+    long clk[4] = {F, F, F, F}, chain = 0;
+    bool staged[4] = {false, false, false, false};
+    int seq = 0, seq0 = 0;
+    auto entry = [&](int wv, int ps) { return &st[(((ps / 32) * 32 + (hf * 4 + wv) * 4 + (ps % 32) / 8) * 8 + ps % 8) * 2]; };
+    auto advance = [&](int wv) {        // skip to the wave's next existing unit, charging round starts and staging
+      while (pos[wv] < rounds * 32 && entry(wv, pos[wv])[0] == 0) {
+        pos[wv] = (pos[wv] / 8 + 1) * 8;           // descriptor 0 ends a slot's list
+        if (pos[wv] % 32 == 0 && pos[wv] < rounds * 32) clk[wv] += F;
+        staged[wv] = false;
+      }
+    };
+    for (int wv = 0; wv < 4; ++wv) advance(wv);
+    for (;;) {
+      int best = -1;
+      long bt = 0;
+      for (int wv = 0; wv < 4; ++wv) {
+        if (pos[wv] >= rounds * 32) continue;
+        const int d = entry(wv, pos[wv])[0];
+        const long t = clk[wv] + (staged[wv] ? 0 : STAGE) + SUB + KS * (((d >> 12) & 15) - ((d >> 8) & 15));
+        if (best < 0 || t < bt) { best = wv; bt = t; }
+      }
+      if (best < 0) break;
+      // the marginalisation pass numbers only the units it runs, in the same relative order
+      const bool in0 = pos[best] / 32 < rounds0;
+      if (seq > 0xfffe) return false;
+      entry(best, pos[best])[1] = seq | (in0 ? seq0 : 0xffff) << 16;
+      ++seq;
+      if (in0) ++seq0;
+      chain = std::max(chain, bt) + COMMIT;
+      clk[best] = chain;
+      staged[best] = true;
+      ++pos[best];
+      if (pos[best] % 8 == 0) {
+        staged[best] = false;
+        if (pos[best] % 32 == 0 && pos[best] < rounds * 32) clk[best] += F;
+      }
+      advance(best);
+    }
+  }
+  return true;
+}
+
+// Replays the commit chains of one pass the way the device runs them (four waves per half, each walking its own units in
+// (round, quarter, unit) order and spinning on the half's ticket counter) and reports whether every wave finishes.
+// marg = true: the MARGIN_OLD pass (first rounds0 rounds, seq0 tickets).
+inline bool point_unit_chains_finish(const int* st, const PointUnitLayout& L, bool marg) {
+  const int nR = marg ? L.rounds0 : L.rounds;
+  for (int hf = 0; hf < 2; ++hf) {
+    int pos[4] = {0, 0, 0, 0};
+    int tick = 0;
+    auto entry = [&](int wv, int ps) { return &st[(((ps / 32) * 32 + (hf * 4 + wv) * 4 + (ps % 32) / 8) * 8 + ps % 8) * 2]; };
+    auto advance = [&](int wv) {
+      while (pos[wv] < nR * 32 && entry(wv, pos[wv])[0] == 0) pos[wv] = (pos[wv] / 8 + 1) * 8;
+    };
+    for (int wv = 0; wv < 4; ++wv) advance(wv);
+    for (;;) {
+      bool progressed = false, pending = false;
+      for (int wv = 0; wv < 4; ++wv) {
+        if (pos[wv] >= nR * 32) continue;
+        pending = true;
+        const int t = entry(wv, pos[wv])[1];
+        const int want = marg ? (t >> 16) & 0xffff : t & 0xffff;
+        if (want == tick) { ++tick; ++pos[wv]; advance(wv); progressed = true; }
+      }
+      if (!pending) break;
+      if (!progressed) return false;   // every pending wave waits for a ticket nobody will pass
+    }
+  }
+  return true;
+}
+
+}  // namespace vpl

@@ -18,6 +18,7 @@
 #include "vplines_ba.h"
 #include "ba_types.h"
 #include "ba_lin.h"
+#include "ba_pack.h"
 #include "ba_solve.h"
 #include "ba_marg.h"
 #include "ba_lineopt.h"
@@ -514,112 +515,16 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       for (int f = 0; f < NF; ++f)
         std::stable_sort(&ps_list[w * B.maxP + cnt[f]], &ps_list[w * B.maxP + cnt[f + 1]],
                          [&](int a, int b) { return v.point_nobs[a] > v.point_nobs[b]; });
-      // work units of the point phase of k_lin: (start frame f, observation index k >= 1, <= 16 of the tracks seen at k),
-      // packed first-fit into quarter-wave slots (full units take a slot, small ones share one on even lane boundaries).
-      // All units of a chunk of tracks go to the same HALF of the work-group (waves 0..3 or 4..7): the per-track sums over
-      // k are then ordered by one four-wave chain per half and need no second copy.
-      struct Slot { int used, nsub, desc[8], first[8], cnt[8], lane0[8], k[8]; };
-      std::vector<Slot> slots[2];
-      std::vector<int> open[2];
-      int slots0[2] = {0, 0}, load[2] = {0, 0};
-      for (int f = 0; f < NF; ++f) {
-        const int c0 = cnt[f], c1 = cnt[f + 1];
-        const int maxno = c1 > c0 ? v.point_nobs[ps_list[w * B.maxP + c0]] : 0;
-        std::vector<int> half_of((c1 - c0 + 15) / 16, -1);
-        for (int k = 1; k < maxno; ++k) {
-          int ck = 0;
-          while (c0 + ck < c1 && v.point_nobs[ps_list[w * B.maxP + c0 + ck]] > k) ++ck;
-          for (int q = 0; q < ck; q += 16) {
-            const int n = std::min(16, ck - q), need = (n + 1) & ~1;
-            int& hf = half_of[q / 16];
-            if (hf < 0) {   // the chunk's lanes over all k go to the lighter half
-              hf = load[1] < load[0] ? 1 : 0;
-              for (int m = q; m < std::min(q + 16, c1 - c0); ++m) load[hf] += v.point_nobs[ps_list[w * B.maxP + c0 + m]] - 1;
-            }
-            std::vector<Slot>& SL = slots[hf];
-            std::vector<int>& OP = open[hf];
-            int si = -1;
-            for (size_t o = 0; o < OP.size() && si < 0; ++o)
-              if (16 - SL[OP[o]].used >= need) si = OP[o];
-            if (si < 0) {
-              si = (int)SL.size();
-              SL.push_back(Slot{});
-              OP.push_back(si);
-            }
-            Slot& S = SL[si];
-            const int i = S.nsub++;
-            S.lane0[i] = S.used; S.first[i] = c0 + q; S.cnt[i] = n; S.k[i] = k;
-            S.desc[i] = f | (f + k) << 4 | (S.used / 2) << 8 | ((S.used + need) / 2) << 12 | 1 << 16;
-            S.used += need;
-            if (S.used == 16) OP.erase(std::find(OP.begin(), OP.end(), si));
-            if (f == 0) slots0[hf] = std::max(slots0[hf], si + 1);
-          }
-        }
-      }
-      const int rounds = (int)(std::max(slots[0].size(), slots[1].size()) + 15) / 16;
-      if (rounds > B.maxPR) return fail(c, VPL_E_CAPACITY, "point work-unit table too small");
-      pu_cnt[w] = rounds;
-      pu_cnt0[w] = (std::max(slots0[0], slots0[1]) + 15) / 16;
-      int* lt = &pu_lane[w * B.maxPR * 1024];
-      int* st = &pu_sub[w * B.maxPR * 512];
-      std::fill(lt, lt + (size_t)rounds * 1024, -1);
-      std::fill(st, st + (size_t)rounds * 512, 0);
-      for (int hf = 0; hf < 2; ++hf)
-        for (size_t si = 0; si < slots[hf].size(); ++si) {   // slot i of a half: round i / 16, wave 4 hf + i % 4, quarter (i % 16) / 4
-          const int rnd = (int)si / 16, wave = 4 * hf + (int)si % 4, qq = ((int)si % 16) / 4;
-          const Slot& S = slots[hf][si];
-          for (int i = 0; i < S.nsub; ++i) {
-            for (int m = 0; m < S.cnt[i]; ++m) {
-              const int p = ps_list[w * B.maxP + S.first[i] + m];
-              int* e = &lt[(rnd * 512 + wave * 64 + qq * 16 + S.lane0[i] + m) * 2];
-              e[0] = p | S.k[i] << 16 | (S.desc[i] & 15) << 20;
-              e[1] = pt_off[w * B.maxP + p];
-            }
-            st[((rnd * 32 + wave * 4 + qq) * 8 + i) * 2] = S.desc[i];
-          }
-        }
-      // commit tickets: two chains (waves 0..3 / 4..7).  A wave reaches its units in (round, quarter, unit) order; the
-      // chain serves, among the four waves' next units, the one a rough cycle model expects to be ready first, so that a
-      // slot packed with many small units does not hold up the waves whose slots are full ones
-      for (int hf = 0; hf < 2; ++hf) {
-        const int F = 11000, STAGE = 1200, KS = 170, SUB = 200, COMMIT = 700;   // factor math, staging, per MFMA step, per unit, per commit
-        int pos[4] = {0, 0, 0, 0};          // next item of each wave: round * 32 + qq * 8 + i
-        long clk[4] = {F, F, F, F}, chain = 0;
-        bool staged[4] = {false, false, false, false};
-        int seq = 0;
-        auto entry = [&](int wv, int ps) { return &st[(((ps / 32) * 32 + (hf * 4 + wv) * 4 + (ps % 32) / 8) * 8 + ps % 8) * 2]; };
-        auto advance = [&](int wv) {        // skip to the wave's next existing unit, charging round starts and staging
-          while (pos[wv] < rounds * 32 && entry(wv, pos[wv])[0] == 0) {
-            pos[wv] = (pos[wv] / 8 + 1) * 8;           // descriptor 0 ends a slot's list
-            if (pos[wv] % 32 == 0 && pos[wv] < rounds * 32) clk[wv] += F;
-            staged[wv] = false;
-          }
-        };
-        for (int wv = 0; wv < 4; ++wv) advance(wv);
-        for (;;) {
-          int best = -1;
-          long bt = 0;
-          for (int wv = 0; wv < 4; ++wv) {
-            if (pos[wv] >= rounds * 32) continue;
-            const int d = entry(wv, pos[wv])[0];
-            const long t = clk[wv] + (staged[wv] ? 0 : STAGE) + SUB + KS * (((d >> 12) & 15) - ((d >> 8) & 15));
-            if (best < 0 || t < bt) { best = wv; bt = t; }
-          }
-          if (best < 0) break;
-          entry(best, pos[best])[1] = seq++;
-          chain = std::max(chain, bt) + COMMIT;
-          clk[best] = chain;
-          staged[best] = true;
-          const int before = pos[best];
-          ++pos[best];
-          if (pos[best] % 8 == 0) {
-            staged[best] = false;
-            if (pos[best] % 32 == 0 && pos[best] < rounds * 32) clk[best] += F;
-          }
-          (void)before;
-          advance(best);
-        }
-      }
+      // work units of the point phase of k_lin and their commit tickets (ba_pack.h)
+      PointUnitLayout PL;
+      if (!pack_point_units(v.point_nobs, &pt_off[w * B.maxP], &ps_list[w * B.maxP], cnt, B.maxPR, &pu_lane[w * B.maxPR * 1024],
+                            &pu_sub[w * B.maxPR * 512], &PL))
+        return fail(c, VPL_E_CAPACITY, "point work-unit table too small");
+      pu_cnt[w] = PL.rounds;
+      pu_cnt0[w] = PL.rounds0;
+      // a pass that waited for a ticket owned by a unit it never runs would spin forever on the device: replay both chains
+      if (!point_unit_chains_finish(&pu_sub[w * B.maxPR * 512], PL, false) || !point_unit_chains_finish(&pu_sub[w * B.maxPR * 512], PL, true))
+        return fail(c, VPL_E_INVALID, "internal: commit-ticket order of the point work units is not executable");
     }
     off = 0;
     int woff = 0, nl = 0;
@@ -725,6 +630,10 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   {   // the first max-over-the-batch rounds of every window
     int rmax = 0;
     for (size_t q = 0; q < W; ++q) rmax = std::max(rmax, pu_cnt[q]);
+    for (size_t q = 0; q < W; ++q) {   // rounds a window does not use are uploaded too: idle lanes, empty slots
+      std::fill(&pu_lane[(q * B.maxPR + pu_cnt[q]) * 1024], &pu_lane[(q * B.maxPR + rmax) * 1024], -1);
+      std::fill(&pu_sub[(q * B.maxPR + pu_cnt[q]) * 512], &pu_sub[(q * B.maxPR + rmax) * 512], 0);
+    }
     if (rmax > 0) {
       HIPCHK(c, hipMemcpy2DAsync(B.pu_lane, (size_t)B.maxPR * 4096, pu_lane.get(), (size_t)B.maxPR * 4096, (size_t)rmax * 4096, W,
                                  hipMemcpyHostToDevice, c->stream));
@@ -1187,6 +1096,36 @@ int vpl_ba_debug_marg_Ab(vpl_ctx* c, int w, double* A, double* b) {
 int vpl_ba_debug_stamps(vpl_ctx* c, int w, long long* out) {
   HIPCHK(c, hipMemcpy(out, c->B.dbg + (size_t)w * 64, 64 * 8, hipMemcpyDeviceToHost));
   return VPL_OK;
+}
+
+// Host-only (no device call): the point work-unit tables upload builds for one window, and a replay of their commit chains.
+int vpl_ba_debug_point_units(int n_points, const int* point_start, const int* point_nobs, int max_rounds, int* lane_table,
+                             int* unit_table, int* rounds, int* rounds0) {
+  if (n_points < 0 || !point_start || !point_nobs || !lane_table || !unit_table || !rounds || !rounds0 || max_rounds < 1) return VPL_E_INVALID;
+  std::vector<int> off(n_points + 1, 0), list(n_points + 1, 0);
+  int cnt[NF + 1] = {0};
+  int o = 0;
+  for (int p = 0; p < n_points; ++p) {
+    if (point_start[p] < 0 || point_nobs[p] < 2 || point_start[p] + point_nobs[p] > NF) return VPL_E_INVALID;
+    off[p] = o; o += point_nobs[p];
+    cnt[point_start[p] + 1]++;
+  }
+  for (int f = 0; f < NF; ++f) cnt[f + 1] += cnt[f];
+  int pos[NF + 1];
+  for (int f = 0; f <= NF; ++f) pos[f] = cnt[f];
+  for (int p = 0; p < n_points; ++p) list[pos[point_start[p]]++] = p;
+  for (int f = 0; f < NF; ++f)
+    std::stable_sort(&list[cnt[f]], &list[cnt[f + 1]], [&](int a, int b) { return point_nobs[a] > point_nobs[b]; });
+  PointUnitLayout PL;
+  if (!pack_point_units(point_nobs, off.data(), list.data(), cnt, max_rounds, lane_table, unit_table, &PL)) return VPL_E_CAPACITY;
+  *rounds = PL.rounds; *rounds0 = PL.rounds0;
+  return VPL_OK;
+}
+int vpl_ba_debug_point_chains(const int* unit_table, int rounds, int rounds0, int marg_pass) {
+  if (!unit_table || rounds < 0 || rounds0 < 0 || rounds0 > rounds) return VPL_E_INVALID;
+  PointUnitLayout PL;
+  PL.rounds = rounds; PL.rounds0 = rounds0;
+  return point_unit_chains_finish(unit_table, PL, marg_pass != 0) ? 1 : 0;
 }
 
 int vpl_ba_enable_kernel_timing(vpl_ctx* c, int enable) {
