@@ -18,8 +18,11 @@ __device__ __forceinline__ void count_active(const DevBatch& B, int k) {
 }
 
 // window of this work-group in a launch of trust-region iteration B.ord_it (identity before the first k_cost)
+// (readfirstlane: the index is the same for the whole work-group, but it comes out of a load -- without the hint every
+// per-window pointer and count derived from it lives in vector registers and all their address arithmetic runs on the VALU)
 __device__ __forceinline__ int ordered_window(const DevBatch& B) {
-  return B.ord_it == 0 ? (int)blockIdx.x : B.order[(size_t)(B.ord_it & 1) * B.nW + blockIdx.x];
+  const int w = B.ord_it == 0 ? (int)blockIdx.x : B.order[(size_t)(B.ord_it & 1) * B.nW + blockIdx.x];
+  return __builtin_amdgcn_readfirstlane(w);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -168,4 +168,80 @@ inline bool point_unit_chains_finish(const int* st, const PointUnitLayout& L, bo
   return true;
 }
 
+// ---- entry table of k_schur (ba_step.h) ---------------------------------------------------------------------------
+// Landmark rows sorted by group (points by start frame, then lines by start frame).  An entry is one K-step of the FP64
+// matrix-core instruction: four points of one start frame, or the four rows of one line.
+// The entries are dealt to the NWV (<= 8) waves of k_schur in contiguous spans of about equal weight; a wave adds its accumulators
+// to the shared system whenever the group changes and at the end of its span.  Those adds are committed in ticket order,
+// sorted by the K-steps the wave has done when it reaches the add (ties: by wave): the waves start together and advance at
+// about the same rate, so a wave seldom finds its ticket not yet due -- and the order is a fixed function of the table.
+//   tab  [maxKS][4] : points {start frame f, id0 | id1 << 16, id2 | id3 << 16, 0} (0xffff = none); lines {32 | f, line, 0, 0}
+//   wave [8][SK_WSTRIDE] : {first entry, end, ticket of flush 0, ticket of flush 1, ...}
+// Returns the number of entries or -1 when a table is too small.
+inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL, const int* ln_start, int maxKS, int* tab,
+                             int* wave, int NWV) {
+  std::vector<int> grp, wgt;
+  int nks = 0;
+  auto push = [&](int g, const int* id) {
+    if (nks >= maxKS) return false;
+    tab[4 * nks] = g; tab[4 * nks + 1] = id[0] | id[1] << 16; tab[4 * nks + 2] = id[2] | id[3] << 16; tab[4 * nks + 3] = 0;
+    grp.push_back(g);
+    wgt.push_back(1);
+    ++nks;
+    return true;
+  };
+  (void)nP;
+  for (int f = 0; f < NF; ++f)
+    for (int q = cnt[f]; q < cnt[f + 1]; q += 4) {
+      int id[4];
+      for (int i = 0; i < 4; ++i) id[i] = q + i < cnt[f + 1] ? ps_list[q + i] : 0xffff;
+      if (!push(f, id)) return -1;
+    }
+  for (int f = 0; f < NF; ++f)
+    for (int l = 0; l < nL; ++l)
+      if (ln_start[l] == f) {
+        const int id[4] = {l, 0, 0, 0};
+        if (!push(32 | f, id)) return -1;
+      }
+  // spans of about equal weight: wave v takes the entries whose weight prefix falls into [v, v + 1) * total / 8
+  std::vector<long> pre(nks + 1, 0);
+  for (int k = 0; k < nks; ++k) pre[k + 1] = pre[k] + wgt[k];
+  const long total = pre[nks];
+  int k0[8], k1[8];
+  {
+    int k = 0;
+    for (int wv = 0; wv < NWV; ++wv) {
+      k0[wv] = k;
+      const long lim = (total * (wv + 1) + NWV - 1) / NWV;
+      while (k < nks && (wv == NWV - 1 || pre[k] + (wgt[k] + 1) / 2 <= lim)) ++k;
+      k1[wv] = k;
+    }
+  }
+  struct Inc { int wv; long when; };
+  std::vector<Inc> inc;
+  for (int wv = 0; wv < NWV; ++wv)
+    for (int k = k0[wv]; k < k1[wv]; ++k)
+      if (k + 1 == k1[wv] || grp[k + 1] != grp[k]) inc.push_back(Inc{wv, pre[k + 1] - pre[k0[wv]]});
+  std::vector<int> order(inc.size());
+  for (size_t i = 0; i < inc.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (inc[a].when != inc[b].when) return inc[a].when < inc[b].when;
+    return inc[a].wv < inc[b].wv;
+  });
+  std::vector<int> ticket(inc.size());
+  for (size_t t = 0; t < order.size(); ++t) ticket[order[t]] = (int)t;
+  for (int wv = 0; wv < NWV; ++wv) {
+    int* o = wave + wv * SK_WSTRIDE;
+    std::fill(o, o + SK_WSTRIDE, -1);
+    o[0] = k0[wv]; o[1] = k1[wv];
+    int nf = 0;
+    for (size_t i = 0; i < inc.size(); ++i)
+      if (inc[i].wv == wv) {
+        if (2 + nf >= SK_WSTRIDE) return -1;
+        o[2 + nf++] = ticket[i];
+      }
+  }
+  return nks;
+}
+
 }  // namespace vpl

@@ -70,6 +70,7 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
   const int lane = tid & 63, wv = tid >> 6;
   TrState* tr = &B.tr[w];
   if (tr->status != 0) return;
+  if (B.path[w] == 0) return;     // the window takes the three-kernel path (ba_step.h)
   count_active(B, tr->reuse ? 2 : 1);
   double* S = sm;                 // NAP tile-major lower (row NC = rhs); first used as 2 staging buffers
   double* sc = S + NAP;           // 176 jacobi scale of cam dims

@@ -24,6 +24,8 @@ constexpr int NCP = NC * (NC + 1) / 2; // packed lower triangle of the cam Hessi
 constexpr int MAXPB = 23;              // prior blocks
 constexpr int MAXPN = 171;             // prior dim
 constexpr int ACT_SLOTS = 64;             // launches of one solve whose activity is counted
+constexpr int SK_WSTRIDE = 32;         // ints per wave in sk_wave: k0, k1, then up to 30 flush tickets
+constexpr int SACC_N = 74 * 75 / 2;     // packed lower triangle of the compact Schur product: 72 vis dims, rhs row, Cauchy row
 constexpr int MAXKEEP = 80;            // new prior dim after MARGIN_OLD: <= 10*6 + 9 + 6 = 75
 
 __host__ __device__ inline int vis2cam(int v) { return v < 66 ? 15 * (v / 6) + (v % 6) : 165 + (v - 66); }
@@ -128,6 +130,25 @@ struct DevBatch {
   int *ord_cnt;                                  // [2][2]
   int ord_it;
   double *lchol;                                 // [W][maxL][10] Cholesky factors of the regularised line blocks
+
+  // ---- the trust-region step as three kernels (ba_step.h): k_schur -> k_chol -> k_back ----
+  // k_schur: landmark elimination.  The rows of X = C^-1 S [W | g | e] are consumed straight from HBM by the matrix cores,
+  // one wave per span of K-steps (4 rows each), in the COMPACT coordinates of the rows' start frame (WS + 2 columns: the
+  // frames start .. start + maxTrack - 1, extrinsic, g, e); a wave adds its product to the window's compact 74 x 74 system
+  // when the start frame changes.  sk_tab: K-steps sorted by group (points by start frame, then lines by start frame):
+  // {group, id0 | id1 << 16, id2 | id3 << 16, 0} for four point rows (0xffff: none) or {group | 32, line, 0, 0} for the four
+  // rows of one line.  sk_wave[wave]: {first K-step, end, tickets of the wave's flushes in order ...} -- the adds into the
+  // shared system are committed in ticket order (group-major, waves descending inside a group) so that every sum has a fixed
+  // order of terms.
+  int *sk_tab, *sk_wave;                         // [W][maxKS][4] ; [W][8][SK_WSTRIDE]
+  int maxKS;
+  double *sacc;                                  // [W][SACC_N] packed lower triangle of the compact Schur product (rows 0..73)
+  double *ycs;                                   // [W][176] S_c y_c: the camera part of the Gauss-Newton step, unscaled (k_chol -> k_back)
+  double *sx;                                    // [W][8] scalars handed from kernel to kernel: a2, a3 of the camera dims
+  // 0: the three-kernel path; 1: general path for the whole solve (the prior holds a speed/bias block other than frame 0's,
+  // which k_chol's elimination order does not cover); 2: general path for this iteration (a factorisation failed: the retry
+  // with a larger mu runs in k_solve).  k_solve (ba_solve.h) is that general path.
+  int *path;                                     // [W]
 
   // ---- trust region vectors over the full index ----
   TrState *tr;                                   // [W]

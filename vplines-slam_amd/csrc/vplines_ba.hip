@@ -20,6 +20,7 @@
 #include "ba_lin.h"
 #include "ba_pack.h"
 #include "ba_solve.h"
+#include "ba_step.h"
 #include "ba_marg.h"
 #include "ba_lineopt.h"
 #include "ba_factors.h"
@@ -43,6 +44,7 @@ struct vpl_ctx {
   // the batch descriptor by value -- are fixed until the next upload); VPL_BA_GRAPH=0 launches kernel by kernel
   hipGraphExec_t graph_exec = nullptr;
   bool use_graph = true;
+  bool force_general = false;                    // VPL_BA_GENERAL=1: every window takes k_solve (A/B runs, tests of the general path)
   std::vector<std::string> kname_store;
   // host-side marg structure of the uploaded windows
   std::vector<int> h_mg_m;
@@ -224,6 +226,8 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
 #undef AL
   if (e == hipSuccess) e = dalloc(c, &c->d_act, (size_t)ACT_SLOTS * 4);
   AL2(order, 2 * W); AL2(ord_cnt, 4);
+  B.maxKS = B.maxP / 4 + B.maxL + NF + 2;
+  AL2(sk_tab, W * B.maxKS * 4); AL2(sk_wave, W * 8 * SK_WSTRIDE); AL2(sacc, W * SACC_N); AL2(ycs, W * 176); AL2(sx, W * 8); AL2(path, W);
   if (e != hipSuccess) {
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -249,11 +253,20 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   hipFuncSetAttribute((const void*)k_lin<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_max);
   hipFuncSetAttribute((const void*)k_lin<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_max);
   hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_max);
+  static size_t schur_max = 0, back_max = 0;
+  schur_max = std::max(schur_max, schur_smem(c->maxP, c->maxL));
+  back_max = std::max(back_max, back_smem(c->maxP, c->maxL));
+  if (schur_max > 159 * 1024 || back_max > 159 * 1024) { for (void* p : c->allocs) hipFree(p); delete c; return VPL_E_CAPACITY; }
+  hipFuncSetAttribute((const void*)k_schur<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_max);
+  hipFuncSetAttribute((const void*)k_schur<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_max);
+  hipFuncSetAttribute((const void*)k_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_SMEM);
+  hipFuncSetAttribute((const void*)k_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)back_max);
   hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SMEM);
   hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
   (void)hipGetLastError();
   vpl_ba_default_options(&c->opt);
   if (const char* gv = std::getenv("VPL_BA_GRAPH")) c->use_graph = std::atoi(gv) != 0;
+  if (const char* gv = std::getenv("VPL_BA_GENERAL")) c->force_general = std::atoi(gv) != 0;
   *out = c;
   return VPL_OK;
 }
@@ -437,6 +450,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   // (no value-initialisation: only the rounds a window uses are filled and uploaded)
   std::unique_ptr<int[]> pu_lane(new int[W * B.maxPR * 1024]), pu_sub(new int[W * B.maxPR * 512]);
   std::vector<int> pu_cnt(W, 0), pu_cnt0(W, 0);
+  std::vector<int> sk_tab(W * B.maxKS * 4, 0), sk_wave(W * 8 * SK_WSTRIDE, -1), path(W, 0);
   std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0), ll_tab(W * B.llSlots, -1), ll_np(W, 0);
   std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
@@ -551,6 +565,13 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       woff += no;
     }
     nL[w] = nl;
+    {   // K-steps of k_schur: landmark rows by start frame, dealt to the 8 waves, flush tickets (ba_pack.h)
+      int cnt[NF + 1];
+      for (int f = 0; f <= NF; ++f) cnt[f] = ps_cnt[w * (NF + 1) + f];
+      if (pack_schur_ksteps(v.n_points, &ps_list[w * B.maxP], cnt, nl, &ln_start[w * B.maxL], B.maxKS, &sk_tab[w * B.maxKS * 4],
+                            &sk_wave[w * 8 * SK_WSTRIDE], SCHUR_THREADS / 64) < 0)
+        return fail(c, VPL_E_CAPACITY, "K-step table of the landmark elimination too small");
+    }
     {   // lane layout of the line phase: llNLW whole tracks per wave, k-major; tracks in the caller's order (tracks that start
         // in the same frame side by side would pile their LDS adds onto the same addresses)
       std::vector<int> ord(nl);
@@ -572,6 +593,10 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       const vpl_prior& pr = *v.prior;
       if (pr.n < 0 || pr.n > MAXPN || pr.n_blocks < 0 || pr.n_blocks > MAXPB) return fail(c, VPL_E_INVALID, "bad prior");
       pr_n[w] = pr.n; pr_nb[w] = pr.n_blocks;
+      // k_chol's elimination order keeps speed/bias 0 in its dense part; a prior that ties another frame's speed/bias block
+      // (never produced by the reference's marginalisation) takes the general path
+      for (int b = 0; b < pr.n_blocks; ++b)
+        if (pr.block_kind[b] == 1 && pr.block_frame[b] != 0) path[w] = 1;
       c->maxPriorN = std::max(c->maxPriorN, pr.n);
       for (int b = 0; b < pr.n_blocks; ++b) {
         pr_kind[w * MAXPB + b] = pr.block_kind[b];
@@ -652,6 +677,8 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.mg_n, mg_n)); HIPCHK(c, up(c, B.mg_nb, mg_nb)); HIPCHK(c, up(c, B.mg_kind, mg_kind));
   HIPCHK(c, up(c, B.mg_frame, mg_frame)); HIPCHK(c, up(c, B.mg_idx, mg_idx)); HIPCHK(c, up(c, B.mg_cam, mg_cam));
   HIPCHK(c, up(c, B.mg_m, c->h_mg_m));
+  if (c->force_general) std::fill(path.begin(), path.end(), 1);
+  HIPCHK(c, up(c, B.sk_tab, sk_tab)); HIPCHK(c, up(c, B.sk_wave, sk_wave)); HIPCHK(c, up(c, B.path, path));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // host staging vectors die here
   return VPL_OK;
 }
@@ -888,7 +915,17 @@ static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
   ++B.launch;
   for (int it = 0; it < c->opt.num_iterations; ++it) {
     B.ord_it = it;      // k_solve / k_cost of iteration `it` walk order[it & 1]; k_cost fills order[(it + 1) & 1]
+    // the step: landmark elimination -> reduced camera system -> (general path: windows flagged in B.path only) -> landmark
+    // back-substitution + dogleg + candidate.
+    { KTimer t(c, "k_schur");
+      if (B.WS + 2 <= 48) hipLaunchKernelGGL(k_schur<3>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 3), s, B);
+      else hipLaunchKernelGGL(k_schur<5>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 5), s, B); }
+    ++B.launch;
+    { KTimer t(c, "k_chol"); hipLaunchKernelGGL(k_chol, grid, dim3(CHOL_THREADS), CHOL_SMEM, s, B); }
+    ++B.launch;
     { KTimer t(c, "k_solve"); hipLaunchKernelGGL(k_solve, grid, dim3(SOLVE_THREADS), solve_smem(B.maxP, B.maxL), s, B); }
+    ++B.launch;
+    { KTimer t(c, "k_back"); hipLaunchKernelGGL(k_back, grid, dim3(BACK_THREADS), back_smem(B.maxP, B.maxL), s, B); }
     ++B.launch;
     { KTimer t(c, "k_cost"); hipLaunchKernelGGL(k_cost, grid, dim3(COST_THREADS), 0, s, B); }
     ++B.launch;
