@@ -38,25 +38,61 @@ def algorithmic_bytes(P, L, n_prior, obs_p, obs_l):
     writes = 8 * ((171 * 171 + 171) + (2 * P + 20 * L) + (42 * P + 168 * L))
     lin_out = 8 * ((171 * 172 // 2 + 171) + (2 * P + 20 * L) + (42 * P + 168 * L))
     k_lin = reads + lin_out
-    k_solve = lin_out + 8 * 2 * nfull                 # a window that computes a new Gauss-Newton step
-    k_solve_reuse = 8 * 6 * nfull                     # a window that re-uses the step of a rejected iteration: vectors only
+    # the trust-region step (k_schur + k_chol + k_back, or k_solve on the general path) of a window that computes a new
+    # Gauss-Newton step reads the linearisation once; one that re-uses the step of a rejected iteration moves vectors only
+    k_solve = lin_out + 8 * 2 * nfull
+    k_solve_reuse = 8 * 6 * nfull
     k_cost = 8 * ((11 * 16 + 7 + P + 4 * L) + (3 * obs_p + 8 * obs_l) + 10 * 62 + (n_prior ** 2 + n_prior + 86))
     return dict(iteration=reads + writes, k_lin=k_lin, k_solve=k_solve, k_solve_reuse=k_solve_reuse, k_cost=k_cost)
 
 
+FP64_PEAK_TFLOPS = 78.6  # MI355X dense FP64 (vector = matrix) peak (MI355X_MICROARCH.md)
+STEP_KERNELS = ("k_schur", "k_chol", "k_solve", "k_back")    # the launches of one trust-region step
+
+
+def _pmc_file(name):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
+    return files[-1] if files else None
+
+
+def _pmc_keys(kernel):
+    if kernel == "k_step":
+        return ["k_schur<3>", "k_chol", "k_solve", "k_back"]
+    return [{"k_lin": "k_lin<0>"}.get(kernel, kernel)]
+
+
 def pmc_traffic(kernel, nW, P, L, which="total"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*/pmc_traffic.json, produced by
+    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC passes (profiles/r*/pmc_traffic.json, produced by
     tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this very command at the default workload,
-    corrected as MI355X_MICROARCH.md prescribes).  None when the workload differs from the profiled one."""
+    corrected as MI355X_MICROARCH.md prescribes) -- not measured in this run.  None when the workload differs from the
+    profiled one or the profile does not hold the kernel."""
     if (nW, P, L) != (512, 200, 80):
         return None
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
-    if not files:
+    f = _pmc_file("pmc_traffic.json")
+    if not f:
         return None
-    k = json.load(open(files[-1])).get("kernels", {})
-    key = {"k_lin": "k_lin<0>"}.get(kernel, kernel)
-    return k[key].get(which) if key in k else None
+    k = json.load(open(f)).get("kernels", {})
+    keys = _pmc_keys(kernel)
+    if not all(q in k for q in keys):
+        return None
+    return sum(k[q].get(which, 0.0) for q in keys)
+
+
+def pmc_flops(kernel, nW, P, L):
+    """FP64 operations per launch of `kernel` (mean over the launches of the profiled run) counted by the SQ instruction
+    counters (profiles/r*/pmc_flops.json: 64 x (ADD + MUL + TRANS + 2 FMA) + 512 x MFMA_MOPS), also from the committed
+    profile.  Returns (flops, n_launches_sampled) or None."""
+    if (nW, P, L) != (512, 200, 80):
+        return None
+    f = _pmc_file("pmc_flops.json")
+    if not f:
+        return None
+    k = json.load(open(f)).get("kernels", {})
+    keys = _pmc_keys(kernel)
+    if not all(q in k for q in keys):
+        return None
+    return sum(k[q]["flops"] for q in keys)
 
 
 def spawn_ranks(args):
@@ -145,23 +181,32 @@ def launch_profile(torch, dev, batch, reps):
 
 
 def roofline_from_profile(prof, ab, nW, P, L):
-    """Prices every launch of k_lin / k_solve / k_cost by the windows that DID WORK in it (device-side counters), not by
-    the batch size.  Returns the roofline object of the dominant kernel plus the per-kernel table."""
+    """Prices every launch of k_lin / the step / k_cost by the windows that DID WORK in it (device-side counters), not by
+    the batch size.  The step is k_schur + k_chol + k_solve (general path, normally idle) + k_back: priced and timed as one
+    unit `k_step` (sum of the four launches).  Returns the roofline object of the dominant kernel plus the per-kernel table."""
     per = {}
-    for name, ms, act in prof:
+    units = []                   # (name, ms, bytes, full-work windows)
+    i = 0
+    while i < len(prof):
+        name, ms, act = prof[i]
         if name == "k_lin":
-            b = ab["k_lin"] * act[0]
-        elif name == "k_solve":
-            b = ab["k_solve"] * act[1] + ab["k_solve_reuse"] * act[2]
+            units.append(("k_lin", ms, ab["k_lin"] * act[0], act[0]))
+        elif name == "k_schur":
+            grp = prof[i:i + 4]
+            assert [g[0] for g in grp] == list(STEP_KERNELS), [g[0] for g in grp]
+            tms = sum(g[1] for g in grp)
+            new = grp[0][2][1] + grp[2][2][1]                 # three-kernel path + general path
+            reuse = grp[3][2][2] + grp[2][2][2]
+            units.append(("k_step", tms, ab["k_solve"] * new + ab["k_solve_reuse"] * reuse, new))
+            i += 3
         elif name == "k_cost":
-            b = ab["k_cost"] * act[3]
-        else:
-            continue
+            units.append(("k_cost", ms, ab["k_cost"] * act[3], act[3]))
+        i += 1
+    for name, ms, b, full in units:
         e = per.setdefault(name, dict(ms=0.0, bytes=0.0, launches=0, heavy=None))
         e["ms"] += ms
         e["bytes"] += b
         e["launches"] += 1
-        full = {"k_lin": act[0], "k_solve": act[1], "k_cost": act[3]}[name]
         if full >= 0.999 * nW and (e["heavy"] is None or ms > e["heavy"]["ms"]):
             e["heavy"] = dict(ms=ms, bytes=b, windows=full)          # slowest launch in which every window did the full work
     dom = max(per, key=lambda k: per[k]["ms"])
@@ -170,6 +215,10 @@ def roofline_from_profile(prof, ab, nW, P, L):
         gbs = e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["ms"] > 0 else 0.0
         table[k] = {"ms_per_solve": e["ms"], "launches": e["launches"], "avg_launch_ms": e["ms"] / e["launches"],
                     "algorithmic_bytes_per_solve": e["bytes"], "GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
+        fl = pmc_flops(k, nW, P, L)
+        if fl is not None:
+            tf = fl * e["launches"] / (e["ms"] * 1e-3) / 1e12
+            table[k]["fp64"] = {"flops_per_launch": fl, "TFLOPs": tf, "frac": tf / FP64_PEAK_TFLOPS}
         if e["heavy"]:
             h = e["heavy"]
             hg = h["bytes"] / (h["ms"] * 1e-3) / 1e9
@@ -177,24 +226,38 @@ def roofline_from_profile(prof, ab, nW, P, L):
                                         "frac": hg / HBM_PEAK_GBS, "traffic": pmc_traffic(k, nW, P, L, "total_max")}
     d = table[dom]
     roof = {"bound": "hbm", "kernel": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
-            "traffic": pmc_traffic(dom, nW, P, L), "avg_launch_ms": d["avg_launch_ms"],
+            "traffic": pmc_traffic(dom, nW, P, L),
+            "traffic_source": "committed PMC profile (%s), not collected in this run" % (os.path.relpath(_pmc_file("pmc_traffic.json"), ROOT) if _pmc_file("pmc_traffic.json") else "none"),
+            "avg_launch_ms": d["avg_launch_ms"],
             "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_solve"] / d["launches"],
             "pricing": "algorithmic bytes of the windows that did work in each launch (device counters) / launch time "
-                       "(HIP events on the launch stream), summed over the %d launches of one solve" % d["launches"],
+                       "(HIP events on the launch stream), summed over the %d launches of one solve; k_step = k_schur + k_chol + "
+                       "k_solve (general path) + k_back" % d["launches"],
             "heavy_launch": d.get("heavy_launch"), "per_kernel": table}
     it_ms = sum(e["ms"] for e in per.values())
     it_bytes = sum(e["bytes"] for e in per.values())
     roof["pipeline_GBps"] = it_bytes / (it_ms * 1e-3) / 1e9
     roof["pipeline_frac"] = roof["pipeline_GBps"] / HBM_PEAK_GBS
+    # second roofline: FP64.  With ~10 MFLOP and ~0.5 MB per window-iteration the kernels sit right of the FP64 ridge
+    # (78.6 TF / 8 TB/s = 9.8 FLOP/B): `binding` names the roof the dominant kernel is closer to.
+    if "fp64" in d:
+        roof["fp64"] = {"bound": "fp64", "achieved": d["fp64"]["TFLOPs"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": d["fp64"]["frac"], "flops_per_launch": d["fp64"]["flops_per_launch"],
+                        "source": "SQ FP64 instruction counters of the committed PMC profile (%s)" % os.path.relpath(_pmc_file("pmc_flops.json"), ROOT)}
+        roof["binding"] = "fp64" if roof["fp64"]["frac"] > roof["frac"] else "hbm"
+    else:
+        roof["fp64"] = None
+        roof["binding"] = "unknown (no FP64 counter profile for this workload)"
     return roof
 
 
 def step_stats(reports, n):
     import numpy as np
     it = np.array([reports[i].iterations for i in range(n)])
-    ok = np.array([reports[i].num_successful_steps for i in range(n)])     # includes iteration 0 (ceres convention)
+    # accepted steps only: the device counter starts at 0 (csrc/ba_lin.h k_prep) and counts accepted steps, as the oracle's
+    # report does (oracle/window.cpp) -- iteration 0 is not in it
+    acc = np.array([reports[i].num_successful_steps for i in range(n)])
     term = np.array([reports[i].termination for i in range(n)])
-    acc = np.maximum(ok - 1, 0)
     return {"mean_tr_iterations": float(it.mean()), "mean_accepted_steps": float(acc.mean()),
             "mean_rejected_steps": float((it - acc).mean()),
             "accepted_histogram": [int((acc == k).sum()) for k in range(int(it.max()) + 1)],
@@ -254,6 +317,32 @@ def frontend_config4(torch, v, dev, steps=5, warm=2, n=64, imgs=None):
                             "frac": n * 752 * 480 * 8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     fe.close()
     return out
+
+
+def frontend_cpu_baseline(imgs, cores, budget_s=8.0):
+    """CPU baseline of config 4: the oracle's EDLines + line matching (CPU restatement of the reference path) on a bounded
+    sample of the same frame stream, fanned over the host threads this process may use (ctypes releases the GIL)."""
+    import numpy as np
+    import oracle_api as o       # checker / CPU baseline only
+    from concurrent.futures import ThreadPoolExecutor
+    o.load()
+    n = min(len(imgs), max(8, 2 * cores))
+    sample = imgs[:n]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        lines = list(ex.map(lambda im: o.edlines(im)[:256], sample))
+        list(ex.map(lambda i: o.line_match(sample[i], sample[i + 1], lines[i], lines[i + 1])[0], range(n - 1)))
+    one = time.perf_counter() - t0
+    reps = max(1, min(50, int(budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        with ThreadPoolExecutor(cores) as ex:
+            lines = list(ex.map(lambda im: o.edlines(im)[:256], sample))
+            list(ex.map(lambda i: o.line_match(sample[i], sample[i + 1], lines[i], lines[i + 1])[0], range(n - 1)))
+    dt = time.perf_counter() - t0
+    return {"value": n * reps / dt, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": o.cpu_model(),
+            "sample": "first %d frames of the stream (detect + %d consecutive-pair matches) x %d repeats over %d host threads, %.1f s"
+                      % (n, n - 1, reps, cores, dt)}
 
 
 def main():
@@ -350,12 +439,17 @@ def main():
             "config": {"workload": "one batch of %d independent synthetic sliding windows (BASELINE config %d shape) block-"
                                    "partitioned over %d GPU(s): 11 frames at 10 Hz, %d points + %d lines (x%d obs) + VP obs, "
                                    "10 IMU factors (20 samples each), prior n=%d from a warm-up solve; max %d TR iterations + "
-                                   "gauge fix + MARGIN_OLD marginalisation"
+                                   "gauge fix + MARGIN_OLD marginalisation; generator as DESIGN.md 2b (drift-style initial error, "
+                                   "triad about the direction of travel, d_z < 0 line directions: deviations from SURVEY 8d)"
                                    % (total, config_id if world == 1 else 5, world, P, L, TL, strong.n_prior, opt.num_iterations),
                        "windows_total": total, "windows_per_gpu": n_local, "points": P, "lines": L, "track_len": TL,
                        "prior_dim": strong.n_prior, "parallelism": "batch block-partitioned x%d, all-gather of results" % world,
                        **stats},
             "roofline": roof,
+            "linearisations_per_solve": sum(act[0] for n_, _, act in prof if n_ == "k_lin") / max(1, n_local),
+            "new_steps_per_solve": sum(act[1] for n_, _, act in prof if n_ in ("k_schur", "k_solve")) / max(1, n_local),
+            "work_note": "'5 iters' = max_num_iterations; a window linearises and factors only after an accepted step "
+                         "(linearisations_per_solve), a rejected iteration re-uses the Gauss-Newton step (DESIGN.md 2b)",
             "kernels_ms_per_step": kms,
             "device_ms_per_step": sum(kms.values()),
             "launches": [{"kernel": n, "ms": round(ms, 5), "active": [round(a, 1) for a in act]} for n, ms, act in prof],
@@ -459,11 +553,13 @@ def main():
                               "heavy_launch": rf2["heavy_launch"], **step_stats(r2, total)}
             c2.close()
             try:
-                stream = v.workload.frame_stream(64)
-                out["config4"] = frontend_config4(torch, v, dev, imgs=stream)
-                b256 = frontend_config4(torch, v, dev, steps=3, warm=1, n=256, imgs=stream)
+                frames = v.workload.frame_stream(64)
+                out["config4"] = frontend_config4(torch, v, dev, imgs=frames)
+                b256 = frontend_config4(torch, v, dev, steps=3, warm=1, n=256, imgs=frames)
                 out["config4"]["frames_in_flight_256"] = {k: b256[k] for k in ("value", "unit", "ms_per_batch", "device_ms_detect",
                                                                                "device_ms_match", "k_ed_grad")}
+                if not args.no_cpu_baseline:
+                    out["config4"]["cpu_baseline"] = frontend_cpu_baseline(frames, cpu_share())
             except Exception as e:   # the headline line must survive a front-end failure; it is reported, not hidden
                 out["config4"] = {"error": repr(e)}
     if rank == 0:

@@ -30,6 +30,23 @@ def test_bench_prints_one_contract_line():
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    assert "traffic_source" in r and "committed" in r["traffic_source"]          # the PMC bytes are NOT collected in this run
+    assert "binding" in r and "fp64" in r
+    if r["fp64"] is not None:
+        assert r["fp64"]["unit"] == "TFLOP/s" and r["fp64"]["peak"] == 78.6 and 0 < r["fp64"]["frac"] < 1
+        assert r["binding"] in ("hbm", "fp64")
+    # what the line says about the work it did is what the device counted
+    cfg = d["config"]
+    acc_hist = cfg["accepted_histogram"]
+    mean_acc = sum(k * n for k, n in enumerate(acc_hist)) / 512.0
+    assert abs(cfg["mean_accepted_steps"] - mean_acc) < 1e-9
+    # every accepted step but the last one of a window that stops there is followed by a linearisation; the first
+    # linearisation precedes all steps: sum(active k_lin) / nW - 1 <= mean accepted steps <= sum(active k_lin) / nW
+    lin = d["linearisations_per_solve"]
+    assert lin - 1.0 - 1e-9 <= cfg["mean_accepted_steps"] <= lin + 1e-9, (lin, cfg["mean_accepted_steps"])
+    assert cfg["mean_accepted_steps"] + cfg["mean_rejected_steps"] == pytest.approx(cfg["mean_tr_iterations"])
+    k_lin_active = sum(l["active"][0] for l in d["launches"] if l["kernel"] == "k_lin")
+    assert abs(k_lin_active / 512.0 - lin) < 1e-6
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

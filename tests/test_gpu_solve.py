@@ -556,3 +556,70 @@ def test_skewed_ragged_windows_marginalisation_pass_terminates():
     for i in range(3):
         assert nn[i] == rep_g[i].prior_n
     ctx.close()
+
+
+def test_general_path_matches_the_three_kernel_path(monkeypatch):
+    """k_solve (ba_solve.h) is the general path of the trust-region step: windows whose prior holds a speed/bias block of
+    another frame than 0, and retries after a failed factorisation.  VPL_BA_GENERAL=1 sends every window through it: same
+    iteration pattern and poses as the oracle, and poses within rounding of the three-kernel path (ba_step.h)."""
+    ws, opt = make_windows(3, 200, 80, True, seed0=70)
+    fast = v.Context(device=0, max_windows=3, max_points=200, max_point_obs=1200, max_lines=80, max_line_obs=480)
+    wf = [w.copy() for w in ws]
+    _, rep_f = fast.solve_windows(wf, opt)
+    fast.close()
+    monkeypatch.setenv("VPL_BA_GENERAL", "1")
+    gen = v.Context(device=0, max_windows=3, max_points=200, max_point_obs=1200, max_lines=80, max_line_obs=480)
+    monkeypatch.delenv("VPL_BA_GENERAL")
+    wg = [w.copy() for w in ws]
+    wc = [w.copy() for w in ws]
+    _, rep_g = gen.solve_windows(wg, opt)
+    gen.close()
+    for i in range(3):
+        _, rep_c = o.solve_window(wc[i], opt)
+        assert rep_g[i].iterations == rep_c.iterations and rep_g[i].num_successful_steps == rep_c.num_successful_steps
+        assert rep_f[i].iterations == rep_c.iterations and rep_f[i].num_successful_steps == rep_c.num_successful_steps
+        dp, dr = pose_err(wg[i], wc[i])
+        assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)
+        dp, dr = pose_err(wg[i], wf[i])
+        assert dp <= 1e-6 and dr <= 1e-8, (dp, dr)
+
+
+def test_prior_with_speed_bias_of_a_later_frame_takes_the_general_path(gpu_ctx):
+    """The reference's marginalisation only ever leaves speed/bias 0 in the prior; the interface allows any block table.  A
+    prior that ties speed/bias 3 is outside k_chol's elimination order (ba_step.h) and is routed to k_solve at upload."""
+    ws, opt = make_windows(2, 60, 20, True, seed0=90)
+    rng = np.random.default_rng(3)
+    pri = []
+    for w in ws:
+        p = v.Prior()
+        kinds, frames = [0, 1, 2], [2, 3, 0]                 # pose 2, speed/bias 3, extrinsic
+        n = 6 + 9 + 6
+        p.n, p.n_blocks = n, 3
+        idx = 0
+        for b, (k, f) in enumerate(zip(kinds, frames)):
+            p.block_kind[b], p.block_frame[b], p.block_idx[b] = k, f, idx
+            x0 = (w.pose[f] if k == 0 else w.speed_bias[f] if k == 1 else w.ex_pose)
+            for j in range(len(x0)):
+                p.x0[b][j] = float(x0[j])
+            idx += 9 if k == 1 else 6
+        J = np.triu(rng.normal(size=(n, n))) * 3.0 + 5.0 * np.eye(n)
+        r = rng.normal(size=n) * 0.1
+        flat = np.zeros(171 * 171)
+        flat[: n * n] = J.reshape(-1)
+        for j in range(n * n):
+            p.J0[j] = float(flat[j])
+        for j in range(n):
+            p.r0[j] = float(r[j])
+        pri.append(p)
+    wg, wc = [], []
+    for w, p in zip(ws, pri):
+        for lst in (wg, wc):
+            c = w.copy()
+            c.prior = p
+            lst.append(c)
+    _, rep_g = gpu_ctx.solve_windows(wg, opt)
+    for i in range(2):
+        _, rep_c = o.solve_window(wc[i], opt)
+        assert rep_g[i].iterations == rep_c.iterations and rep_g[i].num_successful_steps == rep_c.num_successful_steps
+        dp, dr = pose_err(wg[i], wc[i])
+        assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)

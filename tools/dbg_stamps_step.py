@@ -30,5 +30,6 @@ for w in (0, 1, nw // 2, nw - 1):
     print("window", w)
     print("  k_schur: scaling+cauchy %d constants %d product %d tail %d | total %d" % (s[1]-s[0], s[2]-s[1], s[3]-s[2], s[4]-s[3], s[4]-s[0]))
     print("  k_chol : chains %d assemble %d cholesky %d dense back-sub %d chains back + out %d | total %d" % (s[9]-s[8], s[10]-s[9], s[11]-s[10], s[12]-s[11], s[13]-s[12], s[13]-s[8]))
+    print("  k_chol assemble: loads+zero %d puts %d subtract %d" % (s[14]-s[9], s[15]-s[14], s[10]-s[15]))
     print("  k_back : landmark back-sub %d dogleg+candidate %d | total %d" % (s[6]-s[5], s[7]-s[6], s[7]-s[5]))
-    print("  extra stamps", s[40:48])
+    print("  k_schur product, wave 0: transform %d load-issue %d mfma %d flush %d (ticket wait %d) entries %d | wave 1: %d %d %d %d (%d) %d" % tuple(s[30:42]))

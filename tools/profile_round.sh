@@ -9,5 +9,5 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ba -o ba -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/ba.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fe -o fe -- python3 $ROOT/tools/bench_frontend.py > $OUT/fe.log 2>&1
 cd $ROOT
-bash tools/pmc_collect.sh gpurun_out/$1/pmc gpurun_out/$1/pmc_traffic.json
+bash tools/pmc_collect.sh gpurun_out/$1/pmc gpurun_out/$1/pmc_traffic.json gpurun_out/$1/pmc_flops.json
 ls $OUT $OUT/ba $OUT/fe

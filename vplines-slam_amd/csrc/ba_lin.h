@@ -335,10 +335,10 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     __syncthreads();
     auto ticket_wait = [&](int which, int seq) {
       while (__hip_atomic_load(&tick[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) {}
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");   // (what the ticket orders is LDS; global loads in flight stay in flight)
     };
     auto ticket_pass = [&](int which, int seq) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if (lane == 0) __hip_atomic_store(&tick[which], seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 #ifdef VPL_STAMPS

@@ -169,14 +169,16 @@ inline bool point_unit_chains_finish(const int* st, const PointUnitLayout& L, bo
 }
 
 // ---- entry table of k_schur (ba_step.h) ---------------------------------------------------------------------------
-// Landmark rows sorted by group (points by start frame, then lines by start frame).  An entry is one K-step of the FP64
-// matrix-core instruction: four points of one start frame, or the four rows of one line.
-// The entries are dealt to the NWV (<= 8) waves of k_schur in contiguous spans of about equal weight; a wave adds its accumulators
-// to the shared system whenever the group changes and at the end of its span.  Those adds are committed in ticket order,
-// sorted by the K-steps the wave has done when it reaches the add (ties: by wave): the waves start together and advance at
-// about the same rate, so a wave seldom finds its ticket not yet due -- and the order is a fixed function of the table.
-//   tab  [maxKS][4] : points {start frame f, id0 | id1 << 16, id2 | id3 << 16, 0} (0xffff = none); lines {32 | f, line, 0, 0}
-//   wave [8][SK_WSTRIDE] : {first entry, end, ticket of flush 0, ticket of flush 1, ...}
+// Landmark rows sorted by group (points by start frame, then lines by start frame).  An entry holds four landmarks of one
+// group: four points = one K-step of the FP64 matrix-core instruction, four lines = four K-steps (K-step a takes row a of
+// each line; weight 4).
+// The entries are dealt to the NWV (<= 8) waves of k_schur in CHUNKS -- a whole group, or a piece of a group that is heavier
+// than a wave's fair share; a wave adds its accumulators to the shared system at the end of every chunk.  Those adds are
+// committed in ticket order, sorted by the K-steps the wave has done when it reaches the add (ties: by wave): the waves
+// start together and advance at about the same rate, so a wave seldom finds its ticket not yet due -- and the order is a
+// fixed function of the table.
+//   tab  [maxKS][4] : {group (0..10: points of that start frame, 32 | f: lines), id0 | id1 << 16, id2 | id3 << 16, 0}, 0xffff = none
+//   wave [8][SK_WSTRIDE] : {number of chunks n, then n x (first entry, end, ticket)}
 // Returns the number of entries or -1 when a table is too small.
 inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL, const int* ln_start, int maxKS, int* tab,
                              int* wave, int NWV) {
@@ -186,7 +188,7 @@ inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL,
     if (nks >= maxKS) return false;
     tab[4 * nks] = g; tab[4 * nks + 1] = id[0] | id[1] << 16; tab[4 * nks + 2] = id[2] | id[3] << 16; tab[4 * nks + 3] = 0;
     grp.push_back(g);
-    wgt.push_back(1);
+    wgt.push_back((g & 32) ? 4 : 1);
     ++nks;
     return true;
   };
@@ -197,31 +199,60 @@ inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL,
       for (int i = 0; i < 4; ++i) id[i] = q + i < cnt[f + 1] ? ps_list[q + i] : 0xffff;
       if (!push(f, id)) return -1;
     }
-  for (int f = 0; f < NF; ++f)
+  for (int f = 0; f < NF; ++f) {
+    int id[4], n = 0;
     for (int l = 0; l < nL; ++l)
       if (ln_start[l] == f) {
-        const int id[4] = {l, 0, 0, 0};
-        if (!push(32 | f, id)) return -1;
+        id[n++] = l;
+        if (n == 4) { if (!push(32 | f, id)) return -1; n = 0; }
       }
-  // spans of about equal weight: wave v takes the entries whose weight prefix falls into [v, v + 1) * total / 8
+    if (n) {
+      for (int i = n; i < 4; ++i) id[i] = 0xffff;
+      if (!push(32 | f, id)) return -1;
+    }
+  }
+  // Chunks: a group, or a piece of one when the group is heavier than a wave's fair share.  A chunk is worked by ONE wave
+  // and ends with ONE add into the shared system; chunks go to the waves longest-first onto the least loaded wave.
   std::vector<long> pre(nks + 1, 0);
   for (int k = 0; k < nks; ++k) pre[k + 1] = pre[k] + wgt[k];
   const long total = pre[nks];
-  int k0[8], k1[8];
-  {
-    int k = 0;
-    for (int wv = 0; wv < NWV; ++wv) {
-      k0[wv] = k;
-      const long lim = (total * (wv + 1) + NWV - 1) / NWV;
-      while (k < nks && (wv == NWV - 1 || pre[k] + (wgt[k] + 1) / 2 <= lim)) ++k;
-      k1[wv] = k;
+  const long fair = std::max(1L, (total + NWV - 1) / NWV);
+  struct Chunk { int k0, k1; long w; };
+  std::vector<Chunk> chunks;
+  for (int k = 0; k < nks;) {
+    int e = k;
+    while (e < nks && grp[e] == grp[k]) ++e;
+    const long gw = pre[e] - pre[k];
+    const int pieces = (int)((gw + fair - 1) / fair);
+    int c0 = k;
+    for (int pc = 0; pc < pieces; ++pc) {
+      const long lim = pre[k] + gw * (pc + 1) / pieces;
+      int c1 = c0;
+      while (c1 < e && (pc == pieces - 1 || pre[c1 + 1] <= lim)) ++c1;
+      if (c1 > c0) chunks.push_back(Chunk{c0, c1, pre[c1] - pre[c0]});
+      c0 = c1;
     }
+    k = e;
   }
-  struct Inc { int wv; long when; };
+  std::vector<int> ord(chunks.size());
+  for (size_t i = 0; i < ord.size(); ++i) ord[i] = (int)i;
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return chunks[a].w > chunks[b].w; });
+  std::vector<std::vector<int>> mine(NWV);
+  std::vector<long> load(NWV, 0);
+  for (int ci : ord) {
+    int best = 0;
+    for (int wv = 1; wv < NWV; ++wv) if (load[wv] < load[best]) best = wv;
+    mine[best].push_back(ci);
+    load[best] += chunks[ci].w;
+  }
+  // a wave works its chunks in table order; ticket order = by the weight the wave has done when the chunk ends (ties: wave)
+  struct Inc { int wv, ci; long when; };
   std::vector<Inc> inc;
-  for (int wv = 0; wv < NWV; ++wv)
-    for (int k = k0[wv]; k < k1[wv]; ++k)
-      if (k + 1 == k1[wv] || grp[k + 1] != grp[k]) inc.push_back(Inc{wv, pre[k + 1] - pre[k0[wv]]});
+  for (int wv = 0; wv < NWV; ++wv) {
+    std::sort(mine[wv].begin(), mine[wv].end());
+    long done = 0;
+    for (int ci : mine[wv]) { done += chunks[ci].w; inc.push_back(Inc{wv, ci, done}); }
+  }
   std::vector<int> order(inc.size());
   for (size_t i = 0; i < inc.size(); ++i) order[i] = (int)i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
@@ -230,16 +261,17 @@ inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL,
   });
   std::vector<int> ticket(inc.size());
   for (size_t t = 0; t < order.size(); ++t) ticket[order[t]] = (int)t;
-  for (int wv = 0; wv < NWV; ++wv) {
+  for (int wv = 0; wv < 8; ++wv) {
     int* o = wave + wv * SK_WSTRIDE;
     std::fill(o, o + SK_WSTRIDE, -1);
-    o[0] = k0[wv]; o[1] = k1[wv];
-    int nf = 0;
-    for (size_t i = 0; i < inc.size(); ++i)
-      if (inc[i].wv == wv) {
-        if (2 + nf >= SK_WSTRIDE) return -1;
-        o[2 + nf++] = ticket[i];
-      }
+    o[0] = 0;
+  }
+  for (size_t i = 0; i < inc.size(); ++i) {
+    int* o = wave + inc[i].wv * SK_WSTRIDE;
+    const int n = o[0];
+    if (1 + 3 * (n + 1) > SK_WSTRIDE) return -1;
+    o[1 + 3 * n] = chunks[inc[i].ci].k0; o[2 + 3 * n] = chunks[inc[i].ci].k1; o[3 + 3 * n] = ticket[i];
+    o[0] = n + 1;
   }
   return nks;
 }

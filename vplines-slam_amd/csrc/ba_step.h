@@ -29,10 +29,10 @@ constexpr int BACK_THREADS = 256;
 
 __device__ __forceinline__ void lds_ticket_wait(int* t, int seq) {
   while (__hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");   // (LDS only: global loads in flight stay in flight)
 }
 __device__ __forceinline__ void lds_ticket_pass(int* t, int seq, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   if (lane == 0) __hip_atomic_store(t, seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -183,21 +183,24 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
   __syncthreads();   // uc, kP, kL complete
   // camera part of the Cauchy denominator u^T Hcc u: one coalesced pass over the packed triangle (eight loads in flight)
   double qq = 0.0;
+  {
+    // (r, c) of this thread's entries without a root per entry: the first one is decoded, the following ones step T entries on
+    int r, c;
+    tri_decode(tid, r, c);
 #pragma unroll 1
-  for (int base = 0; base < NCP; base += 16 * T) {
-    double hh[16];
+    for (int base = 0; base < NCP; base += 16 * T) {
+      double hh[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * T + tid;
-      hh[u] = idx < NCP ? Hcc[idx] : 0.0;
-    }
+      for (int u = 0; u < 16; ++u) {
+        const int idx = base + u * T + tid;
+        hh[u] = idx < NCP ? Hcc[idx] : 0.0;
+      }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * T + tid;
-      if (idx < NCP) {
-        int r, c;
-        tri_decode(idx, r, c);
-        qq += (r == c ? 1.0 : 2.0) * uc[r] * hh[u] * uc[c];
+      for (int u = 0; u < 16; ++u) {
+        const int idx = base + u * T + tid;
+        if (idx < NCP) qq += (r == c ? 1.0 : 2.0) * uc[r] * hh[u] * uc[c];
+        c += T;
+        while (c > r) { c -= r + 1; ++r; }
       }
     }
   }
@@ -289,7 +292,7 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
     const int m = lane & 15, kk = lane >> 4;
     // the wave's row of the span / ticket table: one int per lane, read with v_readlane
     const int wrow = lane < SK_WSTRIDE ? B.sk_wave[((size_t)w * 8 + wv) * SK_WSTRIDE + lane] : -1;
-    const int k0 = __builtin_amdgcn_readlane(wrow, 0), k1 = __builtin_amdgcn_readlane(wrow, 1);
+    const int nchunk = __builtin_amdgcn_readlane(wrow, 0);
     auto fetch = [&](int k) {        // the entry is the same for every lane: scalar registers, uniform branches
       int4 e = etab[k];
       e.x = __builtin_amdgcn_readfirstlane(e.x); e.y = __builtin_amdgcn_readfirstlane(e.y); e.z = __builtin_amdgcn_readfirstlane(e.z);
@@ -322,98 +325,168 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
       em[t] = c == WS + 1 ? 1.0 : 0.0;
       cl[t] = c < WS ? c : WS - 1;
     }
+    // A table entry is four landmarks of one start frame: four points = ONE K-step, four lines = FOUR K-steps (K-step a takes
+    // row a of each line).  The lane (kk, m) works on landmark kk of the entry: a point lane loads one value per column tile,
+    // a line lane the four rows of ITS line, solves the 4 x 4 triangular system once per column and supplies row a in
+    // K-step a -- every loaded value is used once and the solve is not repeated per K-step.
     // (the g column of X is made once per landmark with the constants: the loop loads rows of W and nothing else)
+    auto lm_id = [&](const int4 e) { return ((kk & 2 ? e.z : e.y) >> (16 * (kk & 1))) & 0xffff; };
     auto load_raw = [&](const int4 e, double (&raw)[NTC][4]) {
       const bool isl = (e.x & 32) != 0;
+      const int idr = lm_id(e);
+      const int id = idr != 0xffff ? idr : 0;
       if (isl) {
-        const double* Wr = Wl + e.y * 4 * WS;
+        const double* Wr = Wl + (unsigned)(id * 4 * WS);
 #pragma unroll
         for (int t = 0; t < NTC; ++t)
 #pragma unroll
+#ifdef VPL_X_NOLOAD
+          for (int qd = 0; qd < 4; ++qd) raw[t][qd] = 1e-3 * (qd + t + id);
+#else
           for (int qd = 0; qd < 4; ++qd) raw[t][qd] = Wr[(unsigned)(qd * WS + cl[t])];
+#endif
       } else {
-        const int pr = ((kk & 2 ? e.z : e.y) >> (16 * (kk & 1))) & 0xffff;
-        const int p = pr != 0xffff ? pr : 0;
 #pragma unroll
-        for (int t = 0; t < NTC; ++t) raw[t][0] = Wp[(unsigned)(p * WS + cl[t])];
+#ifdef VPL_X_NOLOAD
+        for (int t = 0; t < NTC; ++t) raw[t][0] = 1e-3 * (t + id);
+#else
+        for (int t = 0; t < NTC; ++t) raw[t][0] = Wp[(unsigned)(id * WS + cl[t])];
+#endif
 #pragma unroll
         for (int t = 0; t < NTC; ++t)       // (every element defined on both paths)
 #pragma unroll
           for (int qd = 1; qd < 4; ++qd) raw[t][qd] = 0.0;
       }
     };
-    auto transform = [&](const int4 e, const double (&raw)[NTC][4], double (&x)[NTC]) {
+    // x[t][a] = X[row a of the lane's landmark][16 t + m]  (points: a = 0 only)
+    auto transform = [&](const int4 e, const double (&raw)[NTC][4], double (&x)[NTC][4]) {
       const bool isl = (e.x & 32) != 0;
+      const int idr = lm_id(e);
+      const int id = idr != 0xffff ? idr : 0;
+      const double pm = idr != 0xffff ? 1.0 : 0.0;
       if (isl) {
-        const int l = e.y;
-        const double* C = lC + l * 10;
-        const double s0 = lS[4 * l], s1 = lS[4 * l + 1], s2 = lS[4 * l + 2], s3 = lS[4 * l + 3];
+        const double* C = lC + id * 10;
+        const double s0 = lS[4 * id] * pm, s1 = lS[4 * id + 1] * pm, s2 = lS[4 * id + 2] * pm, s3 = lS[4 * id + 3] * pm;
         const double c10 = C[1], c20 = C[3], c21 = C[4], c30 = C[6], c31 = C[7], c32 = C[8];
-        const double ev = lE[4 * l + kk], gv = lG[4 * l + kk];
+        double ev[4], gv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { ev[a] = lE[4 * id + a] * pm; gv[a] = lG[4 * id + a] * pm; }
 #pragma unroll
         for (int t = 0; t < NTC; ++t) {
           const double x0 = s0 * raw[t][0];
           const double x1 = s1 * raw[t][1] - c10 * x0;
           const double x2 = s2 * raw[t][2] - c20 * x0 - c21 * x1;
           const double x3 = s3 * raw[t][3] - c30 * x0 - c31 * x1 - c32 * x2;
-          x[t] = (kk == 0 ? x0 : (kk == 1 ? x1 : (kk == 2 ? x2 : x3))) * wm[t] + gv * gm[t] + ev * em[t];
+          x[t][0] = x0 * wm[t] + gv[0] * gm[t] + ev[0] * em[t];
+          x[t][1] = x1 * wm[t] + gv[1] * gm[t] + ev[1] * em[t];
+          x[t][2] = x2 * wm[t] + gv[2] * gm[t] + ev[2] * em[t];
+          x[t][3] = x3 * wm[t] + gv[3] * gm[t] + ev[3] * em[t];
         }
       } else {
-        const int pr = ((kk & 2 ? e.z : e.y) >> (16 * (kk & 1))) & 0xffff;
-        const int p = pr != 0xffff ? pr : 0;
-        const double pm = pr != 0xffff ? 1.0 : 0.0;
-        const double sp = pS[p] * pm, ep = pE[p] * pm, gq = pG[p] * pm;
+        const double sp = pS[id] * pm, ep = pE[id] * pm, gq = pG[id] * pm;
 #pragma unroll
-        for (int t = 0; t < NTC; ++t) x[t] = sp * raw[t][0] * wm[t] + gq * gm[t] + ep * em[t];
+        for (int t = 0; t < NTC; ++t) {
+          x[t][0] = sp * raw[t][0] * wm[t] + gq * gm[t] + ep * em[t];
+          x[t][1] = 0.0; x[t][2] = 0.0; x[t][3] = 0.0;
+        }
       }
     };
-    int nfl = 0;
-    auto flush = [&](int g) {
+#ifdef VPL_STAMPS
+    long long st_flush = 0, st_wait = 0, st_xf = 0, st_mf = 0, st_ld = 0;
+#endif
+    auto flush = [&](int g, int seq) {
+#ifdef VPL_STAMPS
+      const long long tf0 = __builtin_readcyclecounter();
+#endif
       const int s6 = 6 * (g & 15);
-      const int seq = __builtin_amdgcn_readlane(wrow, __builtin_amdgcn_readfirstlane(2 + nfl));
-      ++nfl;
+      // targets first (one batch of LDS reads), then the ticket, then 4 NLT hardware adds (ds_add_f64: no read-back round
+      // trip).  Only the holder of the ticket adds, one add per address: the order of the terms of every sum is the ticket order.
+      int code[NLT * 4];
+#pragma unroll
+      for (int i = 0; i < NLT * 4; ++i) code[i] = ftab[i * 64 + lane];
+#ifndef VPL_X_NOTICKET
       lds_ticket_wait(&tick[0], seq);
+#endif
+#ifdef VPL_STAMPS
+      st_wait += __builtin_readcyclecounter() - tf0;
+#endif
 #pragma unroll
       for (int t = 0; t < NLT; ++t) {
         const double vals[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int code = ftab[(t * 4 + v) * 64 + lane];
-          if (code >= 0) Cacc[(code & 0xffff) + s6 * (code >> 16)] += vals[v];
+          const int c2 = code[4 * t + v];
+          if (c2 >= 0) lds_add(&Cacc[(c2 & 0xffff) + s6 * (c2 >> 16)], vals[v]);
         }
         acc[t] = v4d{0, 0, 0, 0};
       }
       lds_ticket_pass(&tick[0], seq, lane);
+#ifdef VPL_STAMPS
+      st_flush += __builtin_readcyclecounter() - tf0;
+#endif
     };
-    if (k1 > k0) {
-      double raw0[NTC][4], raw1[NTC][4], raw2[NTC][4], raw3[NTC][4];
-      constexpr int NPF = 4;
+    int nent = 0;
+#pragma unroll 1
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int k0 = __builtin_amdgcn_readlane(wrow, __builtin_amdgcn_readfirstlane(1 + 3 * ch));
+      const int k1 = __builtin_amdgcn_readlane(wrow, __builtin_amdgcn_readfirstlane(2 + 3 * ch));
+      const int seq = __builtin_amdgcn_readlane(wrow, __builtin_amdgcn_readfirstlane(3 + 3 * ch));
+      nent += k1 - k0;
+      double raw0[NTC][4], raw1[NTC][4], raw2[NTC][4];
+      constexpr int NPF = 3;
       load_raw(fetch(k0), raw0);
       load_raw(fetch(min(k0 + 1, k1 - 1)), raw1);
       load_raw(fetch(min(k0 + 2, k1 - 1)), raw2);
-      load_raw(fetch(min(k0 + 3, k1 - 1)), raw3);
-      int gcur = fetch(k0).x;
+      const int gcur = fetch(k0).x;
       auto step = [&](int k, double (&rw)[NTC][4]) {
         const int4 e = fetch(k);
-        if (e.x != gcur) { flush(gcur); gcur = e.x; }
-        double x[NTC];
+#ifdef VPL_STAMPS
+        const long long ts0 = __builtin_readcyclecounter();
+#endif
+        double x[NTC][4];
         transform(e, rw, x);
+#ifdef VPL_STAMPS
+        const long long ts1 = __builtin_readcyclecounter();
+        st_xf += ts1 - ts0;
+#endif
         load_raw(fetch(min(k + NPF, k1 - 1)), rw);      // (past the end: a harmless re-load of the last entry)
-        int t = 0;
+#ifdef VPL_STAMPS
+        const long long ts2 = __builtin_readcyclecounter();
+        st_ld += ts2 - ts1;
+#endif
+        const bool isl = (e.x & 32) != 0;
 #pragma unroll
-        for (int ta = 0; ta < NTC; ++ta)
+        for (int a = 0; a < 4; ++a) {
+          if (a == 0 || isl) {
+            int t = 0;
 #pragma unroll
-          for (int tb = 0; tb <= ta; ++tb, ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ta], x[tb], acc[t], 0, 0, 0);
+            for (int ta = 0; ta < NTC; ++ta)
+#pragma unroll
+#ifdef VPL_X_NOMFMA
+              for (int tb = 0; tb <= ta; ++tb, ++t) acc[t].x += x[ta][a] * x[tb][a];
+#else
+              for (int tb = 0; tb <= ta; ++tb, ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ta][a], x[tb][a], acc[t], 0, 0, 0);
+#endif
+          }
+        }
+#ifdef VPL_STAMPS
+        st_mf += __builtin_readcyclecounter() - ts2;
+#endif
       };
 #pragma unroll 1
       for (int kb = k0; kb < k1; kb += NPF) {
         step(kb, raw0);
         if (kb + 1 < k1) step(kb + 1, raw1);
         if (kb + 2 < k1) step(kb + 2, raw2);
-        if (kb + 3 < k1) step(kb + 3, raw3);
       }
-      flush(gcur);
+      flush(gcur, seq);
     }
+#ifdef VPL_STAMPS
+    if (lane == 0 && wv < 2) {
+      long long* dg_ = B.dbg + (size_t)w * 64 + 30 + 6 * wv;
+      dg_[0] = st_xf; dg_[1] = st_ld; dg_[2] = st_mf; dg_[3] = st_flush; dg_[4] = st_wait; dg_[5] = nent;
+    }
+#endif
   }
   __syncthreads();
   VPL_STAMP(B, w, 3);
@@ -708,6 +781,7 @@ __device__ __forceinline__ void chol_body(const DevBatch& B, const int w, double
     }
     for (int i = tid; i < DNAP; i += T) S[i] = 0.0;
     __syncthreads();
+    VPL_STAMP(B, w, 14);
     // (i) pose / extrinsic block: (Hcc - Schur) in the scaled space + mu D^2; the packed index of the 72 x 72 vis triangle is
     //     the index into the compact Schur product
 #pragma unroll
@@ -737,6 +811,7 @@ __device__ __forceinline__ void chol_body(const DevBatch& B, const int w, double
     if (tid < 6) S[tix(DN + tid, DN + tid)] = 1.0;      // rhs row and padding rows: unit diagonal, never a pivot
   }
   __syncthreads();
+  VPL_STAMP(B, w, 15);
   // (iv) minus the chains' products, chain A's first (fixed order of the two terms per entry)
 #pragma unroll 1
   for (int ch = 0; ch < 2; ++ch) {
@@ -991,21 +1066,22 @@ __device__ __forceinline__ void back_body(const DevBatch& B, const int w, double
     const double mu = tr->mu;
     for (int p = tid; p < nP; p += T) pSt[p] = B.pt_start[(size_t)w * B.maxP + p];
     for (int l = tid; l < nL; l += T) lSt[l] = B.ln_start[(size_t)w * B.maxL + l];
-    for (int c = tid; c < 176; c += T) uc[c] = B.ycs[(size_t)w * 176 + c];
+    for (int c = tid; c < 176; c += T) uc[c] = c < NV ? B.ycs[(size_t)w * 176 + vis2cam(c)] : 0.0;   // vis order: W's column order
     for (int c = tid; c < NC; c += T) lgn[c] = ggn[c];
     __syncthreads();
     double a2 = 0.0, a3 = 0.0;
     {
       const int sub = lane & 7, grp = tid >> 3;   // 64 row groups per pass
       const int nblk = WS / 6;
-      for (int p0 = 0; p0 < nP; p0 += 2 * (T / 8)) {
-        double wyv[2] = {0.0, 0.0}, sv[2], dv[2], hv[2], gv2[2], grv[2];
-        size_t piv[2];
+      constexpr int NPH = 4;   // row groups per trip: their loads are in flight together
+      for (int p0 = 0; p0 < nP; p0 += NPH * (T / 8)) {
+        double wyv[NPH], sv[NPH], dv[NPH], hv[NPH], gv2[NPH], grv[NPH];
+        size_t piv[NPH];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NPH; ++h) {
           const int p = p0 + h * (T / 8) + grp;
           piv[h] = (size_t)w * B.maxP + (p < nP ? p : 0);
-          sv[h] = dv[h] = 1.0; hv[h] = gv2[h] = grv[h] = 0.0;
+          wyv[h] = 0.0; sv[h] = dv[h] = 1.0; hv[h] = gv2[h] = grv[h] = 0.0;
           if (p < nP) {
             const int s0 = pSt[p];
             for (int blk = sub; blk < nblk; blk += 8) {
@@ -1014,7 +1090,7 @@ __device__ __forceinline__ void back_body(const DevBatch& B, const int w, double
               if (!exb && vb >= 66) continue;
               const double* Wr = B.Wp + piv[h] * WS + 6 * blk;
 #pragma unroll
-              for (int k = 0; k < 6; ++k) wyv[h] += Wr[k] * uc[vis2cam(vb + k)];
+              for (int k = 0; k < 6; ++k) wyv[h] += Wr[k] * uc[vb + k];
             }
             if (sub == 0) {
               sv[h] = gscale[LP + p]; dv[h] = gdiag[LP + p]; hv[h] = B.Hpp[piv[h]]; gv2[h] = B.gp[piv[h]];
@@ -1023,7 +1099,7 @@ __device__ __forceinline__ void back_body(const DevBatch& B, const int w, double
           }
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NPH; ++h) {
           const int p = p0 + h * (T / 8) + grp;
           double wy = wyv[h];
           wy += __shfl_xor(wy, 1, 64); wy += __shfl_xor(wy, 2, 64); wy += __shfl_xor(wy, 4, 64);
@@ -1038,7 +1114,7 @@ __device__ __forceinline__ void back_body(const DevBatch& B, const int w, double
           }
         }
       }
-      constexpr int NLH = 3;
+      constexpr int NLH = 5;
       for (int r0 = 0; r0 < 4 * nL; r0 += NLH * (T / 8)) {
         double wyv[NLH], glv[NLH];
 #pragma unroll
@@ -1054,7 +1130,7 @@ __device__ __forceinline__ void back_body(const DevBatch& B, const int w, double
               if (!exb && vb >= 66) continue;
               const double* Wr = B.Wl + (li * 4 + a) * WS + 6 * blk;
 #pragma unroll
-              for (int k = 0; k < 6; ++k) wyv[h] += Wr[k] * uc[vis2cam(vb + k)];
+              for (int k = 0; k < 6; ++k) wyv[h] += Wr[k] * uc[vb + k];
             }
             if (sub == 0) glv[h] = B.gl[li * 4 + a];
           }

@@ -24,7 +24,7 @@ constexpr int NCP = NC * (NC + 1) / 2; // packed lower triangle of the cam Hessi
 constexpr int MAXPB = 23;              // prior blocks
 constexpr int MAXPN = 171;             // prior dim
 constexpr int ACT_SLOTS = 64;             // launches of one solve whose activity is counted
-constexpr int SK_WSTRIDE = 32;         // ints per wave in sk_wave: k0, k1, then up to 30 flush tickets
+constexpr int SK_WSTRIDE = 64;         // ints per wave in sk_wave: chunk count, then up to 21 x (first entry, end, ticket)
 constexpr int SACC_N = 74 * 75 / 2;     // packed lower triangle of the compact Schur product: 72 vis dims, rhs row, Cauchy row
 constexpr int MAXKEEP = 80;            // new prior dim after MARGIN_OLD: <= 10*6 + 9 + 6 = 75
 
@@ -137,9 +137,8 @@ struct DevBatch {
   // frames start .. start + maxTrack - 1, extrinsic, g, e); a wave adds its product to the window's compact 74 x 74 system
   // when the start frame changes.  sk_tab: K-steps sorted by group (points by start frame, then lines by start frame):
   // {group, id0 | id1 << 16, id2 | id3 << 16, 0} for four point rows (0xffff: none) or {group | 32, line, 0, 0} for the four
-  // rows of one line.  sk_wave[wave]: {first K-step, end, tickets of the wave's flushes in order ...} -- the adds into the
-  // shared system are committed in ticket order (group-major, waves descending inside a group) so that every sum has a fixed
-  // order of terms.
+  // rows of one line.  sk_wave[wave]: {number of chunks, then (first entry, end, ticket) per chunk} -- see ba_pack.h; the adds
+  // into the shared system are committed in ticket order so that every sum has a fixed order of terms.
   int *sk_tab, *sk_wave;                         // [W][maxKS][4] ; [W][8][SK_WSTRIDE]
   int maxKS;
   double *sacc;                                  // [W][SACC_N] packed lower triangle of the compact Schur product (rows 0..73)
