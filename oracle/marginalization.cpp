@@ -6,6 +6,10 @@
 
 namespace orc {
 
+// TEST SWITCH (0 = the reference's rule).  > 0: the spectrum of the kept block is cut at max(1e-8, rel * max diagonal) instead of
+// the reference's absolute 1e-8 (marginalization_factor.cpp:349-357) -- the cut the device's pivoted Cholesky makes
+// (csrc/ba_marg.h, kMargNoiseRel); tests/test_gpu_chain.py uses it to measure what that deviation does over a long chain.
+double g_marg_rel_eps = 0.0;
 int g_marg_threads = 1;   // NUM_THREADS of marginalization_factor.h:13 is 4; 1 = the same sums without threads
 
 // marginalization_factor.cpp:3-69
@@ -228,9 +232,15 @@ void MarginalizationInfo::marginalize() {
   sym_eigen(A3, S, V2);
   linearized_jacobians.resize(n2, n2);
   linearized_residuals.assign(n2, 0.0);
+  double cut = eps;
+  if (g_marg_rel_eps > 0.0) {
+    double dmax = 0.0;
+    for (int i = 0; i < n2; ++i) dmax = std::max(dmax, A3(i, i));
+    cut = std::max(eps, g_marg_rel_eps * dmax);
+  }
   for (int k = 0; k < n2; ++k) {
-    const double s = S[k] > eps ? S[k] : 0.0;
-    const double sinv = S[k] > eps ? 1.0 / S[k] : 0.0;
+    const double s = S[k] > cut ? S[k] : 0.0;
+    const double sinv = S[k] > cut ? 1.0 / S[k] : 0.0;
     const double s_sqrt = std::sqrt(s), sinv_sqrt = std::sqrt(sinv);
     double vb = 0;
     for (int i = 0; i < n2; ++i) {

@@ -366,7 +366,10 @@ __device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* 
 
 constexpr int MARG_THREADS = 512;
 constexpr double kMargEps = 1e-8;   // marginalization_factor.h:67
-constexpr double kMargNoiseRel = 1e-9;   // pivots of the kept block below this fraction of its largest diagonal are noise
+#ifndef VPL_MARG_NOISE_REL
+#define VPL_MARG_NOISE_REL 0.0
+#endif
+constexpr double kMargNoiseRel = VPL_MARG_NOISE_REL;   // pivots of the kept block below this fraction of its largest diagonal are noise
 constexpr int MTROWS_MAX = 96;      // landmark rows staged per elimination pass: 96 where the prior leaves the LDS for it (every pass
                                     // costs two global round trips and three barriers), 64 or 32 for large priors
 static_assert(MAXKEEP <= 80, "psd_spectral_factor keeps 10 rows per lane (8 lanes per column pair)");
