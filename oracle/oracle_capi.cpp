@@ -8,6 +8,7 @@
 #include "problem.h"
 
 namespace orc {
+extern double g_test_tolerance_scale;
 int triangulate_lines(vpl_window* w, const vpl_ba_options* opt);
 int triangulate_points(vpl_window* w, const vpl_ba_options* opt, double init_depth);
 int slide_window(vpl_window* w, const vpl_ba_options* opt, int marginalization_flag, double init_depth, vpl_slide_tracks* out);
@@ -151,6 +152,7 @@ int orc_slide_window(vpl_window* w, const vpl_ba_options* opt, int flag, double 
 int orc_only_line_opt(vpl_window* w, const vpl_ba_options* opt, vpl_solve_report* rep) { return only_line_opt(w, opt, rep); }
 
 // threads of MarginalizationInfo's A, b assembly (the reference runs 4, marginalization_factor.h:13)
+void orc_set_tolerance_scale(double sc) { orc::g_test_tolerance_scale = sc > 0.0 ? sc : 0.0; }   // test hook, see window.cpp
 void orc_set_marg_threads(int n) { g_marg_threads = n < 1 ? 1 : n; }
 // test switch: relative truncation of the kept block's spectrum (0 = the reference's absolute 1e-8), see marginalization.cpp
 void orc_set_marg_truncation(double rel) { g_marg_rel_eps = rel > 0.0 ? rel : 0.0; }

@@ -12,6 +12,10 @@
 #include "problem.h"
 
 namespace orc {
+// TEST HOOK: scales ceres' three termination tolerances in the main solve (tests/test_oracle_fixed_point.py runs the solve to
+// its fixed point to compare it with an independent least-squares solver).  0 = off.
+double g_test_tolerance_scale = 0.0;
+
 
 namespace {
 
@@ -463,6 +467,11 @@ int solve_window(vpl_window* w, const vpl_ba_options* opt, vpl_prior* prior_out,
       }
     }
     SolverOptions options;
+    if (g_test_tolerance_scale > 0.0) {   // test hook (oracle_capi.cpp orc_set_tolerance_scale): 0 = ceres' defaults
+      options.function_tolerance *= g_test_tolerance_scale;
+      options.parameter_tolerance *= g_test_tolerance_scale;
+      options.gradient_tolerance *= g_test_tolerance_scale;
+    }
     options.max_num_iterations = opt->num_iterations;
     SolverSummary summary;
     // the prior factor and the loss are owned elsewhere (marginalization info / below)
