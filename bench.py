@@ -345,6 +345,21 @@ def frontend_cpu_baseline(imgs, cores, budget_s=8.0):
                       % (n, n - 1, reps, cores, dt)}
 
 
+def c_abi_latency():
+    """tests/native/latency_check.cpp: wall-clock latency of upload / solve / download through the C ABI from a C++ caller
+    (1, 8, 64 windows).  None when the program cannot be built or run here."""
+    import tempfile
+    try:
+        exe = os.path.join(tempfile.mkdtemp(prefix="vpl_lat_"), "latency_check")
+        libdir = os.path.join(ROOT, "vplines-slam_amd")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "native", "latency_check.cpp"),
+                               "-L", libdir, "-lvplines_hip", "-Wl,-rpath," + libdir, "-o", exe], stderr=subprocess.DEVNULL)
+        return json.loads(subprocess.check_output([exe], text=True, timeout=300))
+    except Exception as e:      # reported, not hidden
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -562,6 +577,10 @@ def main():
                     out["config4"]["cpu_baseline"] = frontend_cpu_baseline(frames, cpu_share())
             except Exception as e:   # the headline line must survive a front-end failure; it is reported, not hidden
                 out["config4"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_extras:
+        lat = c_abi_latency()
+        out["c_abi_latency"] = lat
+        out["latency_1w_ms"] = lat.get("nW1", {}).get("total_ms") if isinstance(lat, dict) else None
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

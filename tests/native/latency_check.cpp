@@ -1,0 +1,109 @@
+// Latency of the drop-in call through the C ABI from C++ (no Python in the loop): what a maintainer who replaces the body of
+// Estimator::optimizationwithLine() (estimator.cpp:1043-1453) with vpl_ba_solve_windows() pays per call, for 1, 8 and 64
+// windows of the benchmark shape (11 frames, 200 points + 80 lines + VP observations, prior of the previous solve).
+// Prints one JSON object: median wall-clock milliseconds of upload / solve (+ synchronize) / download and of the whole
+// call.  Built and run by tests/test_gpu_latency.py and by bench.py.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "vplines_ba.h"
+#include "../../vplines-slam_amd/workload/synth.cpp"   // the synthetic generator (host only, no dependencies)
+
+struct Win {
+  vpl_window w;
+  std::vector<int> ps, pn, ls, ln;
+  std::vector<double> pobs, invd, lobs, lplk, imu, acc0, gyr0;
+};
+
+static void make_window(Win& W, uint64_t seed, double t0, const vplw_config& cfg) {
+  const int P = cfg.n_points, L = cfg.n_lines, TL = cfg.track_len, ns = cfg.imu_rate_div;
+  W.ps.assign(P, 0); W.pn.assign(P, 0); W.ls.assign(L, 0); W.ln.assign(L, 0);
+  W.pobs.assign((size_t)P * TL * 3, 0); W.invd.assign(P, 0); W.lobs.assign((size_t)L * TL * 8, 0); W.lplk.assign((size_t)L * 6, 0);
+  W.imu.assign((size_t)11 * ns * 7, 0); W.acc0.assign(33, 0); W.gyr0.assign(33, 0);
+  std::memset(&W.w, 0, sizeof(W.w));
+  double pt[77], st[99];
+  vplw_generate(seed, &cfg, t0, &W.w.pose[0][0], &W.w.speed_bias[0][0], W.w.ex_pose, pt, st, W.ps.data(), W.pn.data(), W.pobs.data(),
+                W.invd.data(), W.ls.data(), W.ln.data(), W.lobs.data(), W.lplk.data(), W.imu.data(), W.acc0.data(), W.gyr0.data());
+  W.w.n_points = P; W.w.point_start = W.ps.data(); W.w.point_nobs = W.pn.data(); W.w.point_obs = W.pobs.data(); W.w.inv_depth = W.invd.data();
+  W.w.n_lines = L; W.w.line_start = W.ls.data(); W.w.line_nobs = W.ln.data(); W.w.line_obs = W.lobs.data(); W.w.line_plk = W.lplk.data();
+}
+
+static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
+using clk = std::chrono::steady_clock;
+static double ms(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+int main() {
+  vplw_config cfg;
+  vplw_default_config(&cfg, 200, 80, 1);
+  vpl_ba_options opt;
+  vpl_ba_default_options(&opt);
+  const int sizes[3] = {1, 8, 64};
+  std::printf("{");
+  for (int si = 0; si < 3; ++si) {
+    const int nW = sizes[si];
+    vpl_ctx* ctx = nullptr;
+    if (vpl_ctx_create(&ctx, 0, nW, cfg.n_points, cfg.n_points * cfg.track_len, cfg.n_lines, cfg.n_lines * cfg.track_len) != VPL_OK) {
+      std::fprintf(stderr, "vpl_ctx_create failed\n");
+      return 2;
+    }
+    // window A (no prior) -> prior -> window B one keyframe later: B with its prior is what is timed
+    std::vector<Win> A(nW), Bw(nW);
+    for (int i = 0; i < nW; ++i) {
+      make_window(A[i], 0x5EED0000ull + (3ull << 20) + 9000 + 2 * i, 0.61 * i, cfg);
+      make_window(Bw[i], 0x5EED0000ull + (3ull << 20) + 9001 + 2 * i, 0.61 * i + cfg.kf_dt, cfg);
+    }
+    {   // IntegrationBase of all 2 nW x 10 intervals on the device
+      const int n = 2 * nW * 10, ns = cfg.imu_rate_div;
+      std::vector<int> off(n), cnt(n, ns);
+      std::vector<double> smp((size_t)n * ns * 7), a0(n * 3), g0(n * 3), ba(n * 3), bg(n * 3);
+      std::vector<vpl_preintegration> pre(n);
+      for (int i = 0; i < 2 * nW; ++i) {
+        Win& W = i < nW ? A[i] : Bw[i - nW];
+        for (int j = 1; j < 11; ++j) {
+          const int q = i * 10 + j - 1;
+          off[q] = q * ns;
+          std::memcpy(&smp[(size_t)q * ns * 7], &W.imu[(size_t)j * ns * 7], sizeof(double) * ns * 7);
+          for (int k = 0; k < 3; ++k) { a0[q * 3 + k] = W.acc0[j * 3 + k]; g0[q * 3 + k] = W.gyr0[j * 3 + k];
+                                        ba[q * 3 + k] = W.w.speed_bias[j][3 + k]; bg[q * 3 + k] = W.w.speed_bias[j][6 + k]; }
+        }
+      }
+      if (vpl_preintegrate_batch(ctx, n, off.data(), cnt.data(), smp.data(), a0.data(), g0.data(), ba.data(), bg.data(), &opt, pre.data()) != VPL_OK) return 3;
+      for (int i = 0; i < 2 * nW; ++i) {
+        Win& W = i < nW ? A[i] : Bw[i - nW];
+        for (int j = 1; j < 11; ++j) W.w.preint[j] = pre[i * 10 + j - 1];
+      }
+    }
+    std::vector<vpl_window> wa(nW), wb(nW);
+    std::vector<vpl_prior> priorA(nW), priorOut(nW);
+    std::vector<vpl_solve_report> rep(nW);
+    for (int i = 0; i < nW; ++i) wa[i] = A[i].w;
+    if (vpl_ba_solve_windows(ctx, nW, wa.data(), &opt, priorA.data(), rep.data()) != VPL_OK) return 4;
+    std::vector<double> t_up, t_solve, t_down, t_all;
+    std::vector<std::vector<double>> invd0(nW), plk0(nW);
+    for (int i = 0; i < nW; ++i) { invd0[i] = Bw[i].invd; plk0[i] = Bw[i].lplk; }
+    for (int r = 0; r < 23; ++r) {
+      for (int i = 0; i < nW; ++i) {       // fresh inputs (results come back in place)
+        Bw[i].invd = invd0[i]; Bw[i].lplk = plk0[i];
+        wb[i] = Bw[i].w;
+        wb[i].inv_depth = Bw[i].invd.data(); wb[i].line_plk = Bw[i].lplk.data();
+        wb[i].has_prior = 1; wb[i].prior = &priorA[i];
+      }
+      const auto t0 = clk::now();
+      if (vpl_ba_upload(ctx, nW, wb.data(), &opt) != VPL_OK) return 5;
+      const auto t1 = clk::now();
+      if (vpl_ba_solve(ctx) != VPL_OK || vpl_ctx_synchronize(ctx) != VPL_OK) return 6;
+      const auto t2 = clk::now();
+      if (vpl_ba_download(ctx, nW, wb.data(), priorOut.data(), rep.data()) != VPL_OK) return 7;
+      const auto t3 = clk::now();
+      if (r >= 3) { t_up.push_back(ms(t0, t1)); t_solve.push_back(ms(t1, t2)); t_down.push_back(ms(t2, t3)); t_all.push_back(ms(t0, t3)); }
+    }
+    std::printf("%s\"nW%d\": {\"upload_ms\": %.4f, \"solve_ms\": %.4f, \"download_ms\": %.4f, \"total_ms\": %.4f, \"iterations\": %d, \"prior_n\": %d}",
+                si ? ", " : "", nW, med(t_up), med(t_solve), med(t_down), med(t_all), rep[0].iterations, rep[0].prior_n);
+    vpl_ctx_destroy(ctx);
+  }
+  std::printf("}\n");
+  return 0;
+}
