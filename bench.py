@@ -424,7 +424,11 @@ def main():
     # results: one all-gather of the per-window states, parity of the gathered set against the oracle on rank 0
     _, reports = ctx.download()
     n_local = hi - lo
-    gathered = v.shard.gather_states(dist, v.shard.pack_states(strong.B), total, dev)
+    # the block's states are packed on the device and gathered device to device (RCCL); only the sampled rows come to the host
+    gathered_dev = v.shard.gather_states_device(dist, ctx, n_local, total, dev)
+    gathered = gathered_dev.cpu().numpy()
+    host_pack = v.shard.pack_states(strong.B)
+    assert np.array_equal(gathered[lo:hi], host_pack), "device-packed states differ from the downloaded ones"
     stats = step_stats(reports, n_local)
 
     # ---- the same batch with the host round trip (upload of the caller's windows + solve + download): never `value` ----

@@ -229,6 +229,10 @@ int vpl_ba_reset_state(vpl_ctx* ctx);     /* restore the uploaded initial states
 int vpl_ba_download(vpl_ctx* ctx, int n_windows, vpl_window* windows, vpl_prior* priors_out,
                     vpl_solve_report* reports);
 int vpl_ctx_synchronize(vpl_ctx* ctx);
+/* States of the solved batch into a caller-owned DEVICE buffer, [n_windows][183] doubles per window: pose[11][7],
+ * speed_bias[11][9], ex_pose[7] -- after double2vector2.  Asynchronous on the context's stream.  This is what a multi-GPU
+ * run hands to its collective (RCCL all-gather of the batch's results) without a host staging copy. */
+int vpl_ba_pack_states_device(vpl_ctx* ctx, int n_windows, void* d_states);
 
 /* Convenience: upload + solve + synchronize + download. */
 int vpl_ba_solve_windows(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt,

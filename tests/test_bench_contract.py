@@ -53,3 +53,14 @@ def test_bench_prints_one_contract_line():
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
     # the GPU path is checked against the oracle inside the run as well
     assert d["parity"]["max_dp_m"] < 1e-4 and d["parity"]["max_dr_rad"] < 1e-6
+
+
+def test_bench_single_rank_rccl_path():
+    """VPL_FORCE_DIST=1: one rank, but through torch.distributed (backend nccl = RCCL): the block's states are packed on the
+    device and all-gathered device to device, the timing / parity summaries all-reduced -- the code the N > 1 launches run."""
+    env = dict(os.environ, VPL_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras",
+                          "--cpu-windows", "8"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["parity"]["max_dp_m"] < 1e-4 and d["parity"]["allreduce_max"][0] == d["parity"]["max_dp_m"]

@@ -113,3 +113,34 @@ def test_config5_block_partition_reproduces_the_batch(batch, world):
         parts.append((lo, hi))
     assert parts[0][0] == 0 and parts[-1][1] == NW
     ctx.close()
+
+
+_PACK_SCRIPT = r"""
+import sys, os
+import numpy as np
+import torch
+torch.cuda.init()                      # torch first: it brings its own HIP runtime, as in bench.py
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import vplines_slam_amd as v
+from test_gpu_solve import make_windows
+dev = torch.device("cuda", 0)
+ws, opt = make_windows(12, 60, 20, True, seed0=300)
+ctx = v.Context(device=0, max_windows=12, max_points=60, max_point_obs=360, max_lines=20, max_line_obs=120)
+ctx.solve_windows(ws, opt)
+t = v.shard.gather_states_device(None, ctx, 12, 12, dev)
+assert t.is_cuda and tuple(t.shape) == (12, v.shard.STATE_DOUBLES)
+assert np.array_equal(t.cpu().numpy(), v.shard.pack_states(ws))
+print("PACK_OK")
+"""
+
+
+def test_states_packed_on_the_device_equal_the_downloaded_ones():
+    """vpl_ba_pack_states_device + shard.gather_states_device (what bench.py hands to the RCCL all-gather): bit for bit the
+    [nW][183] table shard.pack_states builds from the downloaded windows.  Own process: torch's HIP runtime has to be
+    initialised before the library's (bench.py's order)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _PACK_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "PACK_OK" in out.stdout, out.stderr[-2000:]

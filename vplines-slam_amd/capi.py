@@ -205,6 +205,7 @@ def load_hip_library():
     lib.vpl_ba_reset_state.argtypes = [vp]
     lib.vpl_ba_download.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(Prior), C.POINTER(SolveReport)]
     lib.vpl_ctx_synchronize.argtypes = [vp]
+    lib.vpl_ba_pack_states_device.argtypes = [vp, C.c_int, vp]
     lib.vpl_ba_solve_windows.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(Prior),
                                          C.POINTER(SolveReport)]
     lib.vpl_ba_triangulate_lines.argtypes = [vp, C.c_int, C.POINTER(CWindow)]
@@ -355,6 +356,10 @@ class Context:
         self.solve()
         self.synchronize()
         return self.download()
+
+    def pack_states_device(self, n, data_ptr):
+        """vpl_ba_pack_states_device: the [n][183] states of the solved batch into a device buffer (raw pointer)"""
+        self._check(self.lib.vpl_ba_pack_states_device(self.h, n, C.c_void_p(data_ptr)), "vpl_ba_pack_states_device")
 
     def marginalize(self, windows, opt, flag):
         """vpl_ba_marginalize: (priors, m, n) of the windows' current states, no solve"""

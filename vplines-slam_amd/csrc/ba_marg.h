@@ -768,4 +768,12 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   marg_body(B, blockIdx.x, sm);
 }
 
+// Per-window states of the solved batch as one [nW][183] device array (pose 77 | speed/bias 99 | extrinsic 7): what the
+// multi-GPU run all-gathers over RCCL, packed on the device so that the collective reads HBM, not a host staging copy.
+__global__ void k_pack_states(DevBatch B, double* out) {
+  const int w = blockIdx.x;
+  for (int i = threadIdx.x; i < 183; i += blockDim.x)
+    out[(size_t)w * 183 + i] = i < 77 ? B.pose[(size_t)w * 77 + i] : (i < 176 ? B.sb[(size_t)w * 99 + (i - 77)] : B.ex[(size_t)w * 7 + (i - 176)]);
+}
+
 }  // namespace vpl

@@ -1014,6 +1014,15 @@ static int fetch_priors(vpl_ctx* c, int nW, vpl_prior* priors, std::vector<int>&
   return VPL_OK;
 }
 
+// States of the uploaded batch -> caller's DEVICE buffer [nW][183], asynchronous on the context's stream
+int vpl_ba_pack_states_device(vpl_ctx* c, int nW, void* d_states) {
+  if (!c || nW != c->nW || !d_states) return VPL_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_pack_states, dim3(nW), dim3(192), 0, c->stream, c->B, (double*)d_states);
+  HIPCHK(c, hipGetLastError());
+  return VPL_OK;
+}
+
 int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_solve_report* reports) {
   if (!c || nW != c->nW || !win) return VPL_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));

@@ -91,6 +91,30 @@ def gather_states(dist, local_states, total_windows, device=None):
     return np.concatenate([out[r, : sizes[r][1] - sizes[r][0]] for r in range(world)], axis=0)
 
 
+def gather_states_device(dist, ctx, n_local, total_windows, device):
+    """The same all-gather with the local block packed ON THE DEVICE (vpl_ba_pack_states_device) and handed to the collective
+    as a device tensor: no host staging on the way in.  Returns the gathered [total_windows, 183] DEVICE tensor (window
+    order).  dist=None: the local block alone."""
+    import torch
+    world = 1 if dist is None else dist.get_world_size()
+    rank = 0 if dist is None else dist.get_rank()
+    sizes = [split_batch(total_windows, r, world) for r in range(world)]
+    cap = max(hi - lo for lo, hi in sizes)
+    assert n_local == sizes[rank][1] - sizes[rank][0]
+    buf = torch.zeros((cap, STATE_DOUBLES), dtype=torch.float64, device=device)
+    if n_local:
+        ctx.pack_states_device(n_local, buf.data_ptr())
+        ctx.synchronize()
+    if dist is None:
+        return buf[:n_local]
+    out = torch.empty((world * cap, STATE_DOUBLES), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, buf)
+    out = out.view(world, cap, STATE_DOUBLES)
+    if all(hi - lo == cap for lo, hi in sizes):
+        return out.reshape(world * cap, STATE_DOUBLES)
+    return torch.cat([out[r, : sizes[r][1] - sizes[r][0]] for r in range(world)], dim=0)
+
+
 def reduce_max_vec(dist, values, device=None):
     """element-wise MAX over ranks of a short list of floats (parity / timing summary)"""
     import torch
