@@ -224,6 +224,11 @@ int vpl_line_orth_plus(vpl_ctx* ctx, int n, const double* x, const double* delta
  *   download: device -> host windows / priors / reports
  */
 int vpl_ba_upload(vpl_ctx* ctx, int n_windows, const vpl_window* windows, const vpl_ba_options* opt);
+/* The next windows of a sequence: as vpl_ba_upload, but window i takes the prior that the context's PREVIOUS solve left for
+ * window i (MarginalizationInfo of that solve, estimator.cpp:1229-1447 -> last_marginalization_info) -- it stays in HBM,
+ * handed from the marginalisation's output to the next solve's input on the device; windows[i].prior / has_prior are
+ * ignored.  Needs a previous solve of the same batch size with a marginalisation flag other than VPL_MARGIN_NONE. */
+int vpl_ba_upload_chained(vpl_ctx* ctx, int n_windows, const vpl_window* windows, const vpl_ba_options* opt);
 int vpl_ba_solve(vpl_ctx* ctx);           /* enqueue one batched solve of the uploaded windows */
 int vpl_ba_reset_state(vpl_ctx* ctx);     /* restore the uploaded initial states on device (for repeated timing) */
 int vpl_ba_download(vpl_ctx* ctx, int n_windows, vpl_window* windows, vpl_prior* priors_out,

@@ -119,3 +119,38 @@ def test_free_running_chains_and_the_truncation_rule(gpu_ctx):
     print("free-running chains of %d windows: device vs oracle worst dp %.3g m dr %.3g rad; oracle(relative cut) vs "
           "oracle(absolute cut) worst dp %.3g m dr %.3g rad" % (N_CHAIN, worst[0], worst[1], worst_rule[0], worst_rule[1]))
     assert worst_rule[0] > POS_TOL       # the cut is not a detail: this is what round 2's rule did to the chain
+
+
+def test_device_resident_priors_reproduce_the_host_chain(gpu_ctx):
+    """vpl_ba_upload_chained: the prior stays in HBM from one solve's marginalisation to the next solve (device to device
+    handoff), four chains of 32 windows side by side in one batch.  Every window's states are the bits the chain through
+    host-side vpl_prior structures gives, and the last prior fetched from the device equals the host chain's."""
+    opt = v.default_options()
+    cfg = v.workload.config(120, 40, True)
+    NCH = 4
+    seq = [[v.workload.generate(v.workload.seed_for(3, 7600 + 40 * c + k), cfg, 0.3 + 0.21 * c + k * cfg.kf_dt) for k in range(N_CHAIN)]
+           for c in range(NCH)]
+    o.preintegrate_windows([w for s in seq for w in s], opt)
+    # host chain: priors travel through vpl_prior structs
+    host, prior = [], [None] * NCH
+    for k in range(N_CHAIN):
+        ws = [seq[c][k].copy() for c in range(NCH)]
+        for c in range(NCH):
+            ws[c].prior = prior[c]
+        pri, _ = gpu_ctx.solve_windows(ws, opt)
+        prior = [_copy_prior(pri[c]) for c in range(NCH)]
+        host.append(ws)
+    # device chain: the same context type, priors never leave the device
+    ctx = v.Context(device=0, max_windows=NCH, max_points=120, max_point_obs=720, max_lines=40, max_line_obs=240)
+    for k in range(N_CHAIN):
+        ws = [seq[c][k].copy() for c in range(NCH)]
+        ctx.upload(ws, opt, chained=k > 0)
+        ctx.solve()
+        ctx.synchronize()
+        pri, rep = ctx.download()
+        for c in range(NCH):
+            assert np.array_equal(ws[c].pose, host[k][c].pose) and np.array_equal(ws[c].speed_bias, host[k][c].speed_bias), (k, c)
+            assert np.array_equal(ws[c].inv_depth, host[k][c].inv_depth) and np.array_equal(ws[c].line_plk, host[k][c].line_plk)
+    for c in range(NCH):
+        assert pri[c].n == prior[c].n and np.array_equal(pri[c].J(), prior[c].J()) and np.array_equal(pri[c].r(), prior[c].r())
+    ctx.close()

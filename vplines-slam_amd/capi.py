@@ -202,6 +202,7 @@ def load_hip_library():
     lib.vpl_line_orth_plus.argtypes = [vp, C.c_int, _dp, _dp, _dp]
     lib.vpl_ba_upload.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions)]
     lib.vpl_ba_solve.argtypes = [vp]
+    lib.vpl_ba_upload_chained.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions)]
     lib.vpl_ba_reset_state.argtypes = [vp]
     lib.vpl_ba_download.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(Prior), C.POINTER(SolveReport)]
     lib.vpl_ctx_synchronize.argtypes = [vp]
@@ -327,14 +328,19 @@ class Context:
         return out
 
     # ---- window solve ---------------------------------------------------------------
-    def upload(self, windows, opt):
+    def upload(self, windows, opt, chained=False):
+        """chained=True: vpl_ba_upload_chained -- every window takes the prior the previous solve of this context left for it
+        (device resident), the Windows' own .prior is ignored"""
         n = len(windows)
         cw = (CWindow * n)()
         for i, w in enumerate(windows):
             w.to_c(cw[i])
         self._cw = cw
         self._windows = windows
-        self._check(self.lib.vpl_ba_upload(self.h, n, cw, C.byref(opt)), "vpl_ba_upload")
+        if chained:
+            self._check(self.lib.vpl_ba_upload_chained(self.h, n, cw, C.byref(opt)), "vpl_ba_upload_chained")
+        else:
+            self._check(self.lib.vpl_ba_upload(self.h, n, cw, C.byref(opt)), "vpl_ba_upload")
 
     def solve(self):
         self._check(self.lib.vpl_ba_solve(self.h), "vpl_ba_solve")

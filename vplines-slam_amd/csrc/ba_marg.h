@@ -768,6 +768,21 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
   marg_body(B, blockIdx.x, sm);
 }
 
+// Prior handoff on the device (vpl_ba_upload_chained): the prior the previous solve's marginalisation left in mg_* becomes the
+// prior of the window that is about to be solved -- J0 (n x n, re-strided from MAXKEEP^2 to the batch's prS), r0, x0.  The
+// block tables travel through the host (a few ints per window; upload builds its layout tables from them).
+// keep[w] != 0: the window keeps the prior it already has in pr_* (MARGIN_SECOND_NEW left it untouched, estimator.cpp:1385).
+__global__ void k_prior_handoff(DevBatch B, const int* keep) {
+  const int w = blockIdx.x;
+  if (keep[w]) return;
+  const int n = B.mg_n[w];
+  const double* J = B.mg_J0 + (size_t)w * MAXKEEP * MAXKEEP;
+  double* Jo = B.pr_J0 + (size_t)w * B.prS;
+  for (int i = threadIdx.x; i < n * n; i += blockDim.x) Jo[i] = J[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) B.pr_r0[(size_t)w * MAXPN + i] = B.mg_r0[(size_t)w * MAXKEEP + i];
+  for (int i = threadIdx.x; i < MAXPB * 9; i += blockDim.x) B.pr_x0[(size_t)w * MAXPB * 9 + i] = B.mg_x0[(size_t)w * MAXPB * 9 + i];
+}
+
 // Per-window states of the solved batch as one [nW][183] device array (pose 77 | speed/bias 99 | extrinsic 7): what the
 // multi-GPU run all-gathers over RCCL, packed on the device so that the collective reads HBM, not a host staging copy.
 __global__ void k_pack_states(DevBatch B, double* out) {

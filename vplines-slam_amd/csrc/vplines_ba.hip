@@ -421,7 +421,7 @@ int vpl_line_orth_plus(vpl_ctx* c, int n, const double* x, const double* delta, 
 }
 
 // ---- window batch: upload / solve / download ------------------------------------------------------------
-static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt, bool all_lines) {
+static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt, bool all_lines, bool chained = false) {
   if (!c || !win || !opt || nW < 1) return VPL_E_INVALID;
   if (nW > c->maxW) return fail(c, VPL_E_CAPACITY, "more windows than max_windows");
   if (opt->marginalization_flag != VPL_MARGIN_OLD && opt->marginalization_flag != VPL_MARGIN_SECOND_NEW &&
@@ -461,6 +461,41 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   std::vector<double> pr_x0(W * MAXPB * 9, 0.0), pr_r0(W * MAXPN, 0.0);
   std::vector<int> mg_n(W, 0), mg_nb(W, 0), mg_kind(W * MAXPB, 0), mg_frame(W * MAXPB, 0), mg_idx(W * MAXPB, 0),
       mg_cam(W * MAXPB, 0);
+  // chained mode: window w takes the prior the context's previous solve left for window w (device resident); only its block
+  // table comes through the host
+  struct HostTab { int n = 0, nb = 0, kind[MAXPB], frame[MAXPB], idx[MAXPB]; };
+  std::vector<HostTab> ctab;
+  std::vector<int> keep_prior(W, 0);
+  if (chained) {
+    if (nW != c->nW || c->opt.marginalization_flag == VPL_MARGIN_NONE)
+      return fail(c, VPL_E_INVALID, "upload_chained: needs a previous solve of the same batch size with a marginalisation");
+    ctab.resize(W);
+    std::vector<int> t_n(W), t_nb(W), t_kind(W * MAXPB), t_frame(W * MAXPB), t_idx(W * MAXPB), p_n(W), p_nb(W), p_kind(W * MAXPB),
+        p_frame(W * MAXPB), p_idx(W * MAXPB);
+    HIPCHK(c, hipMemcpyAsync(t_n.data(), B.mg_n, W * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t_nb.data(), B.mg_nb, W * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t_kind.data(), B.mg_kind, W * MAXPB * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t_frame.data(), B.mg_frame, W * MAXPB * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t_idx.data(), B.mg_idx, W * MAXPB * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p_n.data(), B.pr_n, W * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p_nb.data(), B.pr_nb, W * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p_kind.data(), B.pr_kind, W * MAXPB * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p_frame.data(), B.pr_frame, W * MAXPB * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p_idx.data(), B.pr_idx, W * MAXPB * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t w = 0; w < W; ++w) {
+      const bool keep = c->h_passthrough[w] >= 0;      // MARGIN_SECOND_NEW left this window's prior as it was
+      keep_prior[w] = keep ? 1 : 0;
+      HostTab& T = ctab[w];
+      T.n = keep ? p_n[w] : t_n[w];
+      T.nb = keep ? p_nb[w] : t_nb[w];
+      for (int b = 0; b < T.nb; ++b) {
+        T.kind[b] = (keep ? p_kind : t_kind)[w * MAXPB + b];
+        T.frame[b] = (keep ? p_frame : t_frame)[w * MAXPB + b];
+        T.idx[b] = (keep ? p_idx : t_idx)[w * MAXPB + b];
+      }
+    }
+  }
   c->h_mg_m.assign(W, 0);
   c->maxPriorN = 0;
   c->h_passthrough.assign(W, -1);
@@ -472,8 +507,10 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
 
   {   // stride of the per-window prior matrices: the largest prior of the batch
     int nmax = 1;
-    for (size_t w = 0; w < W; ++w)
-      if (win[w].has_prior && win[w].prior) nmax = std::max(nmax, win[w].prior->n);
+    for (size_t w = 0; w < W; ++w) {
+      if (chained) nmax = std::max(nmax, ctab[w].n);
+      else if (win[w].has_prior && win[w].prior) nmax = std::max(nmax, win[w].prior->n);
+    }
     if (nmax > MAXPN) return fail(c, VPL_E_CAPACITY, "prior larger than MAXPN");
     B.prS = (nmax * nmax + 7) & ~7;
   }
@@ -589,7 +626,15 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     c->h_nL[w] = nl;
     nLO[w] = off;
     for (int j = 0; j < NF; ++j) to_dev_preint(v.preint[j], pre[w * NF + j]);
-    if (v.has_prior && v.prior) {
+    if (chained) {
+      const HostTab& T = ctab[w];
+      pr_n[w] = T.n; pr_nb[w] = T.nb;
+      c->maxPriorN = std::max(c->maxPriorN, T.n);
+      for (int b = 0; b < T.nb; ++b) {
+        pr_kind[w * MAXPB + b] = T.kind[b]; pr_frame[w * MAXPB + b] = T.frame[b]; pr_idx[w * MAXPB + b] = T.idx[b];
+        if (T.kind[b] == 1 && T.frame[b] != 0) path[w] = 1;
+      }
+    } else if (v.has_prior && v.prior) {
       const vpl_prior& pr = *v.prior;
       if (pr.n < 0 || pr.n > MAXPN || pr.n_blocks < 0 || pr.n_blocks > MAXPB) return fail(c, VPL_E_INVALID, "bad prior");
       pr_n[w] = pr.n; pr_nb[w] = pr.n_blocks;
@@ -612,9 +657,9 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     // kept blocks of the next prior in the canonical (address) order of the reference's para_* layout
     {
       int* kd = &mg_kind[w * MAXPB]; int* fr = &mg_frame[w * MAXPB]; int* ix = &mg_idx[w * MAXPB]; int* cm = &mg_cam[w * MAXPB];
-      const int pnb = (v.has_prior && v.prior) ? v.prior->n_blocks : 0;
-      const int* pk = pnb ? v.prior->block_kind : nullptr;
-      const int* pf = pnb ? v.prior->block_frame : nullptr;
+      const int pnb = chained ? ctab[w].nb : ((v.has_prior && v.prior) ? v.prior->n_blocks : 0);
+      const int* pk = pnb ? (chained ? ctab[w].kind : v.prior->block_kind) : nullptr;
+      const int* pf = pnb ? (chained ? ctab[w].frame : v.prior->block_frame) : nullptr;
       c->h_passthrough[w] = -1;
       if (opt->marginalization_flag == VPL_MARGIN_OLD) {
         KeepSrc S;
@@ -631,7 +676,14 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
         if (rc == 1) { c->h_mg_m[w] = 6; c->any_second_new = true; }
         else if (pnb) {   // the reference leaves last_marginalization_info as it is (estimator.cpp:1385)
           c->h_passthrough[w] = (int)c->h_pass_priors.size();
-          c->h_pass_priors.push_back(*v.prior);
+          if (chained) {    // the prior lives on the device only: the pass-through entry carries its table (download refetches the rest)
+            vpl_prior hp;
+            std::memset(&hp, 0, sizeof(int) * (2 + 3 * VPL_MAX_PRIOR_BLOCKS));
+            hp.n = -1;      // marker: not available on the host
+            c->h_pass_priors.push_back(hp);
+          } else {
+            c->h_pass_priors.push_back(*v.prior);
+          }
         }
       }
       if (mg_n[w] > MAXKEEP) return fail(c, VPL_E_CAPACITY, "marginalisation keeps more than MAXKEEP dims");
@@ -672,8 +724,17 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.ll_tab, ll_tab)); HIPCHK(c, up(c, B.ll_np, ll_np));
   HIPCHK(c, up(c, B.pre, pre));
   HIPCHK(c, up(c, B.pr_n, pr_n)); HIPCHK(c, up(c, B.pr_nb, pr_nb)); HIPCHK(c, up(c, B.pr_kind, pr_kind));
-  HIPCHK(c, up(c, B.pr_frame, pr_frame)); HIPCHK(c, up(c, B.pr_idx, pr_idx)); HIPCHK(c, up(c, B.pr_x0, pr_x0));
-  HIPCHK(c, up(c, B.pr_r0, pr_r0));
+  HIPCHK(c, up(c, B.pr_frame, pr_frame)); HIPCHK(c, up(c, B.pr_idx, pr_idx));
+  if (!chained) { HIPCHK(c, up(c, B.pr_x0, pr_x0)); HIPCHK(c, up(c, B.pr_r0, pr_r0)); }
+  else {
+    // values of the priors: device to device, before the next solve overwrites mg_*
+    DevBuf dkeep;
+    HIPCHK(c, dkeep.alloc(W * 4));
+    HIPCHK(c, hipMemcpyAsync(dkeep.p, keep_prior.data(), W * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_prior_handoff, dim3(nW), dim3(256), 0, c->stream, B, (const int*)dkeep.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   HIPCHK(c, up(c, B.mg_n, mg_n)); HIPCHK(c, up(c, B.mg_nb, mg_nb)); HIPCHK(c, up(c, B.mg_kind, mg_kind));
   HIPCHK(c, up(c, B.mg_frame, mg_frame)); HIPCHK(c, up(c, B.mg_idx, mg_idx)); HIPCHK(c, up(c, B.mg_cam, mg_cam));
   HIPCHK(c, up(c, B.mg_m, c->h_mg_m));
@@ -697,6 +758,9 @@ int vpl_ba_reset_state(vpl_ctx* c) {
 
 int vpl_ba_upload(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt) {
   return upload_impl(c, nW, win, opt, false);
+}
+int vpl_ba_upload_chained(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt) {
+  return upload_impl(c, nW, win, opt, false, true);
 }
 
 // FeatureManager::triangulateLine for a batch: upload (every line), k_triangulate, flags + Pluecker vectors back
@@ -994,6 +1058,18 @@ static int fetch_priors(vpl_ctx* c, int nW, vpl_prior* priors, std::vector<int>&
     mn[2 * w] = mg_m[w];
     if (c->h_passthrough[w] >= 0) {   // MARGIN_SECOND_NEW without pose WINDOW_SIZE-1 in the prior: the prior stays (estimator.cpp:1385)
       priors[w] = c->h_pass_priors[c->h_passthrough[w]];
+      if (priors[w].n < 0) {          // chained upload: the untouched prior lives on the device only
+        vpl_prior& p = priors[w];
+        std::memset(&p, 0, sizeof(int) * (2 + 3 * VPL_MAX_PRIOR_BLOCKS));
+        HIPCHK(c, hipMemcpy(&p.n, B.pr_n + w, 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&p.n_blocks, B.pr_nb + w, 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(p.block_kind, B.pr_kind + w * MAXPB, MAXPB * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(p.block_frame, B.pr_frame + w * MAXPB, MAXPB * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(p.block_idx, B.pr_idx + w * MAXPB, MAXPB * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(p.x0, B.pr_x0 + w * MAXPB * 9, MAXPB * 9 * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(p.J0, B.pr_J0 + w * (size_t)B.prS, (size_t)p.n * p.n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(p.r0, B.pr_r0 + w * MAXPN, (size_t)p.n * 8, hipMemcpyDeviceToHost));
+      }
       mn[2 * w + 1] = priors[w].n;
       continue;
     }
