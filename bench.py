@@ -144,6 +144,30 @@ class Batch:
         self.ctx.solve()
 
 
+class MultiBatch:
+    """The same batch cut into `parts` blocks, each on a context and a HIP stream of its own: the kernels of the blocks run side
+    by side, so that the low-occupancy launches of one block (iterations in which few of its windows linearise and factor)
+    overlap with the other blocks' work."""
+
+    def __init__(self, torch, v, dev, ids, cfg, opt, config_id, parts, new_ctx_on):
+        ids = list(ids)
+        self.parts = []
+        n = len(ids)
+        for p in range(parts):
+            lo, hi = n * p // parts, n * (p + 1) // parts
+            st = torch.cuda.Stream(dev)
+            ctx = new_ctx_on(hi - lo, st)
+            self.parts.append((Batch(v, ctx, ids[lo:hi], cfg, opt, config_id), st))
+
+    def step(self):
+        for b, _ in self.parts:
+            b.step()
+
+    def close(self):
+        for b, _ in self.parts:
+            b.ctx.close()
+
+
 def timed(torch, dist, dev, batch, steps, warmup, v):
     for _ in range(warmup):
         batch.step()
@@ -371,6 +395,7 @@ def main():
     ap.add_argument("--cpu-windows", type=int, default=64, help="oracle sample size for parity + CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-2 / config-4 / weak-scaling extra keys")
+    ap.add_argument("--streams", type=int, default=1, help="experiment: cut the rank's block into this many blocks on streams of their own")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -420,6 +445,17 @@ def main():
     strong = Batch(v, ctx, range(lo, hi), cfg, opt, config_id)
     elapsed = timed(torch, dist, dev, strong, args.steps, args.warmup, v)
     value = total * args.steps / elapsed
+    multi = None
+    if args.streams > 1:
+        def new_ctx_on(nw, st):
+            c = v.Context(device=local_rank, max_windows=max(nw, 1), max_points=max(P, 1), max_point_obs=max(P * TL, 1),
+                          max_lines=max(L, 1), max_line_obs=max(L * TL, 1))
+            c.set_stream(st.cuda_stream)
+            return c
+        mb = MultiBatch(torch, v, dev, range(lo, hi), cfg, opt, config_id, args.streams, new_ctx_on)
+        em = timed(torch, dist, dev, mb, args.steps, args.warmup, v)
+        multi = {"streams": args.streams, "value": total * args.steps / em, "ms_per_step": 1e3 * em / args.steps}
+        mb.close()
 
     # results: one all-gather of the per-window states, parity of the gathered set against the oracle on rank 0
     _, reports = ctx.download()
@@ -473,6 +509,7 @@ def main():
             "device_ms_per_step": sum(kms.values()),
             "launches": [{"kernel": n, "ms": round(ms, 5), "active": [round(a, 1) for a in act]} for n, ms, act in prof],
             "setup_s": strong.setup_s,
+            "multi_stream": multi,
             "host_round_trip": None if pcie is None else {
                 "value": pcie, "unit": "solves/s",
                 "what": "vpl_ba_solve_windows on host windows: pack + PCIe upload + solve + download + unpack, single host thread"},

@@ -340,18 +340,10 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
 #pragma unroll
         for (int t = 0; t < NTC; ++t)
 #pragma unroll
-#ifdef VPL_X_NOLOAD
-          for (int qd = 0; qd < 4; ++qd) raw[t][qd] = 1e-3 * (qd + t + id);
-#else
           for (int qd = 0; qd < 4; ++qd) raw[t][qd] = Wr[(unsigned)(qd * WS + cl[t])];
-#endif
       } else {
 #pragma unroll
-#ifdef VPL_X_NOLOAD
-        for (int t = 0; t < NTC; ++t) raw[t][0] = 1e-3 * (t + id);
-#else
         for (int t = 0; t < NTC; ++t) raw[t][0] = Wp[(unsigned)(id * WS + cl[t])];
-#endif
 #pragma unroll
         for (int t = 0; t < NTC; ++t)       // (every element defined on both paths)
 #pragma unroll
@@ -404,9 +396,7 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
       int code[NLT * 4];
 #pragma unroll
       for (int i = 0; i < NLT * 4; ++i) code[i] = ftab[i * 64 + lane];
-#ifndef VPL_X_NOTICKET
       lds_ticket_wait(&tick[0], seq);
-#endif
 #ifdef VPL_STAMPS
       st_wait += __builtin_readcyclecounter() - tf0;
 #endif
@@ -462,11 +452,7 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
 #pragma unroll
             for (int ta = 0; ta < NTC; ++ta)
 #pragma unroll
-#ifdef VPL_X_NOMFMA
-              for (int tb = 0; tb <= ta; ++tb, ++t) acc[t].x += x[ta][a] * x[tb][a];
-#else
               for (int tb = 0; tb <= ta; ++tb, ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ta][a], x[tb][a], acc[t], 0, 0, 0);
-#endif
           }
         }
 #ifdef VPL_STAMPS
