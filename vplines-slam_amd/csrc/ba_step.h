@@ -181,27 +181,29 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
     }
   }
   __syncthreads();   // uc, kP, kL complete
-  // camera part of the Cauchy denominator u^T Hcc u: one coalesced pass over the packed triangle (eight loads in flight)
+  // camera part of the Cauchy denominator u^T Hcc u over the entries the factors can fill (B.nz_tab: 6147 of the 14706 of the
+  // packed triangle; everything else is a structural zero on this path), 12 loads in flight per thread
   double qq = 0.0;
   {
-    // (r, c) of this thread's entries without a root per entry: the first one is decoded, the following ones step T entries on
-    int r, c;
-    tri_decode(tid, r, c);
+    constexpr int NB = (NZ_N + SCHUR_THREADS - 1) / SCHUR_THREADS;     // 25 at 256 threads
+    constexpr int HALF = (NB + 1) / 2;
 #pragma unroll 1
-    for (int base = 0; base < NCP; base += 16 * T) {
-      double hh[16];
+    for (int h0 = 0; h0 < NB; h0 += HALF) {
+      int code[HALF];
+      double hh[HALF];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int idx = base + u * T + tid;
-        hh[u] = idx < NCP ? Hcc[idx] : 0.0;
+      for (int u = 0; u < HALF; ++u) {
+        const int e = (h0 + u) * T + tid;
+        code[u] = (h0 + u < NB && e < NZ_N) ? B.nz_tab[e] : -1;
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int idx = base + u * T + tid;
-        if (idx < NCP) qq += (r == c ? 1.0 : 2.0) * uc[r] * hh[u] * uc[c];
-        c += T;
-        while (c > r) { c -= r + 1; ++r; }
-      }
+      for (int u = 0; u < HALF; ++u) hh[u] = code[u] >= 0 ? Hcc[code[u] & 0x3fff] : 0.0;
+#pragma unroll
+      for (int u = 0; u < HALF; ++u)
+        if (code[u] >= 0) {
+          const int r = (code[u] >> 14) & 255, c = code[u] >> 22;
+          qq += (r == c ? 1.0 : 2.0) * uc[r] * hh[u] * uc[c];
+        }
     }
   }
   VPL_STAMP(B, w, 1);
@@ -587,6 +589,7 @@ __device__ __forceinline__ void chol_body(const DevBatch& B, const int w, double
   double* red = Linv + 256;              // 24
   int* flag = (int*)(red + 24);          // [0] failure, [1], [2] blocks finished by chain A / B
   int* cdmap = flag + 8;                 // 2 x 64: dense index of the lanes of the chains' X rows
+  double* rsL = (double*)(cdmap + 128);  // 2 x 5 x 9: 1 / L_kk of the chains' pivot blocks (for the back-substitution)
 
   const size_t fb = (size_t)w * B.nfull;
   const double* gscale = B.scale + fb;
@@ -678,6 +681,7 @@ __device__ __forceinline__ void chol_body(const DevBatch& B, const int w, double
           double rs = __builtin_amdgcn_rsq(piv[k]);
           rs = rs * fma(-0.5 * piv[k] * rs, rs, 1.5);
           rs = rs * fma(-0.5 * piv[k] * rs, rs, 1.5);
+          if (lane == 0) rsL[(5 * ch + b) * 9 + k] = rs;
           const double xv = R[k] * rs;
           Xs(b, k) = col >= 0 ? xv : 0.0;
           Xout[(9 * b + k) * XLD + lane] = dcol ? xv : 0.0;
@@ -798,17 +802,21 @@ __device__ __forceinline__ void chol_body(const DevBatch& B, const int w, double
   }
   __syncthreads();
   VPL_STAMP(B, w, 15);
-  // (iv) minus the chains' products, chain A's first (fixed order of the two terms per entry)
+  // (iv) minus the chains' products.  An entry gets a term from both chains only when both of its dims are met by both:
+  // pose 5 (vis 30..35), speed/bias 5 (81..89), the rhs (90).  Pass 0: chain A's partner subtracts everything it has, chain B's
+  // partner everything outside that overlap -- side by side, on different entries; pass 1: chain B's partner subtracts its
+  // overlap entries.  Every entry sees its terms in the order A, B.
+  auto in_both = [](int d) { return (d >= 30 && d < 36) || d >= 81; };
 #pragma unroll 1
-  for (int ch = 0; ch < 2; ++ch) {
-    if (wv == 2 + ch) {
+  for (int pass = 0; pass < 2; ++pass) {
+    if ((wv == 2 && pass == 0) || wv == 3) {
+      const int ch = wv - 2;
       const int m = lane & 15, kk = lane >> 4;
       int t = 0;
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
         for (int tb = 0; tb <= ta; ++tb, ++t) {
-          const double vals[4] = {U[4 * t], U[4 * t + 1], U[4 * t + 2], U[4 * t + 3]};
           const int j = 16 * tb + m, dj = cdmap[64 * ch + j];
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
@@ -816,10 +824,12 @@ __device__ __forceinline__ void chol_body(const DevBatch& B, const int w, double
             if (i < j) continue;
             const int di = cdmap[64 * ch + i];
             if (di < 0 || dj < 0) continue;
+            if (ch == 1 && (in_both(di) && in_both(dj)) != (pass == 1)) continue;
             const int r = di > dj ? di : dj, c = di > dj ? dj : di;
             if (c >= DN) continue;                       // (rhs, rhs) is not part of the system
-            S[tix(r, c)] -= vals[v];
-            if ((r >> 4) == (c >> 4) && r != c) S[tix(c, r)] -= vals[v];
+            const double val = U[4 * t + v];
+            S[tix(r, c)] -= val;
+            if ((r >> 4) == (c >> 4) && r != c) S[tix(c, r)] -= val;
           }
         }
     }
@@ -970,7 +980,7 @@ __device__ __forceinline__ void chol_body(const DevBatch& B, const int w, double
         // L^T y = t with L^T[k][j] = X[k][pivot lane j]
 #pragma unroll
         for (int j = 8; j >= 0; --j) {
-          const double yj = t[j] / readlane_f64(Xs(b, j), ds + j);
+          const double yj = t[j] * rsL[(5 * ch + b) * 9 + j];
 #pragma unroll
           for (int k = 0; k < j; ++k) t[k] -= readlane_f64(Xs(b, k), ds + j) * yj;
           t[j] = yj;
@@ -1011,7 +1021,7 @@ __global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol(DevBatch B) {
   extern __shared__ double sm[];
   chol_body(B, ordered_window(B), sm);
 }
-constexpr size_t CHOL_SMEM = (size_t)(((XROWS_A + XROWS_B) * XLD > DNAP ? (XROWS_A + XROWS_B) * XLD : DNAP) + 3 * 176 + 2 * 96 + 256 + 24) * sizeof(double) + (8 + 128) * sizeof(int);
+constexpr size_t CHOL_SMEM = (size_t)(((XROWS_A + XROWS_B) * XLD > DNAP ? (XROWS_A + XROWS_B) * XLD : DNAP) + 3 * 176 + 2 * 96 + 256 + 24 + 96) * sizeof(double) + (8 + 128) * sizeof(int);
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_back : landmark back-substitution y_l = A_l^-1 S_l (g_l - W_l S_c y_c), then DoglegStrategy::ComputeTraditionalDoglegStep,

@@ -25,6 +25,8 @@ constexpr int MAXPB = 23;              // prior blocks
 constexpr int MAXPN = 171;             // prior dim
 constexpr int ACT_SLOTS = 64;             // launches of one solve whose activity is counted
 constexpr int SK_WSTRIDE = 64;         // ints per wave in sk_wave: chunk count, then up to 21 x (first entry, end, ticket)
+// non-zeros of the packed cam Hessian on the three-kernel path: 72 x 73 / 2 + 11 x 99 + 10 x 189 + 60 x 9
+constexpr int NZ_N = 2628 + 1089 + 1890 + 540;
 constexpr int SACC_N = 74 * 75 / 2;     // packed lower triangle of the compact Schur product: 72 vis dims, rhs row, Cauchy row
 constexpr int MAXKEEP = 80;            // new prior dim after MARGIN_OLD: <= 10*6 + 9 + 6 = 75
 
@@ -148,6 +150,10 @@ struct DevBatch {
   // which k_chol's elimination order does not cover); 2: general path for this iteration (a factorisation failed: the retry
   // with a larger mu runs in k_solve).  k_solve (ba_solve.h) is that general path.
   int *path;                                     // [W]
+  // Entries of the packed camera Hessian that the factors of a fast-path window can fill (vis x vis, the 15-dim frame blocks
+  // and their sub-diagonal neighbours, speed/bias 0 against everything: 6147 of 14706), as idx | r << 14 | c << 22: the
+  // passes of k_schur that need every non-zero of Hcc walk this list instead of the whole triangle.
+  int *nz_tab;                                   // [NZ_N]
 
   // ---- trust region vectors over the full index ----
   TrState *tr;                                   // [W]

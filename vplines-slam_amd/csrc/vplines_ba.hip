@@ -227,7 +227,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   if (e == hipSuccess) e = dalloc(c, &c->d_act, (size_t)ACT_SLOTS * 4);
   AL2(order, 2 * W); AL2(ord_cnt, 4);
   B.maxKS = B.maxP / 4 + B.maxL + NF + 2;
-  AL2(sk_tab, W * B.maxKS * 4); AL2(sk_wave, W * 8 * SK_WSTRIDE); AL2(sacc, W * SACC_N); AL2(ycs, W * 176); AL2(sx, W * 8); AL2(path, W);
+  AL2(sk_tab, W * B.maxKS * 4); AL2(sk_wave, W * 8 * SK_WSTRIDE); AL2(sacc, W * SACC_N); AL2(nz_tab, NZ_N); AL2(ycs, W * 176); AL2(sx, W * 8); AL2(path, W);
   if (e != hipSuccess) {
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -240,6 +240,22 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
     for (int r = 0, e2 = 0; r < NC; ++r)
       for (int cc = 0; cc <= r; ++cc, ++e2) lin_asm_entry(r, cc, &tab[2 * e2]);
     if (hipMemcpy(B.asm_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      for (void* p : c->allocs) hipFree(p);
+      delete c;
+      return VPL_E_HIP;
+    }
+  }
+  {   // non-zero pattern of the packed cam Hessian of a fast-path window (ba_types.h)
+    std::vector<int> nz;
+    for (int r = 0; r < NC; ++r)
+      for (int cc = 0; cc <= r; ++cc) {
+        const bool vis = cam2vis(r) >= 0 && cam2vis(cc) >= 0;
+        const int fr = r < 165 ? r / 15 : -1, fc = cc < 165 ? cc / 15 : -1;
+        const bool band = fr >= 0 && fc >= 0 && (fr == fc || fr == fc + 1);
+        const bool sb0 = cc >= 6 && cc < 15 && cam2vis(r) >= 0;
+        if (vis || band || sb0) nz.push_back(tri(r, cc) | r << 14 | cc << 22);
+      }
+    if ((int)nz.size() != NZ_N || hipMemcpy(B.nz_tab, nz.data(), nz.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
       for (void* p : c->allocs) hipFree(p);
       delete c;
       return VPL_E_HIP;
