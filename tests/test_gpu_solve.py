@@ -623,3 +623,33 @@ def test_prior_with_speed_bias_of_a_later_frame_takes_the_general_path(gpu_ctx):
         assert rep_g[i].iterations == rep_c.iterations and rep_g[i].num_successful_steps == rep_c.num_successful_steps
         dp, dr = pose_err(wg[i], wc[i])
         assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)
+
+
+def test_layout_tables_are_reused_only_for_the_same_track_layout():
+    """vpl_ba_upload keeps the host-built lane / unit / K-step tables of the previous upload when the batch has the same track
+    layout (start frames, lengths, selected lines): same results, bit for bit, as a context that builds them afresh -- for the
+    same layout with other values, and after the layout has changed."""
+    opt = v.default_options()
+    mk = lambda: v.Context(device=0, max_windows=3, max_points=60, max_point_obs=660, max_lines=24, max_line_obs=264)
+    wsA, _ = make_windows(3, 60, 24, True, seed0=1200)
+    wsB, _ = make_windows(3, 60, 24, True, seed0=1300)             # same layout (generator: start k mod 6, 6 observations), other values
+    cfg = v.workload.config(60, 24, True)
+    cfg.track_len = 9
+    wsC = [v.workload.generate(v.workload.seed_for(3, 1400 + i), cfg, 0.2 * i) for i in range(3)]
+    o.preintegrate_windows(wsC, opt)
+    rng = np.random.default_rng(5)
+    wsC = [_ragged(w, rng) for w in wsC]                           # another layout
+    used = mk()
+    seq = []
+    for ws in (wsA, wsB, wsC, wsB):
+        g = [w.copy() for w in ws]
+        used.solve_windows(g, opt)
+        seq.append(g)
+    used.close()
+    for k, ws in enumerate((wsA, wsB, wsC, wsB)):
+        fresh = mk()
+        g = [w.copy() for w in ws]
+        fresh.solve_windows(g, opt)
+        fresh.close()
+        for a, b in zip(seq[k], g):
+            assert np.array_equal(a.pose, b.pose) and np.array_equal(a.inv_depth, b.inv_depth) and np.array_equal(a.line_plk, b.line_plk), k

@@ -44,6 +44,12 @@ struct vpl_ctx {
   // the batch descriptor by value -- are fixed until the next upload); VPL_BA_GRAPH=0 launches kernel by kernel
   hipGraphExec_t graph_exec = nullptr;
   bool use_graph = true;
+  // signature of the track layout (start frames, lengths, selected lines) of the last upload: when the next batch has the same
+  // one -- the usual case between two solves of a tracker that lost and gained nothing, and every repetition of a benchmark --
+  // the host-built lane / unit / K-step tables and the index arrays already on the device are the right ones and are neither
+  // rebuilt nor uploaded again
+  unsigned long long layout_sig = 0;
+  bool layout_valid = false;
   bool force_general = false;                    // VPL_BA_GENERAL=1: every window takes k_solve (A/B runs, tests of the general path)
   std::vector<std::string> kname_store;
   // host-side marg structure of the uploaded windows
@@ -547,6 +553,23 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     B.wfill = (minTrack != maxTrack || opt->remove_line_outliers) ? 1 : 0;
   }
 
+  bool same_layout = false;
+  {
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+    const int hdr[8] = {nW, B.WS, B.llK, B.llNLW, B.wfill, all_lines ? 1 : 0, B.maxP, B.maxL};
+    mix(hdr, sizeof(hdr));
+    for (size_t w = 0; w < W; ++w) {
+      const vpl_window& v = win[w];
+      mix(&v.n_points, 4); mix(&v.n_lines, 4);
+      if (v.n_points > 0 && v.point_start && v.point_nobs) { mix(v.point_start, 4 * (size_t)v.n_points); mix(v.point_nobs, 4 * (size_t)v.n_points); }
+      if (v.n_lines > 0 && v.line_start && v.line_nobs) { mix(v.line_start, 4 * (size_t)v.n_lines); mix(v.line_nobs, 4 * (size_t)v.n_lines); }
+      if (v.n_lines > 0 && v.line_triangulated) mix(v.line_triangulated, 4 * (size_t)v.n_lines);
+    }
+    same_layout = c->layout_valid && h == c->layout_sig && std::getenv("VPL_BA_NO_LAYOUT_CACHE") == nullptr;
+    c->layout_sig = h;
+    c->layout_valid = false;       // becomes valid when this upload has gone through
+  }
   for (size_t w = 0; w < W; ++w) {
     const vpl_window& v = win[w];
     if (v.n_points > B.maxP || v.n_lines > B.maxL) return fail(c, VPL_E_CAPACITY, "too many tracks for the context");
@@ -570,7 +593,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       invd[w * B.maxP + p] = v.inv_depth[p];
       off += no;
     }
-    {   // counting sort of the point tracks by start frame
+    if (!same_layout) {   // counting sort of the point tracks by start frame
       int cnt[NF + 1] = {0};
       for (int p = 0; p < v.n_points; ++p) cnt[v.point_start[p] + 1]++;
       for (int f = 0; f < NF; ++f) cnt[f + 1] += cnt[f];
@@ -618,14 +641,14 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       woff += no;
     }
     nL[w] = nl;
-    {   // K-steps of k_schur: landmark rows by start frame, dealt to the 8 waves, flush tickets (ba_pack.h)
+    if (!same_layout) {   // K-steps of k_schur: landmark rows by start frame, dealt to the waves, flush tickets (ba_pack.h)
       int cnt[NF + 1];
       for (int f = 0; f <= NF; ++f) cnt[f] = ps_cnt[w * (NF + 1) + f];
       if (pack_schur_ksteps(v.n_points, &ps_list[w * B.maxP], cnt, nl, &ln_start[w * B.maxL], B.maxKS, &sk_tab[w * B.maxKS * 4],
                             &sk_wave[w * 8 * SK_WSTRIDE], SCHUR_THREADS / 64) < 0)
         return fail(c, VPL_E_CAPACITY, "K-step table of the landmark elimination too small");
     }
-    {   // lane layout of the line phase: llNLW whole tracks per wave, k-major; tracks in the caller's order (tracks that start
+    if (!same_layout) {   // lane layout of the line phase: llNLW whole tracks per wave, k-major; tracks in the caller's order (tracks that start
         // in the same frame side by side would pile their LDS adds onto the same addresses)
       std::vector<int> ord(nl);
       for (int i = 0; i < nl; ++i) ord[i] = i;
@@ -716,9 +739,10 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.orth, orth));
   HIPCHK(c, up(c, B.pose_0, pose)); HIPCHK(c, up(c, B.sb_0, sb)); HIPCHK(c, up(c, B.ex_0, ex)); HIPCHK(c, up(c, B.invd_0, invd));
   HIPCHK(c, up(c, B.plk_0, plk));
+  HIPCHK(c, up(c, B.pt_obs, pt_obs));
+  if (!same_layout) {
   HIPCHK(c, up(c, B.nP, nP)); HIPCHK(c, up(c, B.nL, nL));
   HIPCHK(c, up(c, B.pt_start, pt_start)); HIPCHK(c, up(c, B.pt_nobs, pt_nobs)); HIPCHK(c, up(c, B.pt_off, pt_off));
-  HIPCHK(c, up(c, B.pt_obs, pt_obs));
   HIPCHK(c, up(c, B.ps_list, ps_list)); HIPCHK(c, up(c, B.ps_cnt, ps_cnt));
   {   // the first max-over-the-batch rounds of every window
     int rmax = 0;
@@ -735,9 +759,11 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     }
   } HIPCHK(c, up(c, B.pu_cnt, pu_cnt)); HIPCHK(c, up(c, B.pu_cnt0, pu_cnt0));
   HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
-  HIPCHK(c, up(c, B.ln_obs, ln_obs)); HIPCHK(c, up(c, B.ln_tri, ln_tri));
   HIPCHK(c, up(c, B.nLO, nLO)); HIPCHK(c, up(c, B.lo_ln, lo_ln));
   HIPCHK(c, up(c, B.ll_tab, ll_tab)); HIPCHK(c, up(c, B.ll_np, ll_np));
+  HIPCHK(c, up(c, B.sk_tab, sk_tab)); HIPCHK(c, up(c, B.sk_wave, sk_wave));
+  }
+  HIPCHK(c, up(c, B.ln_obs, ln_obs)); HIPCHK(c, up(c, B.ln_tri, ln_tri));
   HIPCHK(c, up(c, B.pre, pre));
   HIPCHK(c, up(c, B.pr_n, pr_n)); HIPCHK(c, up(c, B.pr_nb, pr_nb)); HIPCHK(c, up(c, B.pr_kind, pr_kind));
   HIPCHK(c, up(c, B.pr_frame, pr_frame)); HIPCHK(c, up(c, B.pr_idx, pr_idx));
@@ -755,8 +781,9 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.mg_frame, mg_frame)); HIPCHK(c, up(c, B.mg_idx, mg_idx)); HIPCHK(c, up(c, B.mg_cam, mg_cam));
   HIPCHK(c, up(c, B.mg_m, c->h_mg_m));
   if (c->force_general) std::fill(path.begin(), path.end(), 1);
-  HIPCHK(c, up(c, B.sk_tab, sk_tab)); HIPCHK(c, up(c, B.sk_wave, sk_wave)); HIPCHK(c, up(c, B.path, path));
+  HIPCHK(c, up(c, B.path, path));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // host staging vectors die here
+  c->layout_valid = true;
   return VPL_OK;
 }
 
