@@ -190,9 +190,11 @@ constexpr unsigned ed_truth(bool horizPixel) {
 constexpr unsigned ED_TRUTH = ed_truth(false) | (ed_truth(true) << 16);
 
 __device__ __forceinline__ void ed_tile_load(EdWalker& wk, int x, int y, unsigned S) {
+  // centred on the walker: the two walks of an anchor leave in opposite directions and the next anchor of the scan sits two
+  // rows further down, so a tile placed AHEAD of the direction of travel (rounds 1-2) was thrown away by the very next walk
+  // (~1500 reloads per frame); centred, a tile serves all walks shorter than 64 pixels around a run of anchors
   int tx = x - ED_TILE / 2, ty = y - ED_TILE / 2;
-  if (S & 1) tx = (S & 2) ? x - 16 : x - (ED_TILE - 24);    // travelling RIGHT / LEFT (x stays inside after the rounding below)
-  else ty = (S & 2) ? y - 16 : y - (ED_TILE - 17);          // DOWN / UP
+  (void)S;
   tx &= ~7;
   tx = max(0, min(tx, wk.Wc - ED_TILE));
   ty = max(0, min(ty, wk.H - ED_TILE));
@@ -211,52 +213,76 @@ __device__ __forceinline__ void ed_tile_load(EdWalker& wk, int x, int y, unsigne
 #pragma unroll
     for (int k = 0; k < 8; ++k) *(uint4*)(dst + 4 * (8 * b + k) * ED_TILE) = v[k];
   }
-  wk.tx0 = tx; wk.ty0 = ty;
+  wk.tx0 = __builtin_amdgcn_readfirstlane(tx); wk.ty0 = __builtin_amdgcn_readfirstlane(ty);
   ++wk.nLoads;
   __syncthreads();
 }
 
 // EdgeDrawing's routing loops (edline_detector.cpp:191-647); returns the number of pixels of this part.
-// The pixels of the part go through a 64-entry LDS ring and are written 64 at a time; the tile bounds are only
-// re-examined when the walker may have reached the tile border (it moves one pixel per step).
-__device__ int ed_walk(EdWalker& wk, int x, int y, unsigned S, uint32_t* px, uint32_t* py, int cap) {
+//
+// Round 3: the walk runs on the SCALAR unit.  The walker's state (x, y, travel state, counters) is wave uniform; what made a
+// step cost ~550 cycles was ~75 vector instructions and two dependent LDS reads per pixel.  Now the 64 lanes hold an 8 x 8
+// WINDOW of the frame around the walker -- lane (lx, ly) the routing word and the visited bit of pixel (wx0 + lx, wy0 + ly),
+// fetched from the LDS tile / bitmap with one read each -- and a step inside the window is: one v_readlane of the routing word
+// (the result lands in a scalar register), a dozen scalar instructions (truth table, move, state), one bit set in a 64-bit
+// mask of the pixels claimed in this window and a compare + select that files the pixel's coordinates in the lane of its
+// ordinal.  When the walker leaves the window the claimed pixels are committed to the bitmap (one LDS atomic OR per lane
+// that holds one) and the window is re-centred ahead of the direction of travel (5-6 steps per window on average).
+// Same pixels, same order, same chains as the step-by-step loop.
+__device__ __forceinline__ int ed_walk(EdWalker& wk, int x, int y, unsigned S, uint32_t* px, uint32_t* py, int cap) {
   const int W = wk.W, lane = threadIdx.x;
-  int n = 0, safe = 0;
+  const int lx = lane & 7, ly = lane >> 3;
+  x = __builtin_amdgcn_readfirstlane(x); y = __builtin_amdgcn_readfirstlane(y); S = __builtin_amdgcn_readfirstlane(S);
+  int n = 0;
+  int pxy = 0;                   // lane (i & 63) holds pixel i of the current block of 64
   for (;;) {
-    if (safe == 0) {
-      if ((unsigned)(x - wk.tx0) >= (unsigned)ED_TILE || (unsigned)(y - wk.ty0) >= (unsigned)ED_TILE || wk.tx0 < 0)
-        ed_tile_load(wk, x, y, S);
-      const int rx = x - wk.tx0, ry = y - wk.ty0;
-      safe = min(min(rx, ED_TILE - 1 - rx), min(ry, ED_TILE - 1 - ry));   // steps that cannot leave the tile
-    } else {
-      --safe;
+    if ((unsigned)(x - wk.tx0) >= (unsigned)ED_TILE || (unsigned)(y - wk.ty0) >= (unsigned)ED_TILE || wk.tx0 < 0)
+      ed_tile_load(wk, x, y, S);
+    // window origin: one pixel behind the walker, six ahead, +-3 across the direction of travel; kept inside the tile
+    int wx0, wy0;
+    if (S & 1) { wx0 = (S & 2) ? x - 1 : x - 6; wy0 = y - 3; }
+    else { wy0 = (S & 2) ? y - 1 : y - 6; wx0 = x - 3; }
+    wx0 = __builtin_amdgcn_readfirstlane(max(wk.tx0, min(wx0, wk.tx0 + ED_TILE - 8)));
+    wy0 = __builtin_amdgcn_readfirstlane(max(wk.ty0, min(wy0, wk.ty0 + ED_TILE - 8)));
+    const int qx = wx0 + lx, qy = wy0 + ly;
+    const bool inb = qx < W && qy < wk.H;
+    const int idx = __mul24(qy, W) + qx;
+    const unsigned wcode = wk.tile[(qy - wk.ty0) * ED_TILE + (qx - wk.tx0)];
+    const unsigned bw = inb ? wk.bits[idx >> 5] : 0u;
+    const unsigned long long live = __ballot(inb && (wcode & ED_LIVE) != 0);
+    const unsigned long long vis0 = __ballot(((bw >> (idx & 31)) & 1u) != 0);
+    unsigned long long vmask = 0;
+    bool done = false;
+    for (;;) {
+      const int li = (y - wy0) * 8 + (x - wx0);
+      const unsigned long long bit = 1ull << li;
+      if (!(live & bit) || ((vis0 | vmask) & bit)) { done = true; break; }       // while (g > 0 && !edge)
+      vmask |= bit;
+      pxy = lane == (n & 63) ? (x | (y << 16)) : pxy;     // (compare + select: v_writelane would need two scalar operands)
+      ++n;
+      if ((n & 63) == 0) {
+        const int o = n - 64 + lane;
+        if (o < cap) { px[o] = (unsigned)pxy & 0xffff; py[o] = (unsigned)pxy >> 16; }
+      }
+      const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wcode, li);
+      const unsigned h = (w >> 8) & 1;
+      const unsigned F = (ED_TRUTH >> (h * 16 + S)) & 1;
+      const unsigned mv = (w >> (F ? 0 : 4)) & 15;
+      if (mv == ED_STOP) { done = true; break; }
+      // (v_readfirstlane: the compiler's uniformity analysis loses the walker's state through the loops; one hint per value
+      // keeps all of the arithmetic above on the scalar unit)
+      x = __builtin_amdgcn_readfirstlane(x + (int)(mv & 3) - 1);
+      y = __builtin_amdgcn_readfirstlane(y + (int)(mv >> 2) - 1);
+      S = __builtin_amdgcn_readfirstlane(h | (F << 1) | ((mv & 2) << 1) | (mv & 8));   // dx > 0 <=> (mv & 3) == 2, dy > 0 <=> (mv >> 2) == 2
+      n = __builtin_amdgcn_readfirstlane(n);
+      if ((unsigned)(x - wx0) >= 8u || (unsigned)(y - wy0) >= 8u) break;         // left the window
     }
-    const int idx = __mul24(y, W) + x;
-    const unsigned w = wk.tile[(y - wk.ty0) * ED_TILE + (x - wk.tx0)];
-    const unsigned word = wk.bits[idx >> 5], bit = 1u << (idx & 31);
-    if (!(w & ED_LIVE) || (word & bit)) break;       // while (g > 0 && !edge)
-    if (lane == 0) {
-      wk.bits[idx >> 5] = word | bit;
-      wk.ring[n & 63] = (unsigned)x | ((unsigned)y << 16);
-    }
-    ++n;
-    if ((n & 63) == 0) {
-      const int o = n - 64 + lane;
-      const unsigned pxy = wk.ring[lane];
-      if (o < cap) { px[o] = pxy & 0xffff; py[o] = pxy >> 16; }
-    }
-    const unsigned h = (w >> 8) & 1;
-    const unsigned F = (ED_TRUTH >> (h * 16 + S)) & 1;
-    const unsigned mv = (w >> (F ? 0 : 4)) & 15;
-    if (mv == ED_STOP) break;
-    x += (int)(mv & 3) - 1;
-    y += (int)(mv >> 2) - 1;
-    S = h | (F << 1) | ((mv & 2) << 1) | (mv & 8);   // dx > 0 <=> (mv & 3) == 2, dy > 0 <=> (mv >> 2) == 2
+    if ((vmask >> lane) & 1ull) atomicOr(&wk.bits[idx >> 5], 1u << (idx & 31));
+    if (done) break;
   }
   if (n & 63) {
     const int o = (n & ~63) + lane;
-    const unsigned pxy = wk.ring[lane];
-    if (lane < (n & 63) && o < cap) { px[o] = pxy & 0xffff; py[o] = pxy >> 16; }
+    if (lane < (n & 63) && o < cap) { px[o] = (unsigned)pxy & 0xffff; py[o] = (unsigned)pxy >> 16; }
   }
   wk.nSteps += n;
   return n;
