@@ -12,7 +12,7 @@ namespace vpl {
 
 typedef double v4d_lin __attribute__((ext_vector_type(4)));
 constexpr int LIN_THREADS = 512;
-constexpr int STG_LD = 21;                // row stride of the MFMA staging tiles (odd: the 16 writer lanes spread over the banks)
+constexpr int STG_LD = 17;                // row stride of the MFMA staging tiles (16 columns; odd: the 16 writer lanes spread over the banks)
 constexpr int LIN_STAGE = 8 * 32 * STG_LD;   // MFMA staging of the point phase (doubles)
 constexpr int PRE_LDS = 62;               // leading doubles of DevPreint: sum_dt, dp, dq, dv, lba, lbg, the five 3x3 Jacobian blocks
 constexpr int LIN_HW = 720;               // wave-private partial sums of the line phase: 11 x (21 + 36 + 6) + 21 + 6 doubles
@@ -21,7 +21,7 @@ __host__ __device__ constexpr int lin_stage_doubles(int maxL) {   // MFMA stagin
   const int ln = 8 * LIN_HW + 38 * maxL;                 // line phase
   const int pt = LIN_STAGE + 78 * 36 + NV;               // point phase: MFMA tiles + the second commit chain's Hessian copy
   const int m = ln > pt ? ln : pt;
-  return m > 4650 ? m : 4650;
+  return m > 4650 + 3570 ? m : 4650 + 3570;              // IMU phase: whitened [J | r] of the ten factors + their J^T J blocks (imuH)
 }
 constexpr int PREP_THREADS = 640;         // ten waves: one IMU factor each, all ten in one round
 // per-wave scratch of the whitening (3 x 225) + the staged prior J0 of the batch's largest prior (capped at PREP_NMAX)
@@ -227,46 +227,77 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   }
   for (int i = tid; i < NC; i += T) invmap[i] = -1;
   if (tid < 5) tick[tid] = 0;
+  // The prior's inputs are requested HERE, with the states: its block table and linearisation point (one lane per block), the
+  // index map, and this lane's part of the rows of J0 and H = J0^T J0 (eight lanes per row, the first LIN_PJ columns of
+  // each) -- the phase was three dependent round trips (table -> barrier -> rows), each ~3 k cycles with every CU in it.
+  constexpr int LIN_PJ = 6;
+  const int n = B.pr_n[w], nb = n > 0 ? B.pr_nb[w] : 0;
+  const int prow = tid >> 3, psub = tid & 7;
+  int pkind = 0, pfr = 0, pidx = 0, pmap = -1;
+  double px0[9], pj0[LIN_PJ], phv[LIN_PJ], r0r = 0.0, g0r = 0.0;
+  if (tid < nb) {
+    pkind = B.pr_kind[(size_t)w * MAXPB + tid]; pfr = B.pr_frame[(size_t)w * MAXPB + tid]; pidx = B.pr_idx[(size_t)w * MAXPB + tid];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) px0[k] = B.pr_x0[((size_t)w * MAXPB + tid) * 9 + k];
+  }
+  if (tid < n) pmap = B.pr_map[(size_t)w * MAXPN + tid];
+  {
+    const double* J0 = B.pr_J0 + (size_t)w * B.prS;
+    const double* Hp = B.pr_H + (size_t)w * B.prS;
+#pragma unroll
+    for (int q = 0; q < LIN_PJ; ++q) {
+      const int c = psub + 8 * q;
+      const bool in = prow < n && c < n;
+      pj0[q] = in ? J0[(size_t)prow * n + c] : 0.0;
+      phv[q] = in ? Hp[(size_t)prow * n + c] : 0.0;
+    }
+    if (prow < n && psub == 0) { r0r = B.pr_r0[(size_t)w * MAXPN + prow]; g0r = B.pr_g0[(size_t)w * MAXPN + prow]; }
+  }
   __syncthreads();
   double cost = 0.0;
   VPL_STAMP(B, w, 16);
 
   // ---- prior: r = r0 + J0 dx ; g = J0^T r -------------------------------------------
-  const int n = B.pr_n[w];
   if (n > 0) {
-    const int nb = B.pr_nb[w];
     if (tid < nb) {
-      int kind = B.pr_kind[(size_t)w * MAXPB + tid], fr = B.pr_frame[(size_t)w * MAXPB + tid];
-      int idx = B.pr_idx[(size_t)w * MAXPB + tid];
-      const double* x = kind == 0 ? xp + 7 * fr : kind == 1 ? xs + 9 * fr : xp + 77;
+      const double* x = pkind == 0 ? xp + 7 * pfr : pkind == 1 ? xs + 9 * pfr : xp + 77;
       double dx[9];
-      prior_block_dx(kind, x, B.pr_x0 + ((size_t)w * MAXPB + tid) * 9, dx);
-      int ls = kind == 1 ? 9 : 6;
-      for (int k = 0; k < ls; ++k) prdx[idx + k] = dx[k];
+      prior_block_dx(pkind, x, px0, dx);
+      int ls = pkind == 1 ? 9 : 6;
+      for (int k = 0; k < ls; ++k) prdx[pidx + k] = dx[k];
     }
-    for (int i = tid; i < n; i += T) invmap[B.pr_map[(size_t)w * MAXPN + i]] = i;
+    if (tid < n) invmap[pmap] = tid;
+    for (int i = tid + T; i < n; i += T) invmap[B.pr_map[(size_t)w * MAXPN + i]] = i;
     __syncthreads();
     const double* J0 = B.pr_J0 + (size_t)w * B.prS;
-    // r = r0 + J0 dx and g = J0^T r = g0 + H dx (H = J0^T J0, g0 = J0^T r0 from k_prep) in ONE pass: eight lanes per row,
-    // both rows' loads in flight together -- the second mat-vec used to start after the first (and a barrier) and paid
-    // the global latency of its column reads all over again
+    // r = r0 + J0 dx and g = J0^T r = g0 + H dx (H = J0^T J0, g0 = J0^T r0 from k_prep) in ONE pass: eight lanes per row
     const double* Hp = B.pr_H + (size_t)w * B.prS;
-    for (int r = tid >> 3; r < n; r += T >> 3) {
-      const int sub = tid & 7;
-      // (r0 and g0 of the row are requested with the row, not after the shuffles; eight columns per lane in one batch)
-      const double r0r = sub == 0 ? B.pr_r0[(size_t)w * MAXPN + r] : 0.0, g0r = sub == 0 ? B.pr_g0[(size_t)w * MAXPN + r] : 0.0;
+    for (int r = prow; r < n; r += T >> 3) {
+      const bool first = r == prow;
       double s = 0, sg = 0;
-#pragma unroll 8
-      for (int c = sub; c < n; c += 8) {
+      if (first) {
+#pragma unroll
+        for (int q = 0; q < LIN_PJ; ++q) {
+          const int c = psub + 8 * q;
+          if (c < n) {
+            const double dxc = prdx[c];
+            s += pj0[q] * dxc;
+            sg += phv[q] * dxc;
+            if (n <= PRH_N && c <= r) prH[r * (r + 1) / 2 + c] = phv[q];   // kept for the assembly
+          }
+        }
+      }
+      for (int c = psub + (first ? 8 * LIN_PJ : 0); c < n; c += 8) {
         const double dxc = prdx[c];
         const double hrc = Hp[(size_t)r * n + c];
         s += J0[(size_t)r * n + c] * dxc;
         sg += hrc * dxc;
-        if (n <= PRH_N && c <= r) prH[r * (r + 1) / 2 + c] = hrc;   // kept for the assembly
+        if (n <= PRH_N && c <= r) prH[r * (r + 1) / 2 + c] = hrc;
       }
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
       sg += __shfl_xor(sg, 1, 64); sg += __shfl_xor(sg, 2, 64); sg += __shfl_xor(sg, 4, 64);
-      if (sub == 0) {
+      if (psub == 0) {
+        if (!first) { r0r = B.pr_r0[(size_t)w * MAXPN + r]; g0r = B.pr_g0[(size_t)w * MAXPN + r]; }
         s += r0r;
         prr[r] = s;
         prg[r] = sg + g0r;
@@ -308,13 +339,15 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 
   VPL_STAMP(B, w, 23);
   // points: the work unit is (start frame s, observation index k, <= 16 of the tracks that start in s and are seen at k).
-  // Inside a unit every lane works on the same pair of frames (s, j = s + k), so the six 6x6 blocks a point factor
-  // touches are uniform over its lanes and the sum of J^T [J | r] (19 x 19, J = [J_s J_j J_e]) over them is a rank-2n
-  // update: the lanes stage their two Jacobian rows in LDS and the FP64 matrix cores reduce them (2 tiles of 16x16, K = 4
-  // per instruction; the corner of the last two extrinsic columns and the residual is one sum over the wave), each lane then
-  // adds its accumulator entries to the LDS Hessian.  The host packs the units into quarter-wave slots (pu_lane / pu_sub):
-  // a full unit takes a slot, small ones share one -- 200 tracks x 5 factors are 60 full units + 30 of two tracks = 64
-  // slots = 2 rounds of the 8 waves.
+  // Inside a unit every lane works on the same pair of frames (s, j = s + k), so the 6x6 blocks a point factor touches are
+  // uniform over its lanes and the sum of J^T [J | r] over them is a rank-2n update: the lanes stage their two Jacobian rows
+  // in LDS and the FP64 matrix cores reduce them.  The position columns of frame j are MINUS those of frame s
+  // (projection_factor.cpp:84, :96: jaco_i.leftCols<3>() = ric^T Rj^T, jaco_j.leftCols<3>() = -ric^T Rj^T), bit for bit, so a row
+  // has 16 distinct columns -- s position, s rotation, j rotation, extrinsic, residual -- and ONE 16x16 tile (K = 4 per
+  // instruction) holds the whole 19x19 sum; the blocks of j's position columns are committed from the same accumulator
+  // entries with the sign flipped.  The host packs the units into quarter-wave slots (pu_lane / pu_sub): a full unit takes
+  // a slot, small ones share one -- 200 tracks x 5 factors are 60 full units + 30 of two tracks = 64 slots = 2 rounds of
+  // the 8 waves.
   {
     const int wvi = tid >> 6, nwv = T >> 6;
     const int nRounds = PRIOR_ONLY ? 0 : (MARG ? B.pu_cnt0[w] : B.pu_cnt[w]);
@@ -322,6 +355,8 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     const int* psub = B.pu_sub + (size_t)w * B.maxPR * 512;
     double* stg = imuJ + wvi * (32 * STG_LD);              // this wave's staging tile: 32 rows x 20 (stride STG_LD)
     const int m16 = lane & 15, kk = lane >> 4;
+    const int b_cls = m16 < 6 ? 0 : (m16 < 9 ? 1 : (m16 < 15 ? 2 : 3));       // tile column of this lane: block (s | j | extrinsic | residual)
+    const int b_off = m16 < 6 ? m16 : (m16 < 9 ? m16 - 3 : m16 - 9);        // and offset inside the 6-wide block
     // Every accumulator of this phase is shared by all waves, and floating-point addition does not associate: the adds are
     // therefore committed IN A FIXED ORDER: every unit carries a ticket number from the host; its wave waits for the
     // ticket, adds its Hessian tile, passes the ticket on.  The factor math and the matrix-core reductions of the other
@@ -396,17 +431,9 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
           Wrow[6 * k + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];   // this (track, frame) entry has one writer
         }
       }
-      // corner of the unit's 19 x 19 sum that the two matrix-core tiles do not cover: (e4, e5, r) x (e4, e5)
-      const double cnr[5] = {Je[4] * Je[4] + Je[10] * Je[10], Je[5] * Je[4] + Je[11] * Je[10], Je[5] * Je[5] + Je[11] * Je[11],
-                             Je[4] * r[0] + Je[10] * r[1], Je[5] * r[0] + Je[11] * r[1]};
       const unsigned long long actmask = __ballot(act);
       // per-track sums over k: a track's factors sit in different units, i.e. in different waves -- one chain over all
       // waves; two lanes of a wave may hold the same track with different k: atomic adds, lane order
-      // The extrinsic corner is the same five entries for every unit: one sum over the wave, added with its first tile
-      double cs[5];
-#pragma unroll
-      for (int a = 0; a < 5; ++a) cs[a] = wave_sum_dpp(cnr[a]);
-      bool cs_pending = true;
       PT_LAP(0);
       // Per-track sums over k (H_ll, g_l, W_s, W_ext): a track's factors sit in different units, but (host packing) all in
       // the same half of the work-group: one chain over the half's four waves orders the LDS adds (tick[3 + half]); two
@@ -431,11 +458,11 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
               d0[rr * STG_LD + a] = Ji[6 * rr + a];
-              d0[rr * STG_LD + 6 + a] = Jj[6 * rr + a];
-              d0[rr * STG_LD + 12 + a] = Je[6 * rr + a];
+              d0[rr * STG_LD + 9 + a] = Je[6 * rr + a];
             }
-            d0[rr * STG_LD + 18] = r[rr];
-            d0[rr * STG_LD + 19] = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d0[rr * STG_LD + 6 + a] = Jj[6 * rr + 3 + a];   // (Jj[0..2] = -Ji[0..2])
+            d0[rr * STG_LD + 15] = r[rr];
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -454,51 +481,53 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
             ticket_pass(1 + half, seq);
             continue;
           }
-          v4d_lin c00 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0};
+          v4d_lin c00 = {0, 0, 0, 0};
           // operands of four steps are read before the first of their MFMAs issues (one LDS latency per group)
 #pragma unroll 1
           for (int kb = ks0; kb < ks1; kb += 4) {
-            double lo[4], hi[4];
+            double lo[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (kb + q < ks1) {
-                const double* row = stg + (4 * (kb + q) + kk) * STG_LD;
-                lo[q] = row[m16];
-                hi[q] = m16 < 4 ? row[16 + m16] : 0.0;
-              }
+              if (kb + q < ks1) lo[q] = stg[(4 * (kb + q) + kk) * STG_LD + m16];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (kb + q < ks1) {
-                c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[q], lo[q], c00, 0, 0, 0);
-                c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi[q], lo[q], c10, 0, 0, 0);
-              }
+              if (kb + q < ks1) c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[q], lo[q], c00, 0, 0, 0);
           }
-          // accumulator entry (row a = kk + 4 v (+16), col b = m16) -> LDS Hessian / gradient, in ticket order
+          // accumulator entry (row a = kk + 4 v, col b = m16; the tile is symmetric and every (a, b) sits in exactly one lane)
+          // -> LDS Hessian / gradient, in ticket order.  Tile columns: 0..2 s position, 3..5 s rotation, 6..8 j rotation,
+          // 9..14 extrinsic, 15 residual.  Four adds of the lower triangle (the residual row goes to the gradient, which follows
+          // the Hessian in LDS); the lanes of rows 0..2 (kk < 3, v = 0) hold T[q][c] for every column c and add it a second
+          // time, negated, as the entry of j's position row / column q (and a third time for the (j pos, j pos) block).
+          // All indices are computed before the ticket is waited for: the critical section is six LDS adds.
+          const int tS = 36 * (sq * (sq + 1) / 2), tJ = 36 * (jq * (jq + 1) / 2), tE = 36 * 66, cS = 36 * sq, cJ = 36 * jq, cE = 36 * 11;
+          const int colbase = (b_cls == 0 ? cS : (b_cls == 1 ? cJ : cE)) + b_off;
+          int idx[4];
+          bool on[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int a = kk + 4 * v;
+            const int a_cls = a < 6 ? 0 : (a < 9 ? 1 : (a < 15 ? 2 : 3));
+            const int a_off = a < 6 ? a : (a < 9 ? a - 3 : a - 9);
+            idx[v] = (a_cls == 0 ? tS : (a_cls == 1 ? tJ : tE)) + 6 * a_off + colbase;
+            on[v] = a >= m16;
+            if (a_cls == 3) {
+              idx[v] = HV_DOUBLES + (b_cls == 0 ? 6 * sq : (b_cls == 1 ? 6 * jq : 66)) + b_off;
+              on[v] = m16 < 15;
+            }
+          }
+          const int didx = m16 < 6 ? tJ + cS + 6 * kk + m16
+                         : (m16 < 9 ? tJ + cJ + 6 * (m16 - 3) + kk : (m16 < 15 ? tE + cJ + 6 * (m16 - 9) + kk : HV_DOUBLES + 6 * jq + kk));
+          const int jidx = tJ + cJ + 6 * kk + m16;
+          const bool don = kk < 3, jon = kk < 3 && m16 <= kk;
+          const double v00[4] = {c00.x, c00.y, c00.z, c00.w};
           PT_LAP(3);
           ticket_wait(1 + half, seq);
           PT_LAP(4);
-          {
-            const double v00[4] = {c00.x, c00.y, c00.z, c00.w}, v10[4] = {c10.x, c10.y, c10.z, c10.w};
-            auto visof = [&](int a) { return a < 6 ? 6 * sq + a : (a < 12 ? 6 * jq + (a - 6) : 66 + (a - 12)); };
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const int a0 = kk + 4 * v, bcol = m16;
-              if (a0 >= bcol) lds_add(&HvC[hvi(visof(a0), visof(bcol))], v00[v]);
-              const int a1 = 16 + kk + 4 * v;
-              if (a1 < 18) lds_add(&HvC[hvi(visof(a1), visof(bcol))], v10[v]);
-              else if (a1 == 18) lds_add(&gvC[visof(bcol)], v10[v]);
-            }
-            if (cs_pending) {      // uniform
-              cs_pending = false;
-              if (lane == 0) {
-                lds_add(&HvC[hvi(70, 70)], cs[0]);
-                lds_add(&HvC[hvi(71, 70)], cs[1]);
-                lds_add(&HvC[hvi(71, 71)], cs[2]);
-                lds_add(&gvC[70], cs[3]);
-                lds_add(&gvC[71], cs[4]);
-              }
-            }
-          }
+          for (int v = 0; v < 4; ++v)
+            if (on[v]) lds_add(&HvC[idx[v]], v00[v]);
+          if (don) lds_add(&HvC[didx], -v00[0]);
+          if (jon) lds_add(&HvC[jidx], v00[0]);
           ticket_pass(1 + half, seq);
           PT_LAP(5);
         }
@@ -543,16 +572,18 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     for (int i = lane; i < LIN_HW; i += 64) Hw[i] = 0.0;
     for (int i = tid; i < nL * 38; i += T) lacc[i] = 0.0;
     __syncthreads();
-    const int* ltab = B.ll_tab + (size_t)w * B.llSlots;
+    const int2* ltab = (const int2*)B.ll_tab + (size_t)w * B.llSlots;
     const int npass = B.ll_np[w];
     const int krow = lane / NLW;                         // observation index of this lane's slot
     for (int pass = 0; pass < npass; ++pass) {
-      const int o = (!PRIOR_ONLY && krow < KL) ? ltab[pass * T + tid] : -1;
+      // the lane's record: observation, line | k << 16 | start frame << 20 (one load; the factor's data is the next trip)
+      const int2 lr = (!PRIOR_ONLY && krow < KL) ? ltab[pass * T + tid] : int2{-1, 0};
+      const int o = lr.x;
       const bool inb = o >= 0;
-      const int l = inb ? B.lo_ln[(size_t)w * B.maxLO + o] : 0;
+      const int l = inb ? lr.y & 0xffff : 0;
       const size_t li = (size_t)w * B.maxL + l;
-      const int s = B.ln_start[li], off = B.ln_off[li];
-      const int k = inb ? o - off : 0, j = s + k;
+      const int s = inb ? lr.y >> 20 : 0;
+      const int k = inb ? (lr.y >> 16) & 15 : 0, j = s + k;
       // MARG: start-frame obs skipped (estimator.cpp:1322-1326), erased lines are no longer in f_manager.linefeature
       const bool act = inb && (!MARG || (s == 0 && k >= 1 && !B.ln_removed[li]));
       const double* ob = B.ln_obs + ((size_t)w * B.maxLO + (inb ? o : 0)) * 8;
@@ -566,7 +597,11 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #pragma unroll
       for (int fct = 0; fct < 2; ++fct) {
         // VP factor only in the solve and only when flagged (estimator.cpp:1153, :1341-1351)
+#ifdef VPL_X_NO_VP
+        const bool fa = act && fct == 0;
+#else
         const bool fa = act && (fct == 0 || (!MARG && ob[7] == 1.0));
+#endif
         double r[2] = {0, 0}, Je[12];
 #pragma unroll
         for (int q = 0; q < 12; ++q) Je[q] = 0.0;
@@ -591,6 +626,10 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
           int t = 0;
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
+#ifdef VPL_X_NO_LA
+            for (int c2 = c0; c2 < 6; ++c2) Wj[6 * a + c2] += Jo[a] * Jp[c2] + Jo[4 + a] * Jp[6 + c2] + Je[c2] * r[0];
+            (void)la;
+#else
             lds_add(&la[10 + a], Jo[a] * r[0] + Jo[4 + a] * r[1]);
 #pragma unroll
             for (int c2 = 0; c2 <= a; ++c2, ++t) lds_add(&la[t], Jo[a] * Jo[c2] + Jo[4 + a] * Jo[4 + c2]);
@@ -599,8 +638,10 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
               Wj[6 * a + c2] += Jo[a] * Jp[c2] + Jo[4 + a] * Jp[6 + c2];
               lds_add(&la[14 + 6 * a + c2], Jo[a] * Je[c2] + Jo[4 + a] * Je[6 + c2]);
             }
+#endif
           }
           // blocks (j, j), (ext, j), g_j of this wave's partial sums
+#ifndef VPL_X_NO_HF
           t = 0;
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
@@ -612,9 +653,11 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
             for (int c2 = c0; c2 < 6; ++c2) lds_add(&Hf[21 + 6 * a + c2], Je[a] * Jp[c2] + Je[6 + a] * Jp[6 + c2]);
             lds_add(&Hf[57 + a], Jp[a] * r[0] + Jp[6 + a] * r[1]);
           }
+#endif
         }
         // extrinsic block: every factor touches it.  DPP row_shr sums inside each row of 16 lanes (VALU only), then the four
         // row leaders add to the wave's partial sums
+#ifndef VPL_X_NO_HF
         {
           const bool leader = (lane & 15) == 15;
           const int c0 = fct == 0 ? 0 : 3;
@@ -633,8 +676,13 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
             }
           }
         }
+#endif
       }
+#ifdef VPL_X_NO_WJ
+      if (act && Wj[0] == 123.456) {
+#else
       if (act) {
+#endif
         double* Wl = B.Wl + li * 4 * WS;
 #pragma unroll
         for (int a = 0; a < 4; ++a)

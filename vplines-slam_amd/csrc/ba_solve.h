@@ -908,6 +908,7 @@ static_assert(2 * CROWS * CW <= NAP, "the two staging buffers alias the reduced-
 
 // ---------------------------------------------------------------------------------------------------
 constexpr int COST_THREADS = 512;
+constexpr int COST_PRE_LDS = 62 + 225;   // staged part of a pre-integration in k_cost: the PRE_LDS leading doubles + sqrt_info
 
 // two workgroups per CU (4 waves per SIMD, <= 128 VGPRs): the kernel is a latency chain per lane, occupancy is what helps
 // (0.327 -> 0.283 ms per step against one workgroup per CU at 136 VGPRs)
@@ -916,47 +917,65 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
   TrState* tr = &B.tr[w];
   if (tr->status != 0 || !tr->step_valid) return;
   count_active(B, 3);
+  // The kernel is a chain of global round trips (~2-3 k cycles each with every CU in it), not arithmetic: everything whose
+  // address depends on the window alone is requested in ONE batch at the top -- the candidate state, the leading part and
+  // the information factor of the ten pre-integrations (to LDS, coalesced), the prior's block table and linearisation
+  // point, its Jacobian rows, and the lane records of the point / line factors (the host tables of k_lin: track, k, start
+  // frame and observation offset in one word pair, so that the factor's own data is the second and last trip).
   __shared__ double xp[84], xs[99], prdx[MAXPN], red[20];
+  __shared__ double plds[10 * COST_PRE_LDS], imu_raw[10 * 15];
+  __shared__ int imu_on[10];
   __shared__ int accept;
-  const int nP = B.nP[w], nL = B.nL[w];
+  const int nL = B.nL[w], nP = B.nP[w];
+  const int n = B.pr_n[w], nb = n > 0 ? B.pr_nb[w] : 0;
   for (int i = tid; i < 84; i += T) xp[i] = i < 77 ? B.pose_c[(size_t)w * 77 + i] : B.ex_c[(size_t)w * 7 + (i - 77)];
   for (int i = tid; i < 99; i += T) xs[i] = B.sb_c[(size_t)w * 99 + i];
+  for (int i = tid; i < 10 * COST_PRE_LDS; i += T) {      // per factor: 62 leading doubles, then the 225 of sqrt_info
+    const int f = i / COST_PRE_LDS, e = i - COST_PRE_LDS * f;
+    plds[i] = ((const double*)&B.pre[(size_t)w * NF + f + 1])[e < PRE_LDS ? e : e + 225];
+  }
+  int pkind = 0, pfr = 0, pidx = 0;
+  double px0[9];
+  if (tid < nb) {
+    pkind = B.pr_kind[(size_t)w * MAXPB + tid]; pfr = B.pr_frame[(size_t)w * MAXPB + tid]; pidx = B.pr_idx[(size_t)w * MAXPB + tid];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) px0[k] = B.pr_x0[((size_t)w * MAXPB + tid) * 9 + k];
+  }
+  // eight lanes per row of J0 (coalesced): the first COST_J0 columns of this lane's row wait in registers
+  constexpr int COST_J0 = 6;
+  const int prow = tid >> 3, psub = tid & 7;
+  double j0v[COST_J0], pr0 = 0.0;
+  {
+    const double* J0 = B.pr_J0 + (size_t)w * B.prS;
+#pragma unroll
+    for (int q = 0; q < COST_J0; ++q) {
+      const int c = psub + 8 * q;
+      j0v[q] = (prow < n && c < n) ? J0[(size_t)prow * n + c] : 0.0;
+    }
+    if (prow < n && psub == 0) pr0 = B.pr_r0[(size_t)w * MAXPN + prow];
+  }
+  const int nRounds = B.pu_cnt[w];
+  const int2* plane = (const int2*)B.pu_lane + (size_t)w * B.maxPR * 512;
+  int2 rec0 = nRounds > 0 ? plane[tid] : int2{-1, 0}, rec1 = nRounds > 1 ? plane[512 + tid] : int2{-1, 0};
+  const int2* ltab = (const int2*)B.ll_tab + (size_t)w * B.llSlots;
+  const int npass = B.ll_np[w];
+  const int2 lrec0 = npass > 0 ? ltab[tid] : int2{-1, 0};
   __syncthreads();
   double cost = 0.0;
-  const int n = B.pr_n[w];
   if (n > 0) {
-    const int nb = B.pr_nb[w];
     if (tid < nb) {
-      int kind = B.pr_kind[(size_t)w * MAXPB + tid], fr = B.pr_frame[(size_t)w * MAXPB + tid];
-      int idx = B.pr_idx[(size_t)w * MAXPB + tid];
-      const double* x = kind == 0 ? xp + 7 * fr : kind == 1 ? xs + 9 * fr : xp + 77;
+      const double* x = pkind == 0 ? xp + 7 * pfr : pkind == 1 ? xs + 9 * pfr : xp + 77;
       double dx[9];
-      prior_block_dx(kind, x, B.pr_x0 + ((size_t)w * MAXPB + tid) * 9, dx);
-      int ls = kind == 1 ? 9 : 6;
-      for (int k = 0; k < ls; ++k) prdx[idx + k] = dx[k];
-    }
-    __syncthreads();
-    const double* J0 = B.pr_J0 + (size_t)w * B.prS;
-    for (int r = tid >> 3; r < n; r += T >> 3) {   // eight lanes per row of J0 (coalesced), loads unrolled
-      const int sub = tid & 7;
-      double s = 0;
-#pragma unroll 4
-      for (int c = sub; c < n; c += 8) s += J0[(size_t)r * n + c] * prdx[c];
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-      if (sub == 0) {
-        s += B.pr_r0[(size_t)w * MAXPN + r];
-        cost += 0.5 * s * s;
-      }
+      prior_block_dx(pkind, x, px0, dx);
+      const int ls = pkind == 1 ? 9 : 6;
+      for (int k = 0; k < ls; ++k) prdx[pidx + k] = dx[k];
     }
   }
   // IMU, cost only: the raw residuals by one lane per factor, to LDS; their whitening S r by one lane per (factor, row) after
-  // the visual factors.  (One lane doing both read the 120 entries of S from HBM in a dependent loop while the other 63
-  // lanes of its wave -- and the block sum -- waited.)
-  __shared__ double imu_raw[10 * 15];
-  __shared__ int imu_on[10];
+  // the visual factors
   if (tid >= 64 && tid < 74) {
     const int j = tid - 64 + 1;
-    const DevPreint& dp = B.pre[(size_t)w * NF + j];
+    const DevPreint& dp = *(const DevPreint*)(plds + COST_PRE_LDS * (j - 1));   // (only the staged leading part is read)
     const bool on = !(dp.sum_dt > 10.0);
     imu_on[j - 1] = on ? 1 : 0;
     if (on) {
@@ -969,50 +988,101 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
   }
   const double hub = B.opt.huber_delta;
   const double* xe = xp + 77;
-  // one lane per factor (a lane per track would serialise 5 point / 6 line evaluations behind each other)
-  for (int it = tid; it < nP * (NF - 1); it += T) {
-    const int p = it % nP, k = 1 + it / nP;
-    const size_t pi = (size_t)w * B.maxP + p;
-    const int no = B.pt_nobs[pi];
-    if (k >= no) continue;
-    const int s = B.pt_start[pi], off = B.pt_off[pi];
-    const double lam = B.invd_c[pi];
-    const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + off) * 3;
-    const double* oj = o0 + 3 * k;
+  // one lane per factor.  Data of the first two point rounds and the first line pass: one batch of loads
+  auto pt_load = [&](const int2 rec, double* d) {
+    const bool has = rec.x >= 0;
+    const int p = has ? rec.x & 0xffff : 0, k = has ? (rec.x >> 16) & 15 : 0;
+    const double* o0 = B.pt_obs + ((size_t)w * B.maxPO + (has ? rec.y : 0)) * 3;
+    d[0] = B.invd_c[(size_t)w * B.maxP + p];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { d[1 + q] = o0[q]; d[4 + q] = o0[3 * k + q]; }
+  };
+  auto pt_eval = [&](const int2 rec, const double* d) {
+    if (rec.x < 0) return;
+    const int k = (rec.x >> 16) & 15, s = rec.x >> 20;
     double r[2], sc;
-    projection_factor(xp + 7 * s, xp + 7 * (s + k), xe, lam, V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]},
+    projection_factor(xp + 7 * s, xp + 7 * (s + k), xe, d[0], V3{d[1], d[2], d[3]}, V3{d[4], d[5], d[6]},
                       B.opt.sqrt_info_point, r, false, nullptr, nullptr, nullptr, nullptr);
     cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
-  }
-  {
-    const int nLO = B.nLO[w];
-    const int* lo_ln = B.lo_ln + (size_t)w * B.maxLO;
-    for (int o = T - 1 - tid; o < nLO; o += T) {
-      const int l = lo_ln[o];
-      const size_t li = (size_t)w * B.maxL + l;
-      const int k = o - B.ln_off[li];
-      const double* ob = B.ln_obs + ((size_t)w * B.maxLO + o) * 8;
-      LineCtx c = line_ctx(xp + 7 * (B.ln_start[li] + k), xe, B.orth_c + li * 4);
-      double r[2], sc;
-      line_factor_res(c, ob, B.opt.sqrt_info_line, r, nullptr);
+  };
+  auto ln_load = [&](const int2 lr, double* ob, double* orth) {
+    const int o = lr.x >= 0 ? lr.x : 0, l = lr.x >= 0 ? lr.y & 0xffff : 0;
+    const double* po = B.ln_obs + ((size_t)w * B.maxLO + o) * 8;
+    const double* pq = B.orth_c + ((size_t)w * B.maxL + l) * 4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ob[q] = po[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) orth[q] = pq[q];
+  };
+  auto ln_eval = [&](const int2 lr, const double* ob, const double* orth) {
+    if (lr.x < 0) return;
+    const int k = (lr.y >> 16) & 15, s = lr.y >> 20;
+    LineCtx c = line_ctx(xp + 7 * (s + k), xe, orth);
+    double r[2], sc;
+    line_factor_res(c, ob, B.opt.sqrt_info_line, r, nullptr);
+    cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
+    if (ob[7] == 1.0) {
+      vp_factor_res(c, ob + 4, B.opt.sqrt_info_vp, r, nullptr);
       cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
-      if (ob[7] == 1.0) {
-        vp_factor_res(c, ob + 4, B.opt.sqrt_info_vp, r, nullptr);
-        cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
+    }
+  };
+  double pd0[7], pd1[7], lob[8], lor[4];
+  pt_load(rec0, pd0);
+  pt_load(rec1, pd1);
+  __syncthreads();      // prdx
+  if (n > 0) {
+    // r = r0 + J0 dx
+    if (prow < n) {
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < COST_J0; ++q) {
+        const int c = psub + 8 * q;
+        s += j0v[q] * prdx[c < n ? c : 0];       // (j0v is zero beyond the row)
+      }
+      if (n > 8 * COST_J0) {
+        const double* J0 = B.pr_J0 + (size_t)w * B.prS;
+        for (int c = psub + 8 * COST_J0; c < n; c += 8) s += J0[(size_t)prow * n + c] * prdx[c];
+      }
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      if (psub == 0) {
+        s += pr0;
+        cost += 0.5 * s * s;
+      }
+    }
+    for (int r = prow + (T >> 3); r < n; r += T >> 3) {      // priors of more than 64 rows (none in the reference's windows)
+      const double* J0 = B.pr_J0 + (size_t)w * B.prS;
+      double s = 0;
+      for (int c = psub; c < n; c += 8) s += J0[(size_t)r * n + c] * prdx[c];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      if (psub == 0) {
+        s += B.pr_r0[(size_t)w * MAXPN + r];
+        cost += 0.5 * s * s;
       }
     }
   }
+  ln_load(lrec0, lob, lor);      // (in flight behind the point factors)
+  pt_eval(rec0, pd0);
+  pt_eval(rec1, pd1);
+  ln_eval(lrec0, lob, lor);
+  for (int round = 2; round < nRounds; ++round) {
+    const int2 rec = plane[round * 512 + tid];
+    pt_load(rec, pd0);
+    pt_eval(rec, pd0);
+  }
+  for (int pass = 1; pass < npass; ++pass) {
+    const int2 lr = ltab[pass * T + tid];
+    ln_load(lr, lob, lor);
+    ln_eval(lr, lob, lor);
+  }
+  (void)nP; (void)nL;
   __syncthreads();
   if (tid < 150) {
     const int f = tid / 15, a = tid - 15 * f;
     if (imu_on[f]) {
-      const double* S = B.pre[(size_t)w * NF + f + 1].sqrt_info + a * 15;
-      double sv[15];
-#pragma unroll
-      for (int k = 0; k < 15; ++k) sv[k] = k >= a ? S[k] : 0.0;
+      const double* S = plds + COST_PRE_LDS * f + PRE_LDS + a * 15;
       double v = 0;
 #pragma unroll
-      for (int k = 0; k < 15; ++k) if (k >= a) v += sv[k] * imu_raw[15 * f + k];   // (same order of the terms as before)
+      for (int k = 0; k < 15; ++k) if (k >= a) v += S[k] * imu_raw[15 * f + k];
       cost += 0.5 * v * v;
     }
   }

@@ -96,7 +96,7 @@ struct DevBatch {
   // lane layout of the line phase of k_lin: every wave holds whole tracks, k-major.  Slot pass * 512 + wave * 64 + k * llNLW + i
   // = observation k of the i-th line of that wave (index into ln_obs) or -1; lines sorted by start frame.  llK = longest
   // line track of the batch, llNLW = 64 / llK lines per wave, ll_np[w] passes of 8 waves.
-  int *ll_tab, *ll_np;                           // [W][llSlots] ; [W]
+  int *ll_tab, *ll_np;                           // [W][llSlots][2] (observation, line | k << 16 | start << 20) ; [W]
   int llNLW, llK, llSlots;
   int *ln_removed;                               // [W][maxL] 1 = erased by removeLineOutlier (k_gauge)
   int *ln_tri;                                   // [W][maxL] lineFeaturePerId::is_triangulation (k_triangulate)

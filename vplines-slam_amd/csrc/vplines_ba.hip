@@ -217,7 +217,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   AL(ln_start, W * B.maxL); AL(ln_nobs, W * B.maxL); AL(ln_off, W * B.maxL); AL(ln_obs, W * B.maxLO * 8);
   AL(nLO, W); AL(lo_ln, W * B.maxLO);
   B.llSlots = 512 * ((B.maxL + 8 * (64 / NF) - 1) / (8 * (64 / NF)));   // worst case: 11-frame tracks, 5 lines per wave
-  AL(ll_tab, W * B.llSlots); AL(ll_np, W);
+  AL(ll_tab, W * B.llSlots * 2); AL(ll_np, W);
   AL(pre, W * NF);
   AL(pr_n, W); AL(pr_nb, W); AL(pr_kind, W * MAXPB); AL(pr_frame, W * MAXPB); AL(pr_idx, W * MAXPB);
   AL(pr_x0, W * MAXPB * 9); AL(pr_J0, W * MAXPN * MAXPN); AL(pr_r0, W * MAXPN); AL(pr_H, W * MAXPN * MAXPN); AL(pr_g0, W * MAXPN);
@@ -473,7 +473,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   std::unique_ptr<int[]> pu_lane(new int[W * B.maxPR * 1024]), pu_sub(new int[W * B.maxPR * 512]);
   std::vector<int> pu_cnt(W, 0), pu_cnt0(W, 0);
   std::vector<int> sk_tab(W * B.maxKS * 4, 0), sk_wave(W * 8 * SK_WSTRIDE, -1), path(W, 0);
-  std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0), ll_tab(W * B.llSlots, -1), ll_np(W, 0);
+  std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0), ll_tab(W * B.llSlots * 2, -1), ll_np(W, 0);
   std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
   std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
   std::vector<DevPreint> pre(W * NF);
@@ -658,7 +658,11 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       for (int q = 0; q < nl; ++q) {
         const int dl = ord[q], pass = q / perPass, wave = (q % perPass) / NLW, i = q % NLW;
         const int no = std::min(ln_nobs[w * B.maxL + dl], (int)NF);
-        for (int k = 0; k < no; ++k) ll_tab[w * B.llSlots + pass * 512 + wave * 64 + k * NLW + i] = ln_off[w * B.maxL + dl] + k;
+        for (int k = 0; k < no; ++k) {      // (observation, line | k << 16 | start frame << 20): everything a lane's loads need
+          int* e = &ll_tab[2 * ((size_t)w * B.llSlots + pass * 512 + wave * 64 + k * NLW + i)];
+          e[0] = ln_off[w * B.maxL + dl] + k;
+          e[1] = dl | k << 16 | ln_start[w * B.maxL + dl] << 20;
+        }
       }
     }
     orth_in[w] = v.line_orth ? 1 : 0;
