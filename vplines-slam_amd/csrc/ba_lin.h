@@ -109,6 +109,14 @@ __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double
     Plk Lw = plk_to_pose(Lc, Rwc, twc);
     plk_to_orth(Lw, B.orth + ((size_t)w * B.maxL + l) * 4);
   }
+  // world Pluecker coordinates of every line's orthonormal parameters (what the factors evaluate, line_parameterization /
+  // utility orth_to_plk), once per line: a lane writes the parameters above and reads them back itself
+  for (int l = tid; l < B.nL[w]; l += blockDim.x) {
+    const size_t li = (size_t)w * B.maxL + l;
+    const Plk Lw = orth_to_plk(B.orth + li * 4);
+    double* o = B.lw + li * 6;
+    o[0] = Lw.n.x; o[1] = Lw.n.y; o[2] = Lw.n.z; o[3] = Lw.v.x; o[4] = Lw.v.y; o[5] = Lw.v.z;
+  }
   // (d) prior: H = J0^T J0 (J0 staged in LDS) and the column map
   if (n > 0) {
     const double* J0 = B.pr_J0 + (size_t)w * B.prS;
@@ -588,7 +596,10 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
       const bool act = inb && (!MARG || (s == 0 && k >= 1 && !B.ln_removed[li]));
       const double* ob = B.ln_obs + ((size_t)w * B.maxLO + (inb ? o : 0)) * 8;
       LineCtx c;
-      if (act) c = line_ctx(xp + 7 * j, xe, B.orth + li * 4);
+      if (act) {
+        const double* lw = B.lw + li * 6;     // orth_to_plk(B.orth) of this line (k_prep / k_cost keep it current)
+        c = line_ctx_plk(xp + 7 * j, xe, Plk{V3{lw[0], lw[1], lw[2]}, V3{lw[3], lw[4], lw[5]}});
+      }
       double Wj[24];
 #pragma unroll
       for (int q = 0; q < 24; ++q) Wj[q] = 0.0;

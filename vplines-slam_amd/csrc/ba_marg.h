@@ -70,6 +70,11 @@ __device__ __forceinline__ void gauge_body(const DevBatch& B, const int w) {
     // vector2double() before the marginalisation: getLineOrthVector on the updated state
     Plk Lw2 = plk_to_pose(Lc, Rwc, twc);
     plk_to_orth(Lw2, B.orth + li * 4);
+    {   // the marginalisation pass of k_lin reads the Pluecker image of these parameters (B.lw)
+      const Plk Lq = orth_to_plk(B.orth + li * 4);
+      double* o = B.lw + li * 6;
+      o[0] = Lq.n.x; o[1] = Lq.n.y; o[2] = Lq.n.z; o[3] = Lq.v.x; o[4] = Lq.v.y; o[5] = Lq.v.z;
+    }
 
     // FeatureManager::removeLineOutlier (feature_manager.cpp:702-798) on the gauge-fixed state
     int erase = 0;

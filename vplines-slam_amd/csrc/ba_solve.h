@@ -882,6 +882,9 @@ __device__ __forceinline__ void solve_body(const DevBatch& B, const int w, doubl
       B.orth_c[li * 4 + k] = out[k];
       sn += (x - out[k]) * (x - out[k]); xn += x * x;
     }
+    const Plk Lc_ = orth_to_plk(out);     // the candidate's world Pluecker line, once per line (B.lw_c)
+    double* lwc = B.lw_c + li * 6;
+    lwc[0] = Lc_.n.x; lwc[1] = Lc_.n.y; lwc[2] = Lc_.n.z; lwc[3] = Lc_.v.x; lwc[4] = Lc_.v.y; lwc[5] = Lc_.v.z;
   }
   sn = block_sum(sn, red);
   xn = block_sum(xn, red);
@@ -1008,16 +1011,16 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
   auto ln_load = [&](const int2 lr, double* ob, double* orth) {
     const int o = lr.x >= 0 ? lr.x : 0, l = lr.x >= 0 ? lr.y & 0xffff : 0;
     const double* po = B.ln_obs + ((size_t)w * B.maxLO + o) * 8;
-    const double* pq = B.orth_c + ((size_t)w * B.maxL + l) * 4;
+    const double* pq = B.lw_c + ((size_t)w * B.maxL + l) * 6;
 #pragma unroll
     for (int q = 0; q < 8; ++q) ob[q] = po[q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) orth[q] = pq[q];
+    for (int q = 0; q < 6; ++q) orth[q] = pq[q];
   };
   auto ln_eval = [&](const int2 lr, const double* ob, const double* orth) {
     if (lr.x < 0) return;
     const int k = (lr.y >> 16) & 15, s = lr.y >> 20;
-    LineCtx c = line_ctx(xp + 7 * (s + k), xe, orth);
+    LineCtx c = line_ctx_plk(xp + 7 * (s + k), xe, Plk{V3{orth[0], orth[1], orth[2]}, V3{orth[3], orth[4], orth[5]}});
     double r[2], sc;
     line_factor_res(c, ob, B.opt.sqrt_info_line, r, nullptr);
     cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
@@ -1026,7 +1029,7 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
       cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
     }
   };
-  double pd0[7], pd1[7], lob[8], lor[4];
+  double pd0[7], pd1[7], lob[8], lor[6];
   pt_load(rec0, pd0);
   pt_load(rec1, pd1);
   __syncthreads();      // prdx
@@ -1127,6 +1130,7 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
     for (int i = tid; i < 7; i += T) B.ex[(size_t)w * 7 + i] = B.ex_c[(size_t)w * 7 + i];
     for (int p = tid; p < nP; p += T) B.invd[(size_t)w * B.maxP + p] = B.invd_c[(size_t)w * B.maxP + p];
     for (int i = tid; i < 4 * nL; i += T) B.orth[(size_t)w * B.maxL * 4 + i] = B.orth_c[(size_t)w * B.maxL * 4 + i];
+    for (int i = tid; i < 6 * nL; i += T) B.lw[(size_t)w * B.maxL * 6 + i] = B.lw_c[(size_t)w * B.maxL * 6 + i];
   }
 }
 // two workgroups per CU (4 waves per SIMD, <= 128 VGPRs): the kernel is a latency chain per lane, occupancy is what helps

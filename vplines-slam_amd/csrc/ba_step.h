@@ -1262,6 +1262,9 @@ __device__ __forceinline__ void back_body(const DevBatch& B, const int w, double
       B.orth_c[li * 4 + k] = out[k];
       sn += (x - out[k]) * (x - out[k]); xn += x * x;
     }
+    const Plk Lc_ = orth_to_plk(out);     // the candidate's world Pluecker line, once per line (B.lw_c)
+    double* lwc = B.lw_c + li * 6;
+    lwc[0] = Lc_.n.x; lwc[1] = Lc_.n.y; lwc[2] = Lc_.n.z; lwc[3] = Lc_.v.x; lwc[4] = Lc_.v.y; lwc[5] = Lc_.v.z;
   }
   sn = block_sum(sn, red);
   xn = block_sum(xn, red);

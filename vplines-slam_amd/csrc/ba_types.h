@@ -70,6 +70,10 @@ struct DevBatch {
   // ---- states: current x, candidate, uploaded initial copy ----
   double *pose, *sb, *ex, *invd, *orth;          // [W][11][7] [W][11][9] [W][7] [W][maxP] [W][maxL][4]
   double *pose_c, *sb_c, *ex_c, *invd_c, *orth_c;
+  // world Pluecker coordinates (n, v) of orth / orth_c, [W][maxL][6]: written wherever the orthonormal parameters are (k_prep,
+  // the candidate of k_back / k_solve, k_cost's copy on acceptance) -- the factors of a line's <= 11 observations, in k_lin
+  // and in k_cost, read them instead of evaluating eight sin / cos each
+  double *lw, *lw_c;
   double *pose_0, *sb_0, *ex_0, *invd_0, *plk_0; // as uploaded (vpl_ba_reset_state)
   double *plk;                                   // [W][maxL][6] start-camera-frame Pluecker (in/out)
   double *gauge;                                 // [W][4]: yaw of R0 before (deg), P0 before

@@ -355,16 +355,19 @@ struct LineCtx {
   M3 Rwb, Rbc;
   V3 twb, tbc;
 };
-VPL_HD LineCtx line_ctx(const double* pose, const double* ex, const double* orth) {
+VPL_HD LineCtx line_ctx_plk(const double* pose, const double* ex, const Plk& Lw) {   // world line given in Pluecker coordinates
   LineCtx c;
   c.twb = V3{pose[0], pose[1], pose[2]};
   c.Rwb = qmat(qpose(pose));
   c.tbc = V3{ex[0], ex[1], ex[2]};
   c.Rbc = qmat(qpose(ex));
-  c.Lw = orth_to_plk(orth);
+  c.Lw = Lw;
   c.Lb = plk_from_pose(c.Lw, c.Rwb, c.twb);
   c.Lc = plk_from_pose(c.Lb, c.Rbc, c.tbc);
   return c;
+}
+VPL_HD LineCtx line_ctx(const double* pose, const double* ex, const double* orth) {
+  return line_ctx_plk(pose, ex, orth_to_plk(orth));
 }
 // rows of a 2x3 matrix times 3x3 blocks -> accumulate into 2x6 / 2x4 outputs
 VPL_HD void line_chain_jac(const LineCtx& c, const double* jel, int sel, double* Jp, double* Je, double* Jo) {

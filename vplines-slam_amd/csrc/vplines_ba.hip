@@ -208,7 +208,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
 #define AL(ptr, n) if (e == hipSuccess) e = dalloc(c, &B.ptr, (size_t)(n))
 #define AL2(ptr, n) if (e == hipSuccess) e = dalloc(c, &B.ptr, (size_t)(n))
   AL(pose, W * 77); AL(sb, W * 99); AL(ex, W * 7); AL(invd, W * B.maxP); AL(orth, W * B.maxL * 4);
-  AL(pose_c, W * 77); AL(sb_c, W * 99); AL(ex_c, W * 7); AL(invd_c, W * B.maxP); AL(orth_c, W * B.maxL * 4);
+  AL(pose_c, W * 77); AL(sb_c, W * 99); AL(ex_c, W * 7); AL(invd_c, W * B.maxP); AL(orth_c, W * B.maxL * 4); AL(lw, W * B.maxL * 6); AL(lw_c, W * B.maxL * 6);
   AL(pose_0, W * 77); AL(sb_0, W * 99); AL(ex_0, W * 7); AL(invd_0, W * B.maxP); AL(plk_0, W * B.maxL * 6);
   AL(plk, W * B.maxL * 6); AL(gauge, W * 4); AL(fail_ref, W * 13); AL(orth_in, W);
   AL(nP, W); AL(nL, W);
