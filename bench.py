@@ -37,7 +37,9 @@ def algorithmic_bytes(P, L, n_prior, obs_p, obs_l):
     reads = 8 * ((11 * 16 + 7 + P + 4 * L) + (6 * F_p + 4 * F_l + 3 * F_v) + 10 * 287 + (n_prior ** 2 + n_prior + 86))
     writes = 8 * ((171 * 171 + 171) + (2 * P + 20 * L) + (42 * P + 168 * L))
     lin_out = 8 * ((171 * 172 // 2 + 171) + (2 * P + 20 * L) + (42 * P + 168 * L))
-    k_lin = reads + lin_out
+    # (k_lin2: the point work-group hands its part of the visual Hessian | gradient, 78 x 36 + 72 doubles, to the window's
+    # other work-group through HBM: written once, read once; the lines' world Pluecker coordinates are 6 doubles, not 4)
+    k_lin = reads + lin_out + 8 * (2 * (78 * 36 + 72) + 2 * L)
     # the trust-region step (k_schur + k_chol + k_back, or k_solve on the general path) of a window that computes a new
     # Gauss-Newton step reads the linearisation once; one that re-uses the step of a rejected iteration moves vectors only
     k_solve = lin_out + 8 * 2 * nfull
@@ -59,7 +61,7 @@ def _pmc_file(name):
 def _pmc_keys(kernel):
     if kernel == "k_step":
         return ["k_schur<3>", "k_chol", "k_solve", "k_back"]
-    return [{"k_lin": "k_lin<0>"}.get(kernel, kernel)]
+    return [{"k_lin": "k_lin2"}.get(kernel, kernel)]      # (k_lin2: the solve pass, two work-groups per window)
 
 
 def pmc_traffic(kernel, nW, P, L, which="total"):

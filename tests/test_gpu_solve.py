@@ -584,6 +584,34 @@ def test_general_path_matches_the_three_kernel_path(monkeypatch):
         assert dp <= 1e-6 and dr <= 1e-8, (dp, dr)
 
 
+def test_linearisation_in_one_or_two_work_groups_gives_the_same_bits(monkeypatch):
+    """k_lin2 linearises a window in two work-groups (point factors | everything else) while two CUs per linearising window
+    are to be had, and in one otherwise -- the choice depends on how many windows of the batch accepted their last step, so
+    it must not show in the results: VPL_BA_LIN_SPLIT=0 / 1 force either mode for the whole solve; states, costs and the
+    new priors have to be identical bit for bit (the library is built with -ffp-contract=on: the same factor code rounds
+    the same way whichever kernel body it is inlined into), with and without a prior."""
+    ws, opt = make_windows(12, 200, 80, True, seed0=410)
+    out = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VPL_BA_LIN_SPLIT", mode)
+        ctx = v.Context(device=0, max_windows=12, max_points=200, max_point_obs=1200, max_lines=80, max_line_obs=480)
+        monkeypatch.delenv("VPL_BA_LIN_SPLIT")
+        wa = [w.copy() for w in ws]
+        pri, rep = ctx.solve_windows(wa, opt)
+        keep = []
+        wb = [w.copy() for w in ws]              # second solve WITH the priors of the first
+        for i, w in enumerate(wb):
+            p = v.Prior(); C.memmove(C.byref(p), C.byref(pri[i]), C.sizeof(p)); keep.append(p); w.prior = p
+        pri2, rep2 = ctx.solve_windows(wb, opt)
+        out.append((v.shard.pack_states(wa), v.shard.pack_states(wb), [r.final_cost for r in rep] + [r.final_cost for r in rep2],
+                    [p.J().copy() for p in pri2]))
+        ctx.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2]
+    for Ja, Jb in zip(out[0][3], out[1][3]):
+        assert np.array_equal(Ja, Jb)
+
+
 def test_prior_with_speed_bias_of_a_later_frame_takes_the_general_path(gpu_ctx):
     """The reference's marginalisation only ever leaves speed/bias 0 in the prior; the interface allows any block table.  A
     prior that ties speed/bias 3 is outside k_chol's elimination order (ba_step.h) and is routed to k_solve at upload."""

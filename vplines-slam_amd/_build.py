@@ -40,7 +40,7 @@ def build_hip(force=False, verbose=False):
     deps.append(os.path.join(ROOT, "include", "vplines_frontend.h"))
     if not force and not _newer(HIP_LIB, deps):
         return HIP_LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ffp-contract=on",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_LIB] + srcs
     if os.environ.get("VPL_STAMPS"):
         cmd.insert(1, "-DVPL_STAMPS")

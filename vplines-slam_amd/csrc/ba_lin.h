@@ -164,6 +164,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(DevBatch B, int nstage) {
 // The vis Hessian in LDS: lower block triangle of 12 x 12 blocks of 6 x 6 (frames 0..10, extrinsic), every block stored
 // full -- 78 blocks = 2808 doubles instead of the 72 x 72 square.  Entry (r, c), r >= c in vis indices:
 constexpr int HV_DOUBLES = 78 * 36;
+constexpr int LIN_PART = 78 * 36 + 72 + 8;      // B.lin_part per window: visual Hessian | gradient | cost of the point factors (k_lin2)
 __host__ __device__ __forceinline__ int hvi(int r, int c) {
   const int br = r / 6, bc = c / 6;
   return 36 * (br * (br + 1) / 2 + bc) + 6 * (r - 6 * br) + (c - 6 * bc);
@@ -188,15 +189,24 @@ inline void lin_asm_entry(int r, int c, int* out) {
 
 // MODE 0: solve linearisation; 1: MARGIN_OLD assembly (prior + IMU(0,1) + landmarks that start in frame 0);
 // 2: MARGIN_SECOND_NEW assembly (the prior alone, estimator.cpp:1387-1405)
-template <int MODE>
+// ROLE 0: the whole linearisation in one work-group (the marginalisation passes).  The solve pass runs as TWO work-groups per
+// window, side by side on two CUs: ROLE 1 = the point factors (their per-track sums go to HBM as before, their part of the
+// visual Hessian / gradient to B.lin_part), ROLE 2 = prior, line / VP factors, IMU factors and the assembly, which adds ROLE
+// 1's part in before it reads the visual Hessian.  In the launches where a few windows linearise (most of a solve: the step
+// of the others was rejected) more than half of the CUs were idle while one work-group per window walked the phases one
+// after the other; with every CU busy the split costs nothing (the same work in twice as many work-groups).  ROLE 2's
+// work-group follows ROLE 1's in dispatch order, so the one it waits for is always resident or done.
+template <int MODE, int ROLE>
 __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double* sm) {
   constexpr bool MARG = MODE != 0;
   constexpr bool PRIOR_ONLY = MODE == 2;
+  constexpr bool DO_PTS = ROLE != 2, DO_REST = ROLE != 1;
+  static_assert(ROLE == 0 || MODE == 0, "the marginalisation passes are one work-group");
   const int tid = threadIdx.x, T = LIN_THREADS;
   TrState* tr = &B.tr[w];
   if (!MARG) {
     if (tr->status != 0 || tr->fresh_lin) return;
-    count_active(B, 0);
+    if (DO_REST) count_active(B, 0);
   }
   if (PRIOR_ONLY && B.mg_n[w] == 0) return;
   double* Hv = sm;                 // HV_DOUBLES, see hvi()
@@ -226,12 +236,14 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   // the marginalisation evaluates every block, constant or not (marginalization_factor.cpp:3-69)
   const bool ex_free = MARG || B.opt.estimate_extrinsic != 0;
   for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] = 0.0;
-  for (int i = tid; i < 14 * PST; i += T) pacc[i] = 0.0;
+  if (DO_PTS) for (int i = tid; i < 14 * PST; i += T) pacc[i] = 0.0;
   for (int i = tid; i < 84; i += T) xp[i] = i < 77 ? B.pose[(size_t)w * 77 + i] : B.ex[(size_t)w * 7 + (i - 77)];
-  for (int i = tid; i < 99; i += T) xs[i] = B.sb[(size_t)w * 99 + i];
-  for (int i = tid; i < 10 * PRE_LDS; i += T) {   // (the IMU phase is then free of global round trips)
-    const int f = i / PRE_LDS;
-    plds[i] = ((const double*)&B.pre[(size_t)w * NF + f + 1])[i - PRE_LDS * f];
+  if (DO_REST) {
+    for (int i = tid; i < 99; i += T) xs[i] = B.sb[(size_t)w * 99 + i];
+    for (int i = tid; i < 10 * PRE_LDS; i += T) {   // (the IMU phase is then free of global round trips)
+      const int f = i / PRE_LDS;
+      plds[i] = ((const double*)&B.pre[(size_t)w * NF + f + 1])[i - PRE_LDS * f];
+    }
   }
   for (int i = tid; i < NC; i += T) invmap[i] = -1;
   if (tid < 5) tick[tid] = 0;
@@ -239,7 +251,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   // index map, and this lane's part of the rows of J0 and H = J0^T J0 (eight lanes per row, the first LIN_PJ columns of
   // each) -- the phase was three dependent round trips (table -> barrier -> rows), each ~3 k cycles with every CU in it.
   constexpr int LIN_PJ = 6;
-  const int n = B.pr_n[w], nb = n > 0 ? B.pr_nb[w] : 0;
+  const int n = DO_REST ? B.pr_n[w] : 0, nb = n > 0 ? B.pr_nb[w] : 0;
   const int prow = tid >> 3, psub = tid & 7;
   int pkind = 0, pfr = 0, pidx = 0, pmap = -1;
   double px0[9], pj0[LIN_PJ], phv[LIN_PJ], r0r = 0.0, g0r = 0.0;
@@ -314,6 +326,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     }
   }
 
+  double costp = 0.0;      // this thread's share of the point factors' cost, kept apart from the rest (see below)
   VPL_STAMP(B, w, 18);
   // ---- visual factors ----------------------------------------------------------------------
   // Wave-uniform rounds: in every round each lane linearises (at most) one factor; the extrinsic
@@ -329,11 +342,13 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   if (B.wfill) {
     // (the marginalisation pass only ever reads the rows of the tracks that start in frame 0)
     double* Wp0 = B.Wp + (size_t)w * B.maxP * WS;
-    for (int i = tid; i < nP * WS; i += T)
-      if (!MARG || B.pt_start[(size_t)w * B.maxP + i / WS] == 0) Wp0[i] = 0.0;
+    if (DO_PTS)
+      for (int i = tid; i < nP * WS; i += T)
+        if (!MARG || B.pt_start[(size_t)w * B.maxP + i / WS] == 0) Wp0[i] = 0.0;
     double* Wl0 = B.Wl + (size_t)w * B.maxL * 4 * WS;
-    for (int i = tid; i < nL * 4 * WS; i += T)
-      if (!MARG || B.ln_start[(size_t)w * B.maxL + i / (4 * WS)] == 0) Wl0[i] = 0.0;
+    if (DO_REST)
+      for (int i = tid; i < nL * 4 * WS; i += T)
+        if (!MARG || B.ln_start[(size_t)w * B.maxL + i / (4 * WS)] == 0) Wl0[i] = 0.0;
   } else if (MARG) {
     // uniform tracks: the one slot no factor writes is the start-frame block of the lines (their start observation is
     // skipped in this pass) -- 24 entries per line, not the 13 k entries of all rows
@@ -356,7 +371,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   // entries with the sign flipped.  The host packs the units into quarter-wave slots (pu_lane / pu_sub): a full unit takes
   // a slot, small ones share one -- 200 tracks x 5 factors are 60 full units + 30 of two tracks = 64 slots = 2 rounds of
   // the 8 waves.
-  {
+  if (DO_PTS) {
     const int wvi = tid >> 6, nwv = T >> 6;
     const int nRounds = PRIOR_ONLY ? 0 : (MARG ? B.pu_cnt0[w] : B.pu_cnt[w]);
     const int2* plane = (const int2*)B.pu_lane + (size_t)w * B.maxPR * 512;
@@ -422,7 +437,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
         projection_factor(xp + 7 * s, xp + 7 * j, xe, lam, V3{o0[0], o0[1], o0[2]}, V3{oj[0], oj[1], oj[2]},
                           B.opt.sqrt_info_point, r, true, Ji, Jj, Je, Jl);
         double sc;
-        cost += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
+        costp += 0.5 * huber(r[0] * r[0] + r[1] * r[1], hub, &sc);
         r[0] *= sc; r[1] *= sc; Jl[0] *= sc; Jl[1] *= sc;
 #pragma unroll
         for (int q = 0; q < 12; ++q) { Ji[q] *= sc; Jj[q] *= sc; Je[q] *= sc; }
@@ -549,9 +564,9 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   }
   __syncthreads();
   VPL_STAMP(B, w, 51);
-  for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] += imuJ[LIN_STAGE + i];   // second commit chain's copy (Hv | gv are contiguous)
+  if (DO_PTS) for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] += imuJ[LIN_STAGE + i];   // second commit chain's copy (Hv | gv are contiguous)
   VPL_STAMP(B, w, 50);
-  for (int p = tid; p < nP; p += T) {   // per-track sums out of LDS
+  if (DO_PTS) for (int p = tid; p < nP; p += T) {   // per-track sums out of LDS
     const size_t pi = (size_t)w * B.maxP + p;
     const double* pa = pacc + p;
     double* Wrow = B.Wp + pi * WS;
@@ -563,6 +578,23 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   VPL_STAMP(B, w, 55);
   __syncthreads();   // staging space is handed over to the IMU / line phases
   VPL_STAMP(B, w, 24);
+  // The point factors' cost is summed on its own and joins the rest in thread 0 before the final sum, in EVERY role: one
+  // work-group or two, the window's cost (and with it every accept / reject decision) is the same bits.
+  double cost_pts = 0.0;
+  if (!MARG && DO_PTS) {
+    cost_pts = block_sum(costp, red);
+  }
+  if (ROLE == 1) {
+    // this work-group's part of the visual Hessian / gradient and of the cost go to the window's other work-group with
+    // device-coherent stores (write-through; the flag follows when they have completed): no L2 write-back / invalidate,
+    // which every work-group of the XCD would pay for
+    double* part = B.lin_part + (size_t)w * LIN_PART;
+    for (int i = tid; i < HV_DOUBLES + NV; i += T) __hip_atomic_store(&part[i], sm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&part[HV_DOUBLES + NV], cost_pts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();      // (waits for every wave's stores)
+    if (tid == 0) __hip_atomic_store(&B.lin_flag[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   VPL_STAMP(B, w, 22);
   // ---- lines -----------------------------------------------------------------------------------------------------
   // One lane per (track, observation), laid out by the host table ll_tab: every wave holds WHOLE tracks, k-major --
@@ -608,11 +640,7 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 #pragma unroll
       for (int fct = 0; fct < 2; ++fct) {
         // VP factor only in the solve and only when flagged (estimator.cpp:1153, :1341-1351)
-#ifdef VPL_X_NO_VP
-        const bool fa = act && fct == 0;
-#else
         const bool fa = act && (fct == 0 || (!MARG && ob[7] == 1.0));
-#endif
         double r[2] = {0, 0}, Je[12];
 #pragma unroll
         for (int q = 0; q < 12; ++q) Je[q] = 0.0;
@@ -637,10 +665,6 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
           int t = 0;
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
-#ifdef VPL_X_NO_LA
-            for (int c2 = c0; c2 < 6; ++c2) Wj[6 * a + c2] += Jo[a] * Jp[c2] + Jo[4 + a] * Jp[6 + c2] + Je[c2] * r[0];
-            (void)la;
-#else
             lds_add(&la[10 + a], Jo[a] * r[0] + Jo[4 + a] * r[1]);
 #pragma unroll
             for (int c2 = 0; c2 <= a; ++c2, ++t) lds_add(&la[t], Jo[a] * Jo[c2] + Jo[4 + a] * Jo[4 + c2]);
@@ -649,10 +673,8 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
               Wj[6 * a + c2] += Jo[a] * Jp[c2] + Jo[4 + a] * Jp[6 + c2];
               lds_add(&la[14 + 6 * a + c2], Jo[a] * Je[c2] + Jo[4 + a] * Je[6 + c2]);
             }
-#endif
           }
           // blocks (j, j), (ext, j), g_j of this wave's partial sums
-#ifndef VPL_X_NO_HF
           t = 0;
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
@@ -664,11 +686,9 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
             for (int c2 = c0; c2 < 6; ++c2) lds_add(&Hf[21 + 6 * a + c2], Je[a] * Jp[c2] + Je[6 + a] * Jp[6 + c2]);
             lds_add(&Hf[57 + a], Jp[a] * r[0] + Jp[6 + a] * r[1]);
           }
-#endif
         }
         // extrinsic block: every factor touches it.  DPP row_shr sums inside each row of 16 lanes (VALU only), then the four
         // row leaders add to the wave's partial sums
-#ifndef VPL_X_NO_HF
         {
           const bool leader = (lane & 15) == 15;
           const int c0 = fct == 0 ? 0 : 3;
@@ -687,13 +707,8 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
             }
           }
         }
-#endif
       }
-#ifdef VPL_X_NO_WJ
-      if (act && Wj[0] == 123.456) {
-#else
       if (act) {
-#endif
         double* Wl = B.Wl + li * 4 * WS;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -894,6 +909,21 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   }
 
 
+  if (ROLE == 2) {
+    // the point factors' part (the other work-group of this window): Hv = (lines) + (points), gv likewise -- the sum the
+    // single work-group forms, in the other order of its two terms
+    if (tid == 0) {
+      while (__hip_atomic_load(&B.lin_flag[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(32);
+      __hip_atomic_store(&B.lin_flag[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const double* part = B.lin_part + (size_t)w * LIN_PART;
+    for (int i = tid; i < HV_DOUBLES + NV; i += T) sm[i] += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) cost += __hip_atomic_load(&part[HV_DOUBLES + NV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  } else if (!MARG) {
+    if (tid == 0) cost += cost_pts;
+  }
   VPL_STAMP(B, w, 20);
   // ---- assemble the packed cam Hessian and gradient in HBM -----------------------------------
   double* Hout = B.Hcc + (size_t)w * NCP;
@@ -991,7 +1021,27 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
 template <int MODE>
 __global__ __launch_bounds__(LIN_THREADS) void k_lin(DevBatch B) {
   extern __shared__ double sm[];
-  lin_body<MODE>(B, MODE == 0 ? ordered_window(B) : (int)blockIdx.x, sm);
+  lin_body<MODE, 0>(B, MODE == 0 ? ordered_window(B) : (int)blockIdx.x, sm);
+}
+// the solve pass: two work-groups per window (grid 2 nW), see lin_body
+__global__ __launch_bounds__(LIN_THREADS) void k_lin2(DevBatch B) {
+  extern __shared__ double sm[];
+  // The split pays while the two work-groups of every window that linearises find a CU each (the list k_cost made of those
+  // windows holds their number); beyond that it only adds a second round of work-groups and the hand-over: then the first
+  // nW work-groups do one whole window each, as k_lin<0> did, and the others leave (they sit at the END of the grid:
+  // interleaved with the working ones they cost a third of the launch).
+  const int nlin = B.ord_it == 0 ? B.nW : B.ord_cnt[2 * (B.ord_it & 1)];
+  if (2 * nlin > B.ncu) {
+    if ((int)blockIdx.x < B.nW) lin_body<0, 0>(B, ordered_window(B), sm);
+    return;
+  }
+  // work-groups go to the XCDs round-robin by index: blocks 16 q + x and 16 q + 8 + x (x < 8) are the two work-groups of
+  // window 8 q + x -- same XCD (one L2 between them), the point work-group first in dispatch order
+  const int b = (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7);
+  if (b >= B.nW) return;
+  const int w = __builtin_amdgcn_readfirstlane(B.ord_it == 0 ? b : B.order[(size_t)(B.ord_it & 1) * B.nW + b]);
+  if (blockIdx.x & 8) lin_body<0, 2>(B, w, sm);
+  else lin_body<0, 1>(B, w, sm);
 }
 
 // LDS of k_lin: the fixed part, then whatever is left of the budget holds the prior's J0^T J0 for the assembly (priors of up

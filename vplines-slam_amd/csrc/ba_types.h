@@ -74,6 +74,11 @@ struct DevBatch {
   // the candidate of k_back / k_solve, k_cost's copy on acceptance) -- the factors of a line's <= 11 observations, in k_lin
   // and in k_cost, read them instead of evaluating eight sin / cos each
   double *lw, *lw_c;
+  // k_lin2 (two work-groups per window): the point work-group's part of the visual Hessian | gradient [W][HV + NV], of the
+  // cost [W], and the flag that hands them over [W] (0 between launches)
+  double *lin_part, *lin_pcost;
+  int* lin_flag;
+  int ncu;                                       // compute units of the device (k_lin2 splits a window over two of them while they last)
   double *pose_0, *sb_0, *ex_0, *invd_0, *plk_0; // as uploaded (vpl_ba_reset_state)
   double *plk;                                   // [W][maxL][6] start-camera-frame Pluecker (in/out)
   double *gauge;                                 // [W][4]: yaw of R0 before (deg), P0 before

@@ -200,6 +200,12 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   std::memset(&B, 0, sizeof(B));
   B.maxP = c->maxP; B.maxPO = c->maxPO; B.maxL = c->maxL; B.maxLO = c->maxLO;
   B.nfull = NC + B.maxP + 4 * B.maxL;
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
+    if (const char* sv = std::getenv("VPL_BA_LIN_SPLIT")) ncu = std::atoi(sv) ? 1 << 30 : 0;   // 1: always two work-groups per window, 0: never (A/B runs, tests)
+    B.ncu = ncu;
+  }
   // point work units of k_lin: (start frame, chunk of <= 16 tracks, observation); a unit needs at most one quarter-wave slot
   // slots <= factor lanes / 16 + one partial unit per (start, k) pair; the halves of the work-group differ by less than one chunk
   B.maxPR = std::min((B.maxP / 16 + NF) * (NF - 1), B.maxPO / 16 + NF * (NF - 1) / 2) / 32 + 2;
@@ -209,6 +215,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
 #define AL2(ptr, n) if (e == hipSuccess) e = dalloc(c, &B.ptr, (size_t)(n))
   AL(pose, W * 77); AL(sb, W * 99); AL(ex, W * 7); AL(invd, W * B.maxP); AL(orth, W * B.maxL * 4);
   AL(pose_c, W * 77); AL(sb_c, W * 99); AL(ex_c, W * 7); AL(invd_c, W * B.maxP); AL(orth_c, W * B.maxL * 4); AL(lw, W * B.maxL * 6); AL(lw_c, W * B.maxL * 6);
+  AL(lin_part, W * LIN_PART); AL(lin_pcost, W); AL(lin_flag, W);
   AL(pose_0, W * 77); AL(sb_0, W * 99); AL(ex_0, W * 7); AL(invd_0, W * B.maxP); AL(plk_0, W * B.maxL * 6);
   AL(plk, W * B.maxL * 6); AL(gauge, W * 4); AL(fail_ref, W * 13); AL(orth_in, W);
   AL(nP, W); AL(nL, W);
@@ -271,7 +278,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   static size_t lin_max = 0, solve_max = 0;
   lin_max = std::max(lin_max, lin_smem(c->maxP, c->maxL));
   solve_max = std::max(solve_max, solve_smem(c->maxP, c->maxL));
-  hipFuncSetAttribute((const void*)k_lin<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_max);
+  hipFuncSetAttribute((const void*)k_lin2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_max);
   hipFuncSetAttribute((const void*)k_lin<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_max);
   hipFuncSetAttribute((const void*)k_lin<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_max);
   hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_max);
@@ -1022,7 +1029,7 @@ static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
   const dim3 grid(nw);
   { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(PREP_THREADS), prep_smem(c->maxPriorN), s, B, std::min(c->maxPriorN, PREP_NMAX)); }
   ++B.launch;
-  { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
+  { KTimer t(c, "k_lin"); hipLaunchKernelGGL(k_lin2, dim3(16 * ((nw + 7) / 8)), dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
   ++B.launch;
   for (int it = 0; it < c->opt.num_iterations; ++it) {
     B.ord_it = it;      // k_solve / k_cost of iteration `it` walk order[it & 1]; k_cost fills order[(it + 1) & 1]
@@ -1043,7 +1050,7 @@ static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
     if (it + 1 < c->opt.num_iterations) {
       B.ord_it = it + 1;
       KTimer t(c, "k_lin");
-      hipLaunchKernelGGL(k_lin<0>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B);
+      hipLaunchKernelGGL(k_lin2, dim3(16 * ((nw + 7) / 8)), dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B);
     }
     if (it + 1 < c->opt.num_iterations) ++B.launch;
   }
