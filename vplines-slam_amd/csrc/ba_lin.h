@@ -409,6 +409,48 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     // A global round trip costs ~3 k cycles (1.3 us) when all CUs are in this phase together: the lane records (track, k, start frame,
     // observation offset -- everything the loads of the factor need) and the unit table of round r + 1 are fetched while
     // round r is worked on, so that a round starts one round trip deep, not three.
+    // Commit of one unit's tile.  Accumulator entry (row a = kk + 4 v, col b = m16; the tile is symmetric and every (a, b) sits
+    // in exactly one lane) -> LDS Hessian / gradient, in ticket order.  Tile columns: 0..2 s position, 3..5 s rotation, 6..8 j
+    // rotation, 9..14 extrinsic, 15 residual.  Four adds of the lower triangle (the residual row goes to the gradient, which
+    // follows the Hessian in LDS); the lanes of rows 0..2 (kk < 3, v = 0) hold T[q][c] for every column c and add it a second
+    // time, negated, as the entry of j's position row / column q (and a third time for the (j pos, j pos) block).  All indices
+    // are computed before the ticket is waited for: the critical section is six LDS adds.
+    auto commit = [&](const v4d_lin& acc, const int desc, const int seq) {
+      const int sq = desc & 15, jq = (desc >> 4) & 15;
+      const int tS = 36 * (sq * (sq + 1) / 2), tJ = 36 * (jq * (jq + 1) / 2), tE = 36 * 66, cS = 36 * sq, cJ = 36 * jq, cE = 36 * 11;
+      const int colbase = (b_cls == 0 ? cS : (b_cls == 1 ? cJ : cE)) + b_off;
+      int idx[4];
+      bool on[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int a = kk + 4 * v;
+        const int a_cls = a < 6 ? 0 : (a < 9 ? 1 : (a < 15 ? 2 : 3));
+        const int a_off = a < 6 ? a : (a < 9 ? a - 3 : a - 9);
+        idx[v] = (a_cls == 0 ? tS : (a_cls == 1 ? tJ : tE)) + 6 * a_off + colbase;
+        on[v] = a >= m16;
+        if (a_cls == 3) {
+          idx[v] = HV_DOUBLES + (b_cls == 0 ? 6 * sq : (b_cls == 1 ? 6 * jq : 66)) + b_off;
+          on[v] = m16 < 15;
+        }
+      }
+      const int didx = m16 < 6 ? tJ + cS + 6 * kk + m16
+                     : (m16 < 9 ? tJ + cJ + 6 * (m16 - 3) + kk : (m16 < 15 ? tE + cJ + 6 * (m16 - 9) + kk : HV_DOUBLES + 6 * jq + kk));
+      const int jidx = tJ + cJ + 6 * kk + m16;
+      const bool don = kk < 3, jon = kk < 3 && m16 <= kk;
+      const double v00[4] = {acc.x, acc.y, acc.z, acc.w};
+      ticket_wait(1 + half, seq);
+      PT_LAP(4);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (on[v]) lds_add(&HvC[idx[v]], v00[v]);
+      if (don) lds_add(&HvC[didx], -v00[0]);
+      if (jon) lds_add(&HvC[jidx], v00[0]);
+      ticket_pass(1 + half, seq);
+      PT_LAP(5);
+    };
+    v4d_lin hacc = {0, 0, 0, 0};
+    int pdesc = 0, pseq = 0;
+    bool have = false;
     int2 rec_n = nRounds > 0 ? plane[tid] : int2{-1, 0};
     int subv_n = nRounds > 0 ? psub[(wvi * 4) * 16 + lane] : 0;
     for (int round = 0; round < nRounds; ++round) {
@@ -497,9 +539,10 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
           // tickets of the two passes: the marginalisation pass numbers only the units of the rounds it runs (ba_pack.h)
           const int tk = __builtin_amdgcn_readlane(subv, 16 * qq + 2 * i + 1);
           const int seq = MARG ? (tk >> 16) & 0xffff : tk & 0xffff;
-          const int sq = desc & 15, jq = (desc >> 4) & 15, ks0 = (desc >> 8) & 15, ks1 = (desc >> 12) & 15;
+          const int ks0 = (desc >> 8) & 15, ks1 = (desc >> 12) & 15;
           const unsigned smask = ((1u << (2 * (ks1 - ks0))) - 1u) << (2 * ks0);
           if ((qmask & smask) == 0) {       // uniform: nothing to add (units of later start frames in the marginalisation
+            if (have) { commit(hacc, pdesc, pseq); have = false; }
             ticket_wait(1 + half, seq);     // pass), the ticket still goes round
             ticket_pass(1 + half, seq);
             continue;
@@ -516,45 +559,16 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
             for (int q = 0; q < 4; ++q)
               if (kb + q < ks1) c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[q], lo[q], c00, 0, 0, 0);
           }
-          // accumulator entry (row a = kk + 4 v, col b = m16; the tile is symmetric and every (a, b) sits in exactly one lane)
-          // -> LDS Hessian / gradient, in ticket order.  Tile columns: 0..2 s position, 3..5 s rotation, 6..8 j rotation,
-          // 9..14 extrinsic, 15 residual.  Four adds of the lower triangle (the residual row goes to the gradient, which follows
-          // the Hessian in LDS); the lanes of rows 0..2 (kk < 3, v = 0) hold T[q][c] for every column c and add it a second
-          // time, negated, as the entry of j's position row / column q (and a third time for the (j pos, j pos) block).
-          // All indices are computed before the ticket is waited for: the critical section is six LDS adds.
-          const int tS = 36 * (sq * (sq + 1) / 2), tJ = 36 * (jq * (jq + 1) / 2), tE = 36 * 66, cS = 36 * sq, cJ = 36 * jq, cE = 36 * 11;
-          const int colbase = (b_cls == 0 ? cS : (b_cls == 1 ? cJ : cE)) + b_off;
-          int idx[4];
-          bool on[4];
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int a = kk + 4 * v;
-            const int a_cls = a < 6 ? 0 : (a < 9 ? 1 : (a < 15 ? 2 : 3));
-            const int a_off = a < 6 ? a : (a < 9 ? a - 3 : a - 9);
-            idx[v] = (a_cls == 0 ? tS : (a_cls == 1 ? tJ : tE)) + 6 * a_off + colbase;
-            on[v] = a >= m16;
-            if (a_cls == 3) {
-              idx[v] = HV_DOUBLES + (b_cls == 0 ? 6 * sq : (b_cls == 1 ? 6 * jq : 66)) + b_off;
-              on[v] = m16 < 15;
-            }
-          }
-          const int didx = m16 < 6 ? tJ + cS + 6 * kk + m16
-                         : (m16 < 9 ? tJ + cJ + 6 * (m16 - 3) + kk : (m16 < 15 ? tE + cJ + 6 * (m16 - 9) + kk : HV_DOUBLES + 6 * jq + kk));
-          const int jidx = tJ + cJ + 6 * kk + m16;
-          const bool don = kk < 3, jon = kk < 3 && m16 <= kk;
-          const double v00[4] = {c00.x, c00.y, c00.z, c00.w};
           PT_LAP(3);
-          ticket_wait(1 + half, seq);
-          PT_LAP(4);
-#pragma unroll
-          for (int v = 0; v < 4; ++v)
-            if (on[v]) lds_add(&HvC[idx[v]], v00[v]);
-          if (don) lds_add(&HvC[didx], -v00[0]);
-          if (jon) lds_add(&HvC[jidx], v00[0]);
-          ticket_pass(1 + half, seq);
-          PT_LAP(5);
+          // the PREVIOUS unit's tile is committed now, behind this unit's matrix-core instructions: the wait for its ticket
+          // (a third of the phase when every unit stopped for its own) overlaps with work that does not need the ticket
+          if (have) commit(hacc, pdesc, pseq);
+          hacc = c00; pdesc = desc; pseq = seq; have = true;
         }
       }
+      // nothing stays pending across a round: the next thing this wave waits for is the per-track chain of the next round,
+      // and the waves ahead of it in that chain may be waiting for this very ticket
+      if (have) { commit(hacc, pdesc, pseq); have = false; }
     }
 #ifdef VPL_STAMPS
     if (lane == 0) B.dbg[(size_t)w * 64 + 56 + wvi] = __builtin_readcyclecounter() - B.dbg[(size_t)w * 64 + 23];
