@@ -288,9 +288,29 @@ int vpl_ba_triangulate_points(vpl_ctx* ctx, int n_windows, vpl_window* windows, 
 /* Estimator::onlyLineOpt (estimator.cpp:950-1039): line-only Levenberg-Marquardt with the poses and the extrinsic
  * constant, CauchyLoss(1.0), at most options.num_iterations iterations, then double2vector + removeLineOutlier.
  * Updates line_plk / line_removed of the triangulated lines; windows with fewer than four such lines are left untouched
- * (as :1019-1022).  Synchronous. */
+ * (as :1019-1022).  Synchronous (asynchronous variant below). */
 int vpl_ba_only_line_opt(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt,
                          vpl_solve_report* reports);
+
+/* ---- asynchronous variants of the five entry points above -------------------------------------------------------------- *
+ * Same arguments, same results, but the call returns as soon as its uploads, kernels and read-backs are ENQUEUED on the
+ * context's stream; the results are written into the caller's arrays (windows, tracks, priors_out, m, n, reports) by
+ * vpl_ba_collect -- or by the next call on the context that touches the batch (any upload / solve / download, another of
+ * these calls, vpl_ctx_synchronize), which completes a pending call first.  The host is free in between (the reference's
+ * processImage() does its feature-manager bookkeeping on the host, estimator.cpp:121-200); the arrays a call was given must stay
+ * alive, and must not be read, until it has been collected.  One call can be pending per context.  The integer track
+ * bookkeeping of vpl_ba_slide_window (`tracks`) is host work and is complete when the call returns; its states, inverse
+ * depths and Pluecker lines are not. */
+int vpl_ba_triangulate_points_async(vpl_ctx* ctx, int n_windows, vpl_window* windows, double init_depth);
+int vpl_ba_triangulate_lines_async(vpl_ctx* ctx, int n_windows, vpl_window* windows);
+int vpl_ba_only_line_opt_async(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt,
+                               vpl_solve_report* reports);
+int vpl_ba_slide_window_async(vpl_ctx* ctx, int n_windows, vpl_window* windows, int marginalization_flag, double init_depth,
+                              vpl_slide_tracks* tracks);
+int vpl_ba_marginalize_async(vpl_ctx* ctx, int n_windows, const vpl_window* windows, const vpl_ba_options* opt,
+                             int marginalization_flag, vpl_prior* priors_out, int* m, int* n);
+/* Completes the pending asynchronous call, if any (waits for the stream, writes the results).  Returns its status. */
+int vpl_ba_collect(vpl_ctx* ctx);
 
 /* ---- instrumentation (bench.py) ------------------------------------------ */
 /* Per-kernel device time of the last solve measured with hipEvents on the

@@ -214,6 +214,10 @@ def load_hip_library():
     lib.vpl_ba_slide_window.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.c_int, C.c_double, C.POINTER(CSlideTracks)]
     lib.vpl_ba_triangulate_points.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.c_double]
     lib.vpl_ba_only_line_opt.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.POINTER(SolveReport)]
+    for name in ("vpl_ba_triangulate_lines", "vpl_ba_marginalize", "vpl_ba_slide_window", "vpl_ba_triangulate_points",
+                 "vpl_ba_only_line_opt"):
+        getattr(lib, name + "_async").argtypes = getattr(lib, name).argtypes
+    lib.vpl_ba_collect.argtypes = [vp]
     lib.vpl_ba_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.vpl_ba_kernel_times.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), _dp, _ip]
     lib.vpl_ba_launch_profile.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), _dp, _ip]
@@ -261,6 +265,34 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.vpl_ctx_synchronize(self.h), "vpl_ctx_synchronize")
+        self._after_collect()
+
+    def collect(self):
+        """vpl_ba_collect: completes the call that was enqueued with async_=True (its results are in the Windows / the returned
+        objects afterwards)"""
+        self._check(self.lib.vpl_ba_collect(self.h), "vpl_ba_collect")
+        self._after_collect()
+
+    def _settle(self):
+        """an enqueued call is completed before anything else touches the context (the library does the same on its side)"""
+        if getattr(self, "_pending_refs", None) is not None:
+            self.collect()
+
+    def _after_collect(self):
+        fin, self._pending_fin = getattr(self, "_pending_fin", None), None
+        self._pending_refs = None
+        if fin:
+            fin()
+
+    def _call5(self, name, async_, refs, fin, *args):
+        """one of the five line-map entry points, synchronous or enqueued (vpl_ba_<name>[_async])"""
+        self._settle()
+        fn = getattr(self.lib, name + ("_async" if async_ else ""))
+        self._check(fn(self.h, *args), name)
+        if async_:
+            self._pending_refs, self._pending_fin = refs, fin      # keep the C arrays alive until the call is collected
+        elif fin:
+            fin()
 
     # ---- single factor evaluators -------------------------------------------------
     def _factor(self, fn, params, consts, sqrt_info, nres, njac, want_jac=True):
@@ -331,6 +363,7 @@ class Context:
     def upload(self, windows, opt, chained=False):
         """chained=True: vpl_ba_upload_chained -- every window takes the prior the previous solve of this context left for it
         (device resident), the Windows' own .prior is ignored"""
+        self._settle()
         n = len(windows)
         cw = (CWindow * n)()
         for i, w in enumerate(windows):
@@ -358,6 +391,7 @@ class Context:
         return priors, reports
 
     def solve_windows(self, windows, opt):
+        self._settle()
         self.upload(windows, opt)
         self.solve()
         self.synchronize()
@@ -367,7 +401,7 @@ class Context:
         """vpl_ba_pack_states_device: the [n][183] states of the solved batch into a device buffer (raw pointer)"""
         self._check(self.lib.vpl_ba_pack_states_device(self.h, n, C.c_void_p(data_ptr)), "vpl_ba_pack_states_device")
 
-    def marginalize(self, windows, opt, flag):
+    def marginalize(self, windows, opt, flag, async_=False):
         """vpl_ba_marginalize: (priors, m, n) of the windows' current states, no solve"""
         n = len(windows)
         cw = (CWindow * n)()
@@ -376,19 +410,19 @@ class Context:
         priors = (Prior * n)()
         m = np.zeros(n, np.int32)
         nn = np.zeros(n, np.int32)
-        self._check(self.lib.vpl_ba_marginalize(self.h, n, cw, C.byref(opt), flag, priors, m.ctypes.data_as(_ip),
-                                                nn.ctypes.data_as(_ip)), "vpl_ba_marginalize")
+        self._call5("vpl_ba_marginalize", async_, (cw, windows, priors, m, nn, opt), None, n, cw, C.byref(opt), flag, priors,
+                    m.ctypes.data_as(_ip), nn.ctypes.data_as(_ip))
         return priors, m, nn
 
-    def triangulate_lines(self, windows):
+    def triangulate_lines(self, windows, async_=False):
         """FeatureManager::triangulateLine on the device; updates line_plk / line_triangulated of the Windows in place"""
         n = len(windows)
         cw = (CWindow * n)()
         for i, w in enumerate(windows):
             w.to_c(cw[i])
-        self._check(self.lib.vpl_ba_triangulate_lines(self.h, n, cw), "vpl_ba_triangulate_lines")
+        self._call5("vpl_ba_triangulate_lines", async_, (cw, windows), None, n, cw)
 
-    def slide_window(self, windows, marginalization_flag, init_depth=5.0):
+    def slide_window(self, windows, marginalization_flag, init_depth=5.0, async_=False):
         """Estimator::slideWindow; pose / speed_bias / inv_depth / line_plk of the Windows change in place,
         returns one SlideTracks (new start / nobs / dropped observation per track) per window"""
         n = len(windows)
@@ -399,27 +433,28 @@ class Context:
             w.to_c(cw[i])
             res.append(SlideTracks(len(w.point_start), len(w.line_start)))
             res[-1].to_c(ct[i])
-        self._check(self.lib.vpl_ba_slide_window(self.h, n, cw, marginalization_flag, init_depth, ct), "vpl_ba_slide_window")
-        for i, w in enumerate(windows):
-            w.from_c(cw[i])
+        def fin():
+            for i, w in enumerate(windows):
+                w.from_c(cw[i])
+        self._call5("vpl_ba_slide_window", async_, (cw, ct, windows, res), fin, n, cw, marginalization_flag, init_depth, ct)
         return res
 
-    def triangulate_points(self, windows, init_depth=5.0):
+    def triangulate_points(self, windows, init_depth=5.0, async_=False):
         """FeatureManager::triangulate on the device; updates inv_depth of the Windows in place"""
         n = len(windows)
         cw = (CWindow * n)()
         for i, w in enumerate(windows):
             w.to_c(cw[i])
-        self._check(self.lib.vpl_ba_triangulate_points(self.h, n, cw, init_depth), "vpl_ba_triangulate_points")
+        self._call5("vpl_ba_triangulate_points", async_, (cw, windows), None, n, cw, init_depth)
 
-    def only_line_opt(self, windows, opt):
+    def only_line_opt(self, windows, opt, async_=False):
         """Estimator::onlyLineOpt on the device; updates line_plk / line_removed in place, returns the reports"""
         n = len(windows)
         cw = (CWindow * n)()
         for i, w in enumerate(windows):
             w.to_c(cw[i])
         reps = (SolveReport * n)()
-        self._check(self.lib.vpl_ba_only_line_opt(self.h, n, cw, C.byref(opt), reps), "vpl_ba_only_line_opt")
+        self._call5("vpl_ba_only_line_opt", async_, (cw, windows, reps, opt), None, n, cw, C.byref(opt), reps)
         return reps
 
     def enable_kernel_timing(self, on=True):

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -61,6 +62,10 @@ struct vpl_ctx {
   std::vector<std::vector<int>> h_lmap;          // per window: device line index -> index in the vpl_window arrays
   size_t marg_smem = 0;
   int maxPriorN = 0;                             // largest prior of the uploaded batch (k_prep stages J0 in LDS)
+  // asynchronous variants of the line-map entry points: the host-side completion (wait for the stream, scatter the staged
+  // results into the caller's arrays) of the call that was enqueued last; run by vpl_ba_collect or by the next call that
+  // touches the batch
+  std::function<int()> pending;
 };
 
 static void drop_graph(vpl_ctx* c) {
@@ -70,6 +75,20 @@ static void drop_graph(vpl_ctx* c) {
 static int fail(vpl_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
   return code;
+}
+
+// completes the asynchronous call that is still pending on this context, if any
+static int settle(vpl_ctx* c) {
+  if (!c || !c->pending) return VPL_OK;
+  std::function<int()> fin;
+  fin.swap(c->pending);
+  return fin();
+}
+// the tail of an entry point: now, or (asynchronous variant) when the caller collects
+static int finish_or_defer(vpl_ctx* c, bool async, std::function<int()> fin) {
+  if (!async) return fin();
+  c->pending = std::move(fin);
+  return VPL_OK;
 }
 #define HIPCHK(ctx, call)                                                                         \
   do {                                                                                            \
@@ -320,7 +339,11 @@ const char* vpl_last_error(const vpl_ctx* c) { return c ? c->err.c_str() : "null
 int vpl_ctx_synchronize(vpl_ctx* c) {
   if (!c) return VPL_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return VPL_OK;
+  return settle(c);
+}
+int vpl_ba_collect(vpl_ctx* c) {
+  if (!c) return VPL_E_INVALID;
+  return settle(c);
 }
 
 // ---- IMU pre-integration ---------------------------------------------------------------------------
@@ -457,6 +480,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       opt->marginalization_flag != VPL_MARGIN_NONE)
     return fail(c, VPL_E_INVALID, "unknown marginalization_flag");
   HIPCHK(c, hipSetDevice(c->device));
+  { const int rs = settle(c); if (rs) return rs; }   // an asynchronous call whose results have not been collected yet
   drop_graph(c);
   c->opt = *opt;
   c->nW = nW;
@@ -799,6 +823,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
 }
 
 int vpl_ba_reset_state(vpl_ctx* c) {
+  if (c) { const int rs = settle(c); if (rs) return rs; }
   if (!c || c->nW < 1) return VPL_E_INVALID;
   DevBatch& B = c->B;
   const size_t W = c->nW;
@@ -818,7 +843,7 @@ int vpl_ba_upload_chained(vpl_ctx* c, int nW, const vpl_window* win, const vpl_b
 }
 
 // FeatureManager::triangulateLine for a batch: upload (every line), k_triangulate, flags + Pluecker vectors back
-int vpl_ba_triangulate_lines(vpl_ctx* c, int nW, vpl_window* win) {
+static int triangulate_lines_impl(vpl_ctx* c, int nW, vpl_window* win, bool async) {
   if (!c || !win || nW < 1) return VPL_E_INVALID;
   for (int w = 0; w < nW; ++w)
     if (win[w].n_lines > 0 && !win[w].line_triangulated) return fail(c, VPL_E_INVALID, "line_triangulated is required");
@@ -832,29 +857,34 @@ int vpl_ba_triangulate_lines(vpl_ctx* c, int nW, vpl_window* win) {
   { KTimer t(c, "k_triangulate"); hipLaunchKernelGGL(k_triangulate, dim3(nW), dim3(128), 0, s, B); }
   HIPCHK(c, hipGetLastError());
   const size_t W = nW;
-  std::vector<double> plk(W * B.maxL * 6);
-  std::vector<int> tri(W * B.maxL);
-  HIPCHK(c, hipMemcpyAsync(plk.data(), B.plk, plk.size() * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(tri.data(), B.ln_tri, tri.size() * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  for (size_t w = 0; w < W; ++w) {
-    vpl_window& v = win[w];
-    const std::vector<int>& lmap = c->h_lmap[w];
-    for (size_t dl = 0; dl < lmap.size(); ++dl) {
-      const int l = lmap[dl];
-      if (!v.line_triangulated[l] && tri[w * B.maxL + dl]) {
-        std::memcpy(v.line_plk + (size_t)l * 6, &plk[(w * B.maxL + dl) * 6], 6 * 8);
-        v.line_triangulated[l] = 1;
+  auto plk = std::make_shared<std::vector<double>>(W * B.maxL * 6);
+  auto tri = std::make_shared<std::vector<int>>(W * B.maxL);
+  HIPCHK(c, hipMemcpyAsync(plk->data(), B.plk, plk->size() * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(tri->data(), B.ln_tri, tri->size() * 4, hipMemcpyDeviceToHost, s));
+  const int maxL = B.maxL;
+  return finish_or_defer(c, async, [c, win, W, plk, tri, maxL, s]() -> int {
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (size_t w = 0; w < W; ++w) {
+      vpl_window& v = win[w];
+      const std::vector<int>& lmap = c->h_lmap[w];
+      for (size_t dl = 0; dl < lmap.size(); ++dl) {
+        const int l = lmap[dl];
+        if (!v.line_triangulated[l] && (*tri)[w * maxL + dl]) {
+          std::memcpy(v.line_plk + (size_t)l * 6, &(*plk)[(w * maxL + dl) * 6], 6 * 8);
+          v.line_triangulated[l] = 1;
+        }
       }
     }
-  }
-  return VPL_OK;
+    return VPL_OK;
+  });
 }
+int vpl_ba_triangulate_lines(vpl_ctx* c, int nW, vpl_window* win) { return triangulate_lines_impl(c, nW, win, false); }
+int vpl_ba_triangulate_lines_async(vpl_ctx* c, int nW, vpl_window* win) { return triangulate_lines_impl(c, nW, win, true); }
 
 // Estimator::slideWindow for a batch.  The list bookkeeping (start frames, dropped observations, erased tracks) is integer
 // work on the caller's arrays and is done here on the host; the re-anchoring arithmetic of removeBackShiftDepth runs in
 // k_slide_shift over the gathered start-frame-0 survivors of all windows.
-int vpl_ba_slide_window(vpl_ctx* c, int nW, vpl_window* win, int flag, double init_depth, vpl_slide_tracks* out) {
+static int slide_window_impl(vpl_ctx* c, int nW, vpl_window* win, int flag, double init_depth, vpl_slide_tracks* out, bool async) {
   if (!c || !win || !out || nW < 1 || !(init_depth > 0.0)) return VPL_E_INVALID;
   if (flag != VPL_MARGIN_OLD && flag != VPL_MARGIN_SECOND_NEW) return fail(c, VPL_E_INVALID, "slide_window: marginalization_flag");
   constexpr int WS = VPL_NFRAMES - 1;
@@ -872,6 +902,7 @@ int vpl_ba_slide_window(vpl_ctx* c, int nW, vpl_window* win, int flag, double in
         return fail(c, VPL_E_INVALID, "slide_window: line track outside the window");
   }
   HIPCHK(c, hipSetDevice(c->device));
+  { const int rs = settle(c); if (rs) return rs; }
   if (flag == VPL_MARGIN_SECOND_NEW) {
     // removeFront(frame_count = WINDOW_SIZE): no arithmetic
     auto front = [](int n, const int* start, const int* nobs, int* ostart, int* onobs, int* odrop) {
@@ -891,8 +922,15 @@ int vpl_ba_slide_window(vpl_ctx* c, int nW, vpl_window* win, int flag, double in
     }
     return VPL_OK;
   }
-  std::vector<double> fr((size_t)nW * 21), pd, ld;
-  std::vector<int> pw, lw, pidx, lidx;
+  struct SlideJob {
+    std::vector<double> fr, pd, ld;
+    std::vector<int> pw, lw, pidx, lidx;
+    DevBuf dfr, dpw, dpd, dlw, dld;
+  };
+  auto job = std::make_shared<SlideJob>();
+  std::vector<double>&fr = job->fr, &pd = job->pd, &ld = job->ld;
+  std::vector<int>&pw = job->pw, &lw = job->lw, &pidx = job->pidx, &lidx = job->lidx;
+  fr.resize((size_t)nW * 21);
   for (int w = 0; w < nW; ++w) {
     const vpl_window& W = win[w];
     std::memcpy(&fr[(size_t)w * 21], W.pose[0], 56);
@@ -921,9 +959,9 @@ int vpl_ba_slide_window(vpl_ctx* c, int nW, vpl_window* win, int flag, double in
     }
   }
   const int nPts = (int)pw.size(), nLns = (int)lw.size();
+  hipStream_t s = c->stream;
   if (nPts + nLns > 0) {
-    DevBuf dfr, dpw, dpd, dlw, dld;
-    hipStream_t s = c->stream;
+    DevBuf &dfr = job->dfr, &dpw = job->dpw, &dpd = job->dpd, &dlw = job->dlw, &dld = job->dld;
     HIPCHK(c, dfr.alloc(fr.size() * 8)); HIPCHK(c, dpw.alloc(pw.size() * 4)); HIPCHK(c, dpd.alloc(pd.size() * 8));
     HIPCHK(c, dlw.alloc(lw.size() * 4)); HIPCHK(c, dld.alloc(ld.size() * 8));
     HIPCHK(c, hipMemcpyAsync(dfr.p, fr.data(), fr.size() * 8, hipMemcpyHostToDevice, s));
@@ -937,19 +975,30 @@ int vpl_ba_slide_window(vpl_ctx* c, int nW, vpl_window* win, int flag, double in
     HIPCHK(c, hipGetLastError());
     if (nPts) HIPCHK(c, hipMemcpyAsync(pd.data(), dpd.p, pd.size() * 8, hipMemcpyDeviceToHost, s));
     if (nLns) HIPCHK(c, hipMemcpyAsync(ld.data(), dld.p, ld.size() * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    for (int k = 0; k < nPts; ++k) win[pw[k]].inv_depth[pidx[k]] = pd[(size_t)k * 4 + 3];
-    for (int k = 0; k < nLns; ++k) std::memcpy(win[lw[k]].line_plk + 6 * lidx[k], &ld[(size_t)k * 6], 48);
   }
-  for (int w = 0; w < nW; ++w) {
-    std::memmove(win[w].pose[0], win[w].pose[1], sizeof(win[w].pose[0]) * WS);            // frames 1..10 -> 0..9, 10 stays
-    std::memmove(win[w].speed_bias[0], win[w].speed_bias[1], sizeof(win[w].speed_bias[0]) * WS);
-  }
-  return VPL_OK;
+  // (the job owns the staging vectors and the device buffers until the results have been scattered)
+  return finish_or_defer(c, async, [c, win, nW, job, nPts, nLns, s]() -> int {
+    if (nPts + nLns > 0) {
+      HIPCHK(c, hipStreamSynchronize(s));
+      for (int k = 0; k < nPts; ++k) win[job->pw[k]].inv_depth[job->pidx[k]] = job->pd[(size_t)k * 4 + 3];
+      for (int k = 0; k < nLns; ++k) std::memcpy(win[job->lw[k]].line_plk + 6 * job->lidx[k], &job->ld[(size_t)k * 6], 48);
+    }
+    for (int w = 0; w < nW; ++w) {
+      std::memmove(win[w].pose[0], win[w].pose[1], sizeof(win[w].pose[0]) * WS);            // frames 1..10 -> 0..9, 10 stays
+      std::memmove(win[w].speed_bias[0], win[w].speed_bias[1], sizeof(win[w].speed_bias[0]) * WS);
+    }
+    return VPL_OK;
+  });
+}
+int vpl_ba_slide_window(vpl_ctx* c, int nW, vpl_window* win, int flag, double init_depth, vpl_slide_tracks* out) {
+  return slide_window_impl(c, nW, win, flag, init_depth, out, false);
+}
+int vpl_ba_slide_window_async(vpl_ctx* c, int nW, vpl_window* win, int flag, double init_depth, vpl_slide_tracks* out) {
+  return slide_window_impl(c, nW, win, flag, init_depth, out, true);
 }
 
 // FeatureManager::triangulate for a batch: upload, k_triangulate_points, inverse depths back
-int vpl_ba_triangulate_points(vpl_ctx* c, int nW, vpl_window* win, double init_depth) {
+static int triangulate_points_impl(vpl_ctx* c, int nW, vpl_window* win, double init_depth, bool async) {
   if (!c || !win || nW < 1 || !(init_depth > 0.0)) return VPL_E_INVALID;
   vpl_ba_options opt;
   vpl_ba_default_options(&opt);
@@ -961,17 +1010,22 @@ int vpl_ba_triangulate_points(vpl_ctx* c, int nW, vpl_window* win, double init_d
   { KTimer t(c, "k_triangulate_points"); hipLaunchKernelGGL(k_triangulate_points, dim3(nW), dim3(128), 0, s, B, init_depth); }
   HIPCHK(c, hipGetLastError());
   const size_t W = nW;
-  std::vector<double> invd(W * B.maxP);
-  HIPCHK(c, hipMemcpyAsync(invd.data(), B.invd, invd.size() * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  for (size_t w = 0; w < W; ++w)
-    for (int p = 0; p < win[w].n_points; ++p) win[w].inv_depth[p] = invd[w * B.maxP + p];
-  return VPL_OK;
+  auto invd = std::make_shared<std::vector<double>>(W * B.maxP);
+  HIPCHK(c, hipMemcpyAsync(invd->data(), B.invd, invd->size() * 8, hipMemcpyDeviceToHost, s));
+  const int maxP = B.maxP;
+  return finish_or_defer(c, async, [c, win, W, invd, maxP, s]() -> int {
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (size_t w = 0; w < W; ++w)
+      for (int p = 0; p < win[w].n_points; ++p) win[w].inv_depth[p] = (*invd)[w * maxP + p];
+    return VPL_OK;
+  });
 }
+int vpl_ba_triangulate_points(vpl_ctx* c, int nW, vpl_window* win, double init_depth) { return triangulate_points_impl(c, nW, win, init_depth, false); }
+int vpl_ba_triangulate_points_async(vpl_ctx* c, int nW, vpl_window* win, double init_depth) { return triangulate_points_impl(c, nW, win, init_depth, true); }
 
 // Estimator::onlyLineOpt for a batch: upload (triangulated lines), k_prep (world orth of the lines), k_line_opt (the LM
 // loop), k_gauge (setLineOrth + removeLineOutlier; the gauge transform is the identity, the poses did not move)
-int vpl_ba_only_line_opt(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt_in, vpl_solve_report* reports) {
+static int only_line_opt_impl(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt_in, vpl_solve_report* reports, bool async) {
   if (!c || !win || !opt_in || nW < 1) return VPL_E_INVALID;
   if (c->maxL > LOPT_THREADS) return fail(c, VPL_E_CAPACITY, "onlyLineOpt handles at most 256 lines per window");
   vpl_ba_options opt = *opt_in;
@@ -987,35 +1041,46 @@ int vpl_ba_only_line_opt(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_optio
   { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
   HIPCHK(c, hipGetLastError());
   const size_t W = nW;
-  std::vector<double> plk(W * B.maxL * 6);
-  std::vector<int> removed(W * B.maxL);
-  std::vector<TrState> tr(W);
-  HIPCHK(c, hipMemcpyAsync(plk.data(), B.plk, plk.size() * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(removed.data(), B.ln_removed, removed.size() * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(tr.data(), B.tr, W * sizeof(TrState), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  for (size_t w = 0; w < W; ++w) {
-    vpl_window& v = win[w];
-    const std::vector<int>& lmap = c->h_lmap[w];
-    if (v.line_removed)
-      for (int l = 0; l < v.n_lines; ++l) v.line_removed[l] = 0;
-    if (reports) std::memset(&reports[w], 0, sizeof(reports[w]));
-    if (lmap.size() < 4) continue;       // "if (feature_index < 3) return;" -- nothing is touched
-    for (size_t dl = 0; dl < lmap.size(); ++dl) {
-      if (!removed[w * B.maxL + dl]) std::memcpy(v.line_plk + (size_t)lmap[dl] * 6, &plk[(w * B.maxL + dl) * 6], 6 * 8);
-      if (v.line_removed) v.line_removed[lmap[dl]] = removed[w * B.maxL + dl] ? 1 : 0;
-      if (reports) reports[w].n_lines_removed += removed[w * B.maxL + dl] ? 1 : 0;
+  auto plk = std::make_shared<std::vector<double>>(W * B.maxL * 6);
+  auto removed = std::make_shared<std::vector<int>>(W * B.maxL);
+  auto tr = std::make_shared<std::vector<TrState>>(W);
+  HIPCHK(c, hipMemcpyAsync(plk->data(), B.plk, plk->size() * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(removed->data(), B.ln_removed, removed->size() * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(tr->data(), B.tr, W * sizeof(TrState), hipMemcpyDeviceToHost, s));
+  const int maxL = B.maxL;
+  return finish_or_defer(c, async, [c, win, reports, W, plk, removed, tr, maxL, s]() -> int {
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (size_t w = 0; w < W; ++w) {
+      vpl_window& v = win[w];
+      const std::vector<int>& lmap = c->h_lmap[w];
+      if (v.line_removed)
+        for (int l = 0; l < v.n_lines; ++l) v.line_removed[l] = 0;
+      if (reports) std::memset(&reports[w], 0, sizeof(reports[w]));
+      if (lmap.size() < 4) continue;       // "if (feature_index < 3) return;" -- nothing is touched
+      for (size_t dl = 0; dl < lmap.size(); ++dl) {
+        const bool rem = (*removed)[w * maxL + dl] != 0;
+        if (!rem) std::memcpy(v.line_plk + (size_t)lmap[dl] * 6, &(*plk)[(w * maxL + dl) * 6], 6 * 8);
+        if (v.line_removed) v.line_removed[lmap[dl]] = rem ? 1 : 0;
+        if (reports) reports[w].n_lines_removed += rem ? 1 : 0;
+      }
+      if (reports) {
+        vpl_solve_report& r = reports[w];
+        const TrState& t = (*tr)[w];
+        r.iterations = t.iter;
+        r.num_successful_steps = t.num_successful;
+        r.termination = t.status == 1 ? 1 : t.status == 2 ? 2 : 0;
+        r.initial_cost = t.initial_cost;
+        r.final_cost = t.x_cost;
+      }
     }
-    if (reports) {
-      vpl_solve_report& r = reports[w];
-      r.iterations = tr[w].iter;
-      r.num_successful_steps = tr[w].num_successful;
-      r.termination = tr[w].status == 1 ? 1 : tr[w].status == 2 ? 2 : 0;
-      r.initial_cost = tr[w].initial_cost;
-      r.final_cost = tr[w].x_cost;
-    }
-  }
-  return VPL_OK;
+    return VPL_OK;
+  });
+}
+int vpl_ba_only_line_opt(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt, vpl_solve_report* reports) {
+  return only_line_opt_impl(c, nW, win, opt, reports, false);
+}
+int vpl_ba_only_line_opt_async(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt, vpl_solve_report* reports) {
+  return only_line_opt_impl(c, nW, win, opt, reports, true);
 }
 
 // The whole solve of the windows [w0, w0 + nw) on stream s
@@ -1070,6 +1135,7 @@ static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
 
 // vpl_ba_solve: the kernel-per-phase sequence over the whole batch, asynchronous on the context's stream.
 int vpl_ba_solve(vpl_ctx* c) {
+  if (c) { const int rs = settle(c); if (rs) return rs; }
   if (!c || c->nW < 1) return VPL_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->use_graph && !c->timing && c->stream != nullptr) {   // (the legacy default stream cannot be captured)
@@ -1146,6 +1212,7 @@ static int fetch_priors(vpl_ctx* c, int nW, vpl_prior* priors, std::vector<int>&
 
 // States of the uploaded batch -> caller's DEVICE buffer [nW][183], asynchronous on the context's stream
 int vpl_ba_pack_states_device(vpl_ctx* c, int nW, void* d_states) {
+  if (c) { const int rs = settle(c); if (rs) return rs; }
   if (!c || nW != c->nW || !d_states) return VPL_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   hipLaunchKernelGGL(k_pack_states, dim3(nW), dim3(192), 0, c->stream, c->B, (double*)d_states);
@@ -1154,6 +1221,7 @@ int vpl_ba_pack_states_device(vpl_ctx* c, int nW, void* d_states) {
 }
 
 int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_solve_report* reports) {
+  if (c) { const int rs = settle(c); if (rs) return rs; }
   if (!c || nW != c->nW || !win) return VPL_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   DevBatch& B = c->B;
@@ -1209,8 +1277,8 @@ int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_
 // (marginalization_factor.cpp:89-129,177-363 as driven by estimator.cpp:1229-1447): the factor subset of the flag is
 // linearised at the windows' current states (k_lin<1|2>), the landmarks and the dropped frame are eliminated and the kept
 // block is factored into (J0, r0) (k_marg).  The states are not touched.
-int vpl_ba_marginalize(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt_in, int marginalization_flag,
-                       vpl_prior* priors, int* m_out, int* n_out) {
+static int marginalize_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt_in, int marginalization_flag,
+                            vpl_prior* priors, int* m_out, int* n_out, bool async) {
   if (!c || !win || !opt_in || !priors || nW < 1) return VPL_E_INVALID;
   if (marginalization_flag != VPL_MARGIN_OLD && marginalization_flag != VPL_MARGIN_SECOND_NEW)
     return fail(c, VPL_E_INVALID, "vpl_ba_marginalize: flag must be VPL_MARGIN_OLD or VPL_MARGIN_SECOND_NEW");
@@ -1236,14 +1304,25 @@ int vpl_ba_marginalize(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   }
   if (ran) { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   HIPCHK(c, hipGetLastError());
-  std::vector<int> mn;
-  rc = fetch_priors(c, nW, priors, mn);
-  if (rc) return rc;
-  for (int w = 0; w < nW; ++w) {
-    if (m_out) m_out[w] = mn[2 * w];
-    if (n_out) n_out[w] = mn[2 * w + 1];
-  }
-  return VPL_OK;
+  // (the priors are fetched from the device when the call completes: any later call on the context completes this one first)
+  return finish_or_defer(c, async, [c, nW, priors, m_out, n_out]() -> int {
+    std::vector<int> mn;
+    const int rf = fetch_priors(c, nW, priors, mn);
+    if (rf) return rf;
+    for (int w = 0; w < nW; ++w) {
+      if (m_out) m_out[w] = mn[2 * w];
+      if (n_out) n_out[w] = mn[2 * w + 1];
+    }
+    return VPL_OK;
+  });
+}
+int vpl_ba_marginalize(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt, int marginalization_flag,
+                       vpl_prior* priors, int* m_out, int* n_out) {
+  return marginalize_impl(c, nW, win, opt, marginalization_flag, priors, m_out, n_out, false);
+}
+int vpl_ba_marginalize_async(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt, int marginalization_flag,
+                             vpl_prior* priors, int* m_out, int* n_out) {
+  return marginalize_impl(c, nW, win, opt, marginalization_flag, priors, m_out, n_out, true);
 }
 
 int vpl_ba_solve_windows(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt, vpl_prior* priors,
