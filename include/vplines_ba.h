@@ -292,6 +292,17 @@ int vpl_ba_triangulate_points(vpl_ctx* ctx, int n_windows, vpl_window* windows, 
 int vpl_ba_only_line_opt(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt,
                          vpl_solve_report* reports);
 
+/* Estimator::solveOdometry (estimator.cpp:624-648) in one call:  f_manager.triangulate  ||  (f_manager.triangulateLine ->
+ * onlyLineOpt)  ->  optimizationwithLine.  `windows` are packed as for the single stages (every point track with
+ * inv_depth < 0 where estimated_depth is unset; every line track that passes the LINE_MIN_OBS filter with its
+ * is_triangulation flag; line_removed writable).  On return: inv_depth / line_plk / line_triangulated / line_removed as the
+ * three map stages leave them -- a track erased by removeLineOutlier has line_removed = 1 and line_triangulated = 0 and took
+ * no part in the solve -- and states, priors_out and reports as vpl_ba_solve_windows leaves them; line_reports (may be NULL)
+ * are onlyLineOpt's.  The stages run back to back, each with its own upload: which lines take part changes between them
+ * and the kernels' layout tables are built on the host from that set. */
+int vpl_ba_solve_odometry(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt, double init_depth,
+                          vpl_prior* priors_out, vpl_solve_report* line_reports, vpl_solve_report* reports);
+
 /* ---- asynchronous variants of the five entry points above -------------------------------------------------------------- *
  * Same arguments, same results, but the call returns as soon as its uploads, kernels and read-backs are ENQUEUED on the
  * context's stream; the results are written into the caller's arrays (windows, tracks, priors_out, m, n, reports) by

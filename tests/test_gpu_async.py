@@ -97,3 +97,60 @@ def test_marginalize_async_and_implicit_completion_by_the_next_call(gpu_ctx):
     gpu_ctx.solve_windows(again, opt)
     for x, y in zip(other, again):
         assert np.array_equal(x.pose, y.pose)
+
+
+def _odometry_windows(n):
+    """windows as solveOdometry() finds them: some depths unset, some lines not yet triangulated, noisy line map"""
+    rng = np.random.default_rng(21)
+    ws = []
+    for i in range(n):
+        w, opt = make(1200 + i, L=40, P=60, sigma_px=0.5, pose_noise=True, t=0.2 * i)
+        w.inv_depth[i % 4::4] = -1.0
+        w.line_plk += rng.normal(0, 0.01, w.line_plk.shape) * np.abs(w.line_plk)
+        w.line_triangulated[:] = 1
+        w.line_triangulated[i % 5::5] = 0
+        w.line_plk[w.line_triangulated[:40] == 0] = 0
+        w.line_removed[:] = 0
+        ws.append(w)
+    opt.num_iterations = 5
+    return ws, opt
+
+
+def test_solve_odometry_is_the_four_stages_back_to_back_and_matches_the_oracle(gpu_ctx):
+    """vpl_ba_solve_odometry = Estimator::solveOdometry (estimator.cpp:624-648): triangulate || (triangulateLine -> onlyLineOpt)
+    -> optimizationwithLine.  Bit-identical to the single entry points called in that order; against the oracle's stages
+    the usual bars (same lines triangulated and erased, same iteration pattern, poses within 1e-4 m / 1e-6 rad)."""
+    import oracle_api as o
+    from test_gpu_solve import POS_TOL, ROT_TOL, pose_err
+    ws, opt = _odometry_windows(5)
+    a = [w.copy() for w in ws]
+    pri_a, lrep_a, rep_a = gpu_ctx.solve_odometry(a, opt, 5.0)
+    # the stages one by one
+    b = [w.copy() for w in ws]
+    gpu_ctx.triangulate_points(b, 5.0)
+    gpu_ctx.triangulate_lines(b)
+    lrep_b = gpu_ctx.only_line_opt(b, opt)
+    for w in b:
+        w.line_triangulated[w.line_removed[:len(w.line_triangulated)] != 0] = 0
+    pri_b, rep_b = gpu_ctx.solve_windows(b, opt)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x.pose, y.pose) and np.array_equal(x.speed_bias, y.speed_bias)
+        assert np.array_equal(x.inv_depth, y.inv_depth) and np.array_equal(x.line_plk, y.line_plk)
+        assert np.array_equal(x.line_triangulated, y.line_triangulated) and np.array_equal(x.line_removed, y.line_removed)
+        assert rep_a[i].iterations == rep_b[i].iterations and rep_a[i].final_cost == rep_b[i].final_cost
+        assert lrep_a[i].iterations == lrep_b[i].iterations and lrep_a[i].n_lines_removed == lrep_b[i].n_lines_removed
+        assert np.array_equal(pri_a[i].J(), pri_b[i].J())
+    # the oracle's stages
+    for i, w in enumerate(ws):
+        c = w.copy()
+        o.triangulate_points(c, opt, 5.0)
+        o.triangulate_lines(c, opt)
+        lrc = o.only_line_opt(c, opt)
+        c.line_triangulated[c.line_removed[:len(c.line_triangulated)] != 0] = 0
+        pc, rc = o.solve_window(c, opt)
+        assert np.array_equal(a[i].line_triangulated, c.line_triangulated) and np.array_equal(a[i].line_removed, c.line_removed)
+        assert lrep_a[i].iterations == lrc.iterations and lrep_a[i].n_lines_removed == lrc.n_lines_removed
+        assert rep_a[i].iterations == rc.iterations and rep_a[i].num_successful_steps == rc.num_successful_steps, i
+        dp, dr = pose_err(a[i], c)
+        assert dp <= POS_TOL and dr <= ROT_TOL, (i, dp, dr)
+        assert pri_a[i].n == pc.n

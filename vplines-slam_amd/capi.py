@@ -218,6 +218,8 @@ def load_hip_library():
                  "vpl_ba_only_line_opt"):
         getattr(lib, name + "_async").argtypes = getattr(lib, name).argtypes
     lib.vpl_ba_collect.argtypes = [vp]
+    lib.vpl_ba_solve_odometry.argtypes = [vp, C.c_int, C.POINTER(CWindow), C.POINTER(BaOptions), C.c_double, C.POINTER(Prior),
+                                          C.POINTER(SolveReport), C.POINTER(SolveReport)]
     lib.vpl_ba_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.vpl_ba_kernel_times.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), _dp, _ip]
     lib.vpl_ba_launch_profile.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_char_p), _dp, _ip]
@@ -396,6 +398,21 @@ class Context:
         self.solve()
         self.synchronize()
         return self.download()
+
+    def solve_odometry(self, windows, opt, init_depth=5.0):
+        """vpl_ba_solve_odometry: triangulate || (triangulateLine -> onlyLineOpt) -> solve, in place; (priors, line reports, reports)"""
+        self._settle()
+        n = len(windows)
+        cw = (CWindow * n)()
+        for i, w in enumerate(windows):
+            w.to_c(cw[i])
+        priors = (Prior * n)()
+        lreps = (SolveReport * n)()
+        reps = (SolveReport * n)()
+        self._check(self.lib.vpl_ba_solve_odometry(self.h, n, cw, C.byref(opt), init_depth, priors, lreps, reps), "vpl_ba_solve_odometry")
+        for i, w in enumerate(windows):
+            w.from_c(cw[i])
+        return priors, lreps, reps
 
     def pack_states_device(self, n, data_ptr):
         """vpl_ba_pack_states_device: the [n][183] states of the solved batch into a device buffer (raw pointer)"""

@@ -1336,6 +1336,37 @@ int vpl_ba_solve_windows(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_optio
   return vpl_ba_download(c, nW, win, priors, reports);
 }
 
+// Estimator::solveOdometry (estimator.cpp:624-648) for a batch, in one call: triangulate || (triangulateLine -> onlyLineOpt)
+// -> optimizationwithLine.  The two line stages change WHICH lines take part (newly triangulated ones join, the ones
+// removeLineOutlier erases leave), and the lane / unit / K-step tables of the kernels are built on the host from that set: the
+// stages are the entry points above run back to back on the caller's arrays, each with its own upload.
+int vpl_ba_solve_odometry(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt, double init_depth,
+                          vpl_prior* priors, vpl_solve_report* line_reports, vpl_solve_report* reports) {
+  if (!c || !win || !opt || nW < 1) return VPL_E_INVALID;
+  bool any_lines = false;
+  for (int w = 0; w < nW; ++w)
+    if (win[w].n_lines > 0) {
+      any_lines = true;
+      if (!win[w].line_triangulated || !win[w].line_removed)
+        return fail(c, VPL_E_INVALID, "solve_odometry: line_triangulated and line_removed are required for windows with lines");
+    }
+  int rc = vpl_ba_triangulate_points(c, nW, win, init_depth);
+  if (rc) return rc;
+  if (any_lines) {
+    rc = vpl_ba_triangulate_lines(c, nW, win);
+    if (rc) return rc;
+    rc = vpl_ba_only_line_opt(c, nW, win, opt, line_reports);
+    if (rc) return rc;
+    // f_manager.removeLineOutlier erased these tracks (estimator.cpp:1037): they take no part in the solve
+    for (int w = 0; w < nW; ++w)
+      for (int l = 0; l < win[w].n_lines; ++l)
+        if (win[w].line_removed[l]) win[w].line_triangulated[l] = 0;
+  } else if (line_reports) {
+    std::memset(line_reports, 0, sizeof(vpl_solve_report) * (size_t)nW);
+  }
+  return vpl_ba_solve_windows(c, nW, win, opt, priors, reports);
+}
+
 // Debug/test access to the marginalisation invariants (A, b before the final eigen-decomposition),
 // mirroring the reference's commented check at marginalization_factor.cpp:361-362.
 int vpl_ba_debug_marg_Ab(vpl_ctx* c, int w, double* A, double* b) {
