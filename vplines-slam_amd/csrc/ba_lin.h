@@ -493,7 +493,9 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
         for (int a = 0; a < 6; ++a) {
           pv[2 + a] = Jl[0] * Ji[a] + Jl[1] * Ji[6 + a];
           pv[8 + a] = Jl[0] * Je[a] + Jl[1] * Je[6 + a];
-          Wrow[6 * k + a] = Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];   // this (track, frame) entry has one writer
+          // this (track, frame) entry has one writer; j's position columns are minus s's (the same bits, negated): they are
+          // never formed
+          Wrow[6 * k + a] = a < 3 ? -pv[2 + a] : Jl[0] * Jj[a] + Jl[1] * Jj[6 + a];
         }
       }
       const unsigned long long actmask = __ballot(act);
