@@ -1336,10 +1336,46 @@ int vpl_ba_solve_windows(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_optio
   return vpl_ba_download(c, nW, win, priors, reports);
 }
 
+// f_manager.triangulate and f_manager.triangulateLine on ONE upload (both work on the window with every line, and touch
+// different arrays): what solveOdometry's two threads start with
+static int triangulate_points_and_lines(vpl_ctx* c, int nW, vpl_window* win, double init_depth) {
+  if (!(init_depth > 0.0)) return VPL_E_INVALID;
+  vpl_ba_options opt;
+  vpl_ba_default_options(&opt);
+  opt.marginalization_flag = VPL_MARGIN_NONE;
+  int rc = upload_impl(c, nW, win, &opt, true);
+  if (rc) return rc;
+  DevBatch& B = c->B;
+  hipStream_t s = c->stream;
+  { KTimer t(c, "k_triangulate_points"); hipLaunchKernelGGL(k_triangulate_points, dim3(nW), dim3(128), 0, s, B, init_depth); }
+  { KTimer t(c, "k_triangulate"); hipLaunchKernelGGL(k_triangulate, dim3(nW), dim3(128), 0, s, B); }
+  HIPCHK(c, hipGetLastError());
+  const size_t W = nW;
+  std::vector<double> invd(W * B.maxP), plk(W * B.maxL * 6);
+  std::vector<int> tri(W * B.maxL);
+  HIPCHK(c, hipMemcpyAsync(invd.data(), B.invd, invd.size() * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(plk.data(), B.plk, plk.size() * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(tri.data(), B.ln_tri, tri.size() * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (size_t w = 0; w < W; ++w) {
+    vpl_window& v = win[w];
+    for (int p = 0; p < v.n_points; ++p) v.inv_depth[p] = invd[w * B.maxP + p];
+    const std::vector<int>& lmap = c->h_lmap[w];
+    for (size_t dl = 0; dl < lmap.size(); ++dl) {
+      const int l = lmap[dl];
+      if (!v.line_triangulated[l] && tri[w * B.maxL + dl]) {
+        std::memcpy(v.line_plk + (size_t)l * 6, &plk[(w * B.maxL + dl) * 6], 6 * 8);
+        v.line_triangulated[l] = 1;
+      }
+    }
+  }
+  return VPL_OK;
+}
+
 // Estimator::solveOdometry (estimator.cpp:624-648) for a batch, in one call: triangulate || (triangulateLine -> onlyLineOpt)
 // -> optimizationwithLine.  The two line stages change WHICH lines take part (newly triangulated ones join, the ones
 // removeLineOutlier erases leave), and the lane / unit / K-step tables of the kernels are built on the host from that set: the
-// stages are the entry points above run back to back on the caller's arrays, each with its own upload.
+// stages are the entry points above run back to back on the caller's arrays (the two triangulations share one upload).
 int vpl_ba_solve_odometry(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt, double init_depth,
                           vpl_prior* priors, vpl_solve_report* line_reports, vpl_solve_report* reports) {
   if (!c || !win || !opt || nW < 1) return VPL_E_INVALID;
@@ -1350,11 +1386,9 @@ int vpl_ba_solve_odometry(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_opti
       if (!win[w].line_triangulated || !win[w].line_removed)
         return fail(c, VPL_E_INVALID, "solve_odometry: line_triangulated and line_removed are required for windows with lines");
     }
-  int rc = vpl_ba_triangulate_points(c, nW, win, init_depth);
+  int rc = any_lines ? triangulate_points_and_lines(c, nW, win, init_depth) : vpl_ba_triangulate_points(c, nW, win, init_depth);
   if (rc) return rc;
   if (any_lines) {
-    rc = vpl_ba_triangulate_lines(c, nW, win);
-    if (rc) return rc;
     rc = vpl_ba_only_line_opt(c, nW, win, opt, line_reports);
     if (rc) return rc;
     // f_manager.removeLineOutlier erased these tracks (estimator.cpp:1037): they take no part in the solve
