@@ -298,7 +298,7 @@ int vpl_ba_only_line_opt(vpl_ctx* ctx, int n_windows, vpl_window* windows, const
  * is_triangulation flag; line_removed writable).  On return: inv_depth / line_plk / line_triangulated / line_removed as the
  * three map stages leave them -- a track erased by removeLineOutlier has line_removed = 1 and line_triangulated = 0 and took
  * no part in the solve -- and states, priors_out and reports as vpl_ba_solve_windows leaves them; line_reports (may be NULL)
- * are onlyLineOpt's.  The stages run back to back, each with its own upload: which lines take part changes between them
+ * are onlyLineOpt's.  The stages run back to back (the two triangulations on one upload): which lines take part changes between them
  * and the kernels' layout tables are built on the host from that set. */
 int vpl_ba_solve_odometry(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt, double init_depth,
                           vpl_prior* priors_out, vpl_solve_report* line_reports, vpl_solve_report* reports);
