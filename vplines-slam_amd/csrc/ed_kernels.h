@@ -189,6 +189,24 @@ constexpr unsigned ed_truth(bool horizPixel) {
 }
 constexpr unsigned ED_TRUTH = ed_truth(false) | (ed_truth(true) << 16);
 
+// One quarter of a tile (32 of its 128 rows): a tile row is 256 B = 16 lanes x 16 B, one instruction moves four rows, eight
+// loads in flight.  The four waves of the work-group take a quarter each (k_ed_route).
+constexpr int ED_ROUTE_WAVES = ED_TILE / 32;
+__device__ __forceinline__ void ed_tile_rows(const EdWalker& wk, int tx, int ty, int b, int lane) {
+  const int sub = lane >> 4, col = (lane & 15) * 8;
+  const uint16_t* src = wk.code + (size_t)(ty + sub) * wk.Wc + tx + col;
+  uint16_t* dst = wk.tile + sub * ED_TILE + col;
+  uint4 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int row = ty + sub + 4 * (8 * b + k);
+    v[k] = row < wk.H ? *(const uint4*)(src + (size_t)4 * (8 * b + k) * wk.Wc) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) *(uint4*)(dst + 4 * (8 * b + k) * ED_TILE) = v[k];
+}
+// The walker (wave 0) asks for a tile: command and origin to LDS, barrier A (the three helper waves wait there), every wave
+// loads its quarter, barrier B.  Between B and the next A the helpers touch nothing.
 __device__ __forceinline__ void ed_tile_load(EdWalker& wk, int x, int y, unsigned S) {
   // centred on the walker: the two walks of an anchor leave in opposite directions and the next anchor of the scan sits two
   // rows further down, so a tile placed AHEAD of the direction of travel (rounds 1-2) was thrown away by the very next walk
@@ -198,24 +216,13 @@ __device__ __forceinline__ void ed_tile_load(EdWalker& wk, int x, int y, unsigne
   tx &= ~7;
   tx = max(0, min(tx, wk.Wc - ED_TILE));
   ty = max(0, min(ty, wk.H - ED_TILE));
-  // a tile row is 256 B = 16 lanes x 16 B: one instruction moves four rows; eight loads in flight per batch
-  const int lane = threadIdx.x, sub = lane >> 4, col = (lane & 15) * 8;
-  const uint16_t* src = wk.code + (size_t)(ty + sub) * wk.Wc + tx + col;
-  uint16_t* dst = wk.tile + sub * ED_TILE + col;
-#pragma unroll 1
-  for (int b = 0; b < ED_TILE / 32; ++b) {
-    uint4 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int row = ty + sub + 4 * (8 * b + k);
-      v[k] = row < wk.H ? *(const uint4*)(src + (size_t)4 * (8 * b + k) * wk.Wc) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) *(uint4*)(dst + 4 * (8 * b + k) * ED_TILE) = v[k];
-  }
-  wk.tx0 = __builtin_amdgcn_readfirstlane(tx); wk.ty0 = __builtin_amdgcn_readfirstlane(ty);
+  tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty);
+  if (threadIdx.x == 0) { wk.ring[0] = 1u; wk.ring[1] = (unsigned)tx; wk.ring[2] = (unsigned)ty; }
+  __syncthreads();   // A
+  ed_tile_rows(wk, tx, ty, 0, threadIdx.x);
+  wk.tx0 = tx; wk.ty0 = ty;
   ++wk.nLoads;
-  __syncthreads();
+  __syncthreads();   // B
 }
 
 // EdgeDrawing's routing loops (edline_detector.cpp:191-647); returns the number of pixels of this part.
@@ -288,9 +295,12 @@ __device__ __forceinline__ int ed_walk(EdWalker& wk, int x, int y, unsigned S, u
   return n;
 }
 
-__global__ __launch_bounds__(64) void k_ed_route(EdBatch B) {
+// One work-group of four waves per frame: wave 0 walks (everything below), waves 1-3 only help to load tiles of routing words
+// -- a reload was four dependent batches of loads for a lone wave (15 % of the kernel), it is one batch per wave now.  The
+// helpers sit at a work-group barrier between requests (no polling); every barrier of the walker belongs to a request.
+__global__ __launch_bounds__(64 * ED_ROUTE_WAVES) void k_ed_route(EdBatch B) {
   extern __shared__ unsigned ed_sm[];
-  const int n = blockIdx.x, lane = threadIdx.x;
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int W = B.W, H = B.H;
   const int nWords = (W * H + 31) >> 5;
   EdWalker wk;
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(64) void k_ed_route(EdBatch B) {
   wk.tx0 = -1; wk.ty0 = 0;
   wk.nSteps = wk.nLoads = wk.nWalks = 0;
   const long long t0 = __builtin_readcyclecounter();
-  for (int k = lane; k < nWords; k += 64) wk.bits[k] = 0;
+  for (int k = threadIdx.x; k < nWords; k += 64 * ED_ROUTE_WAVES) wk.bits[k] = 0;
   const uint32_t* ax = B.anchX + (size_t)n * B.cap;
   const uint32_t* ay = B.anchY + (size_t)n * B.cap;
   uint32_t* fX = B.fX + (size_t)n * B.cap;
@@ -313,6 +323,14 @@ __global__ __launch_bounds__(64) void k_ed_route(EdBatch B) {
   const int nA = B.nAnch[n];
   int nC = 0, nE = 0;   // chain pixels written, edges accepted (uniform across the wave)
   __syncthreads();
+  if (wave != 0) {
+    for (;;) {
+      __syncthreads();   // A: a request of the walker
+      if (wk.ring[0] == 2u) return;
+      ed_tile_rows(wk, (int)wk.ring[1], (int)wk.ring[2], wave, lane);
+      __syncthreads();   // B
+    }
+  }
   for (int i0 = 0; i0 < nA; i0 += 64) {
     // 64 anchors per trip: coordinates and routing word of the anchor pixel (its direction) in one latency
     unsigned mx = 0, my = 0;
@@ -337,16 +355,21 @@ __global__ __launch_bounds__(64) void k_ed_route(EdBatch B) {
       const int ns = ed_walk(wk, x, y, h, cX + nC + nf - 1, cY + nC + nf - 1, room > 0 ? room : 0);
       const bool go = nf + ns >= B.minLineLen + 1 && nE < B.capEdges && nC + nf + ns - 1 <= 2 * B.cap && nf <= B.cap;
       if (go) {
-        // chain = reverse(first part) ++ second part without the anchor
-        __syncthreads();
+        // chain = reverse(first part) ++ second part without the anchor (the scratch arrays were written by other lanes of
+        // this wave: a fence, not a work-group barrier -- those belong to the tile requests)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
         for (int q = lane; q < nf; q += 64) { cX[nC + nf - 1 - q] = fX[q]; cY[nC + nf - 1 - q] = fY[q]; }
         if (lane == 0) sId[nE] = nC;
         nC += nf + ns - 1;
         nE += 1;
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }
+  if (lane == 0) wk.ring[0] = 2u;      // the helpers leave
+  __syncthreads();                     // A
   if (lane == 0) {
     sId[nE] = nC;
     B.nEdges[n] = nE;

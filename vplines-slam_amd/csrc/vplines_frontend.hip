@@ -271,7 +271,7 @@ int vpl_edlines_detect(vpl_fe_ctx* c, const vpl_edline_param* p) {
   { FeTimer t(c, "k_ed_grad"); hipLaunchKernelGGL(k_ed_grad, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B); }
   { FeTimer t(c, "k_ed_anchor"); hipLaunchKernelGGL(k_ed_anchor, dim3(c->n), dim3(1024), 0, s, B); }
   { FeTimer t(c, "k_ed_code"); hipLaunchKernelGGL(k_ed_code, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B); }
-  { FeTimer t(c, "k_ed_route"); hipLaunchKernelGGL(k_ed_route, dim3(c->n), dim3(64), c->routeSmem, s, B); }
+  { FeTimer t(c, "k_ed_route"); hipLaunchKernelGGL(k_ed_route, dim3(c->n), dim3(64 * ED_ROUTE_WAVES), c->routeSmem, s, B); }
   { FeTimer t(c, "k_ed_fit"); hipLaunchKernelGGL(k_ed_fit, dim3(ED_FIT_BLOCKS, c->n), dim3(64), 0, s, B); }
   FECHK(c, hipGetLastError());
   return VPL_OK;
