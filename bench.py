@@ -306,12 +306,12 @@ def frontend_config4(torch, v, dev, steps=5, warm=2, n=64, imgs=None):
     pairs = [(i, i + 1) for i in range(n - 1)]
 
     def step():
+        # detector -> matcher on the device (vpl_match_from_detected); lines and matches come back at the end of the batch
         fe.detect()
-        fe.synchronize()
-        lines = [l[:256] for l in fe.download()]
-        fe.match_upload(pairs, [lines[a] for a, _ in pairs], [lines[b] for _, b in pairs])
+        fe.match_from_detected(pairs, 256)
         fe.match_run()
         fe.synchronize()
+        lines = [l[:256] for l in fe.download()]
         return lines, fe.match_download()
 
     for _ in range(warm):

@@ -124,6 +124,12 @@ int vpl_match_reserve(vpl_fe_ctx* ctx, int max_pairs, int max_kps);
 /* three-phase form.  lines_ref / lines_cur: [n_pairs][max_lines_per_image] (the stride given to vpl_fe_create). */
 int vpl_match_upload(vpl_fe_ctx* ctx, int n_pairs, const int* ref_image, const int* cur_image,
                      const vpl_line* lines_ref, const int* n_ref, const vpl_line* lines_cur, const int* n_cur);
+/* The lines of this context's last vpl_edlines_detect as the matcher's input, device to device: what
+ * LineFeatureTracker::readImage does between detector and matcher (line_feature_tracker.cpp:110-118, :290-322) without the lines
+ * leaving HBM.  At most max_lines lines per frame take part (the first ones in the detector's order).  Asynchronous.
+ * vpl_match_counts: how many lines of each pair's frames take part (sizes of the rows vpl_match_download fills). */
+int vpl_match_from_detected(vpl_fe_ctx* ctx, int n_pairs, const int* ref_image, const int* cur_image, int max_lines);
+int vpl_match_counts(vpl_fe_ctx* ctx, int n_pairs, int* n_ref, int* n_cur);
 int vpl_match_run(vpl_fe_ctx* ctx, const vpl_match_param* param);   /* enqueue; asynchronous */
 /* line_ref_to_line_cur [n_pairs][max_lines] (-1 = unmatched; rows of pairs with matched == 0 are left untouched, as
  * Matching() leaves its output vector when it returns false); matched [n_pairs] = Matching()'s return value.

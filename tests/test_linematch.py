@@ -216,3 +216,36 @@ def test_gpu_matching_edge_cases():
     with pytest.raises(RuntimeError):
         fs.match_debug_level(0, 2)
     fs.close()
+
+
+@pytest.mark.gpu
+def test_matcher_fed_from_the_detector_on_the_device_equals_the_host_hand_over():
+    """vpl_match_from_detected: the lines of the last detect() go to the matcher device to device (sorted into the reference's
+    order and converted to the wire layout by k_ed_sort_lines) -- same matches, same lines as download + vpl_match_upload."""
+    import vplines_slam_amd as v
+    imgs = v.workload.frame_stream(8)
+    fe = v.frontend.FrontendContext(device=0, max_images=8, width=752, height=480, max_lines=256)
+    fe.match_reserve(7, 8192)
+    fe.upload(imgs)
+    pairs = [(i, i + 1) for i in range(7)]
+    fe.detect()
+    fe.synchronize()
+    lines = [l[:200] for l in fe.download()]
+    fe.match_upload(pairs, [lines[a] for a, _ in pairs], [lines[b] for _, b in pairs])
+    fe.match_run()
+    fe.synchronize()
+    r_host, ok_host = fe.match_download()
+    fe.detect()
+    fe.match_from_detected(pairs, 200)
+    fe.match_run()
+    fe.synchronize()
+    r_dev, ok_dev = fe.match_download()
+    lines2 = [l[:200] for l in fe.download()]
+    assert ok_host == ok_dev and sum(ok_dev) >= 5
+    for a, b in zip(r_host, r_dev):
+        assert np.array_equal(a, b)
+    for a, b in zip(lines, lines2):
+        assert a.tobytes() == b.tobytes()
+    nr, nc = fe.match_counts()
+    assert nr == [len(lines[a]) for a, _ in pairs] and nc == [len(lines[b]) for _, b in pairs]
+    fe.close()

@@ -1,10 +1,12 @@
 """Secondary metric of SURVEY 8(d), config 4: frames/s of the whole line front-end -- EDLines on 64 frames 752x480 plus KLT
-line matching of the 63 consecutive pairs -- with the frames resident in HBM.  The detected lines pass through the host
-between the two stages, as they do in the reference (the tracker owns them); that round trip is inside the timed region.
+line matching of the 63 consecutive pairs -- with the frames resident in HBM.  The detected lines go from the detector to the matcher on the
+device (vpl_match_from_detected) and are downloaded, with the matches, at the end of the batch (VPL_FE_HOST_HANDOVER=1: through
+the host between the two stages, as rounds 1-3 measured it); all of it inside the timed region.
 With --prep the raw frames first go through the undistortion remap + CLAHE(3.0, 8x8) of LineFeatureTracker::readImage
 (EuRoC cam0 maps) on the device, inside the timed region.  With --vp the vanishing-point stage runs on the lines of every
 frame after the match (hypotheses from all lines of the frame), also inside the timed region.  Prints one JSON line."""
-import json, os, sys, time
+import json
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.dirname(__file__))
 import numpy as np
@@ -40,12 +42,17 @@ def main():
         if prep:
             fe.pre_run(True, 3.0, (8, 8))
         fe.detect()
-        fe.synchronize()
-        lines = fe.download()
-        lines = [l[:256] for l in lines]
-        fe.match_upload(pairs, [lines[a] for a, _ in pairs], [lines[b] for _, b in pairs])
+        if os.environ.get("VPL_FE_HOST_HANDOVER"):      # rounds 1-3: the lines went through the host between detector and matcher
+            fe.synchronize()
+            lines = fe.download()
+            lines = [l[:256] for l in lines]
+            fe.match_upload(pairs, [lines[a] for a, _ in pairs], [lines[b] for _, b in pairs])
+        else:
+            fe.match_from_detected(pairs, 256)          # device to device (vpl_match_from_detected)
         fe.match_run()
         fe.synchronize()
+        if not os.environ.get("VPL_FE_HOST_HANDOVER"):
+            lines = [l[:256] for l in fe.download()]
         out = fe.match_download()
         if vp:
             t = time.perf_counter()

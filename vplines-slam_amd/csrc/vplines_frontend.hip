@@ -29,6 +29,8 @@ struct vpl_fe_ctx {
   bool lmReserved = false;
   int *d_refImg = nullptr, *d_curImg = nullptr, *d_nRef = nullptr, *d_nCur = nullptr;
   vpl_line *d_linesRef = nullptr, *d_linesCur = nullptr;
+  vpl_line* d_sorted = nullptr;       // [maxN][maxLines] the detected lines in the reference's order (k_ed_sort_lines)
+  int* d_sortedCnt = nullptr;         // [maxN]
   // image preparation (remap + CLAHE)
   uint8_t *d_raw = nullptr, *d_mid = nullptr, *d_lut = nullptr;
   float *d_mapx = nullptr, *d_mapy = nullptr;
@@ -95,6 +97,39 @@ void vpl_edline_default_param(vpl_edline_param* p) {
   p->minLineLen = 35; p->lineFitErrThreshold = 1.8;
 }
 
+// The detected lines of a frame in their deterministic order -- by (edge chain, ordinal inside the chain), the order the
+// reference's sequential loop produces -- and in the vpl_line layout, ON THE DEVICE: vpl_edlines_download copies this table, and
+// vpl_match_from_detected hands it to the matcher without a host round trip.  One work-group per frame; the rank of a line is
+// the number of keys below its own (keys are unique; <= maxLines lines).
+__global__ __launch_bounds__(256) void k_ed_sort_lines(EdBatch B, vpl_line* out, int* outCnt, int ML) {
+  const int n = blockIdx.x;
+  const int m = min(B.nLines[n], ML);
+  if (threadIdx.x == 0) outCnt[n] = m;
+  const uint32_t* K = B.lkey + (size_t)n * ML;
+  for (int k = threadIdx.x; k < m; k += blockDim.x) {
+    const uint32_t key = K[k];
+    int rank = 0;
+    for (int j = 0; j < m; ++j) rank += K[j] < key ? 1 : 0;
+    const double* o = B.lines + ((size_t)n * ML + k) * 10;
+    vpl_line& dst = out[(size_t)n * ML + rank];
+    for (int q = 0; q < 4; ++q) dst.line_endpoint[q] = (float)o[q];
+    for (int q = 0; q < 3; ++q) dst.line_equation[q] = o[4 + q];
+    dst.center[0] = (float)o[7]; dst.center[1] = (float)o[8];
+    dst.length = (float)o[9];
+  }
+}
+// lines of the pairs' frames out of the sorted table (at most `cap` per frame)
+__global__ __launch_bounds__(256) void k_lm_take_lines(const vpl_line* sorted, const int* cnt, int ML, int cap, const int* refImg,
+                                                       const int* curImg, vpl_line* linesRef, vpl_line* linesCur, int* nRef, int* nCur) {
+  const int i = blockIdx.x, side = blockIdx.y;
+  const int img = side ? curImg[i] : refImg[i];
+  const int m = min(cnt[img], cap);
+  if (threadIdx.x == 0) (side ? nCur : nRef)[i] = m;
+  vpl_line* dst = (side ? linesCur : linesRef) + (size_t)i * ML;
+  const vpl_line* src = sorted + (size_t)img * ML;
+  for (int k = threadIdx.x; k < m; k += blockDim.x) dst[k] = src[k];
+}
+
 int vpl_fe_create(vpl_fe_ctx** out, int device, int max_images, int width, int height, int max_lines_per_image) {
   if (!out || max_images < 1 || width < 8 || height < 8 || max_lines_per_image < 1) return VPL_E_INVALID;
   int nd = 0;
@@ -120,6 +155,7 @@ int vpl_fe_create(vpl_fe_ctx** out, int device, int max_images, int width, int h
   AL(B.fX, N * B.cap); AL(B.fY, N * B.cap); AL(B.cX, N * 2 * B.cap); AL(B.cY, N * 2 * B.cap);
   AL(B.sId, N * (B.capEdges + 2)); AL(B.nEdges, N);
   AL(B.lines, N * B.maxLines * 10); AL(B.lkey, N * B.maxLines); AL(B.nLines, N);
+  AL(c->d_sorted, N * B.maxLines); AL(c->d_sortedCnt, N);
 #undef AL
   // k_ed_route keeps the frame's edge bitmap and one tile of routing codes in LDS
   c->routeSmem = (size_t)(((((size_t)width * height + 31) >> 5) + 3) & ~(size_t)3) * 4 + ED_TILE * ED_TILE * 2 + 64 * 4;
@@ -273,6 +309,7 @@ int vpl_edlines_detect(vpl_fe_ctx* c, const vpl_edline_param* p) {
   { FeTimer t(c, "k_ed_code"); hipLaunchKernelGGL(k_ed_code, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B); }
   { FeTimer t(c, "k_ed_route"); hipLaunchKernelGGL(k_ed_route, dim3(c->n), dim3(64 * ED_ROUTE_WAVES), c->routeSmem, s, B); }
   { FeTimer t(c, "k_ed_fit"); hipLaunchKernelGGL(k_ed_fit, dim3(ED_FIT_BLOCKS, c->n), dim3(64), 0, s, B); }
+  { FeTimer t(c, "k_ed_sort_lines"); hipLaunchKernelGGL(k_ed_sort_lines, dim3(c->n), dim3(256), 0, s, B, c->d_sorted, c->d_sortedCnt, c->maxLines); }
   FECHK(c, hipGetLastError());
   return VPL_OK;
 }
@@ -281,29 +318,11 @@ int vpl_edlines_download(vpl_fe_ctx* c, int n, vpl_line* lines, int* counts) {
   if (!c || n != c->n || !lines || !counts) return VPL_E_INVALID;
   FECHK(c, hipSetDevice(c->device));
   const size_t ML = c->maxLines;
-  std::vector<double> L((size_t)n * ML * 10);
-  std::vector<uint32_t> K((size_t)n * ML);
-  std::vector<int> cnt(n);
-  FECHK(c, hipMemcpyAsync(cnt.data(), c->B.nLines, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  FECHK(c, hipMemcpyAsync(L.data(), c->B.lines, L.size() * 8, hipMemcpyDeviceToHost, c->stream));
-  FECHK(c, hipMemcpyAsync(K.data(), c->B.lkey, K.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  // (the deterministic order -- edge chain, ordinal inside the chain -- and the vpl_line layout are made on the device by
+  // k_ed_sort_lines; rows beyond counts[i] are not defined)
+  FECHK(c, hipMemcpyAsync(counts, c->d_sortedCnt, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipMemcpyAsync(lines, c->d_sorted, (size_t)n * ML * sizeof(vpl_line), hipMemcpyDeviceToHost, c->stream));
   FECHK(c, hipStreamSynchronize(c->stream));
-  for (int i = 0; i < n; ++i) {
-    const int m = std::min<int>(cnt[i], (int)ML);
-    counts[i] = m;
-    // deterministic order: (edge chain, ordinal inside the chain) -- plumbing, the lines themselves come from the device
-    std::vector<int> ord(m);
-    for (int k = 0; k < m; ++k) ord[k] = k;
-    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return K[i * ML + a] < K[i * ML + b]; });
-    for (int k = 0; k < m; ++k) {
-      const double* o = &L[((size_t)i * ML + ord[k]) * 10];
-      vpl_line& dst = lines[(size_t)i * ML + k];
-      for (int q = 0; q < 4; ++q) dst.line_endpoint[q] = (float)o[q];
-      for (int q = 0; q < 3; ++q) dst.line_equation[q] = o[4 + q];
-      dst.center[0] = (float)o[7]; dst.center[1] = (float)o[8];
-      dst.length = (float)o[9];
-    }
-  }
   return VPL_OK;
 }
 
@@ -432,6 +451,39 @@ int vpl_match_upload(vpl_fe_ctx* c, int n_pairs, const int* ref_image, const int
   FECHK(c, hipMemcpyAsync(c->d_linesCur, lines_cur, P * ML * sizeof(vpl_line), hipMemcpyHostToDevice, s));
   FECHK(c, hipStreamSynchronize(s));   // the caller's buffers may be pageable and short-lived
   c->nPairs = n_pairs;
+  return VPL_OK;
+}
+
+// The lines of the last vpl_edlines_detect of this context as the matcher's input, device to device (LineFeatureTracker::readImage
+// keeps the previous frame's lines and matches the new frame's against them: line_feature_tracker.cpp:110-118, :290-322): no download /
+// upload of the lines between the two stages.  At most max_lines lines per frame take part (the first ones in the
+// detector's order).  Asynchronous on the context's stream.
+int vpl_match_from_detected(vpl_fe_ctx* c, int n_pairs, const int* ref_image, const int* cur_image, int max_lines) {
+  if (!c || !c->lmReserved || n_pairs < 1 || !ref_image || !cur_image || max_lines < 1) return VPL_E_INVALID;
+  if (n_pairs > c->maxPairs) return fe_fail(c, VPL_E_CAPACITY, "more pairs than max_pairs");
+  if (c->n < 1) return fe_fail(c, VPL_E_INVALID, "no images uploaded");
+  for (int i = 0; i < n_pairs; ++i)
+    if (ref_image[i] < 0 || ref_image[i] >= c->n || cur_image[i] < 0 || cur_image[i] >= c->n)
+      return fe_fail(c, VPL_E_INVALID, "pair names an image that was not uploaded");
+  FECHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t P = n_pairs;
+  FECHK(c, hipMemcpyAsync(c->d_refImg, ref_image, P * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipMemcpyAsync(c->d_curImg, cur_image, P * 4, hipMemcpyHostToDevice, s));
+  FECHK(c, hipStreamSynchronize(s));   // (two small index arrays; the caller's buffers may be short-lived)
+  hipLaunchKernelGGL(k_lm_take_lines, dim3(n_pairs, 2), dim3(256), 0, s, c->d_sorted, c->d_sortedCnt, c->maxLines,
+                     std::min(max_lines, c->maxLines), c->d_refImg, c->d_curImg, c->d_linesRef, c->d_linesCur, c->d_nRef, c->d_nCur);
+  FECHK(c, hipGetLastError());
+  c->nPairs = n_pairs;
+  return VPL_OK;
+}
+// number of lines of every pair's two frames that take part in the match (after vpl_match_upload / vpl_match_from_detected)
+int vpl_match_counts(vpl_fe_ctx* c, int n_pairs, int* n_ref, int* n_cur) {
+  if (!c || !c->lmReserved || n_pairs != c->nPairs || !n_ref || !n_cur) return VPL_E_INVALID;
+  FECHK(c, hipSetDevice(c->device));
+  FECHK(c, hipMemcpyAsync(n_ref, c->d_nRef, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipMemcpyAsync(n_cur, c->d_nCur, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipStreamSynchronize(c->stream));
   return VPL_OK;
 }
 

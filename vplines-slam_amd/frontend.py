@@ -103,6 +103,8 @@ def _bind(lib):
     lib.vpl_match_reserve.argtypes = [vp, C.c_int, C.c_int]
     lib.vpl_match_upload.argtypes = [vp, C.c_int, ip, ip, C.POINTER(Line), ip, C.POINTER(Line), ip]
     lib.vpl_match_run.argtypes = [vp, C.POINTER(MatchParam)]
+    lib.vpl_match_from_detected.argtypes = [vp, C.c_int, ip, ip, C.c_int]
+    lib.vpl_match_counts.argtypes = [vp, C.c_int, ip, ip]
     lib.vpl_match_download.argtypes = [vp, C.c_int, ip, ip]
     lib.vpl_line_match_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8), C.c_int, ip, ip, C.POINTER(Line), ip,
                                          C.POINTER(Line), ip, C.POINTER(MatchParam), ip, ip]
@@ -292,6 +294,20 @@ class FrontendContext:
         self._check(self.lib.vpl_match_upload(self.h, self.n_pairs, ri, ci, lr.ctypes.data_as(C.POINTER(Line)), nr,
                                               lc.ctypes.data_as(C.POINTER(Line)), nc), "vpl_match_upload")
 
+    def match_from_detected(self, pairs, max_lines=None):
+        """vpl_match_from_detected: the lines of the last detect() as the matcher's input, device to device"""
+        self.n_pairs = len(pairs)
+        ri = (C.c_int * self.n_pairs)(*[p[0] for p in pairs])
+        ci = (C.c_int * self.n_pairs)(*[p[1] for p in pairs])
+        self._check(self.lib.vpl_match_from_detected(self.h, self.n_pairs, ri, ci, int(max_lines or self.max_lines)),
+                    "vpl_match_from_detected")
+        self._nref = None
+
+    def match_counts(self):
+        nr, nc = (C.c_int * self.n_pairs)(), (C.c_int * self.n_pairs)()
+        self._check(self.lib.vpl_match_counts(self.h, self.n_pairs, nr, nc), "vpl_match_counts")
+        return [int(x) for x in nr], [int(x) for x in nc]
+
     def match_run(self, param=None):
         self._mparam = param or default_match_param()
         self._check(self.lib.vpl_match_run(self.h, C.byref(self._mparam)), "vpl_match_run")
@@ -301,6 +317,8 @@ class FrontendContext:
         ok = (C.c_int * self.n_pairs)()
         self._check(self.lib.vpl_match_download(self.h, self.n_pairs, a.ctypes.data_as(C.POINTER(C.c_int)), ok),
                     "vpl_match_download")
+        if self._nref is None:
+            self._nref = self.match_counts()[0]
         return [a[i, :self._nref[i]].copy() for i in range(self.n_pairs)], [int(x) for x in ok]
 
     def match_batch(self, images, pairs, lines_ref, lines_cur, param=None):
