@@ -149,7 +149,7 @@ __global__ __launch_bounds__(128) void k_gauge(DevBatch B) { gauge_body(B, block
 // left in A (upper part zeroed), perm[t] = original index of row t.  An optional right-hand side c (length n, permuted in
 // step) rides along: on exit c[k] = y_k for k < rank, where L(0:rank,0:rank) y = (P c)(0:rank).
 // Stops at the first pivot <= max(abs_tol, max(n eps, rel_tol) * max_i a_ii); the trailing block is then treated as zero.
-__device__ int psd_pivoted_cholesky(double* A, int n, int ld, int* perm, double* red, int* iflag, double rel_tol,
+__device__ __forceinline__ int psd_pivoted_cholesky(double* A, int n, int ld, int* perm, double* red, int* iflag, double rel_tol,
                                     double abs_tol, double* c, double* col /* n doubles of scratch */) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
   for (int i = tid; i < n; i += T) perm[i] = i;
@@ -229,7 +229,7 @@ __device__ int psd_pivoted_cholesky(double* A, int n, int ld, int* perm, double*
 // (the permutation is applied once at the end).  The work-group version above pays five barriers per pivot step
 // (~3.9 k cycles; 175 k for the 45 x 45 kept block).  All threads of the block must call it; Lo is n x ld scratch.
 template <int NMAX>
-__device__ int psd_pivoted_cholesky_wave(double* A, int n, int ld, int* perm, int* iflag, double rel_tol, double abs_tol,
+__device__ __forceinline__ int psd_pivoted_cholesky_wave(double* A, int n, int ld, int* perm, int* iflag, double rel_tol, double abs_tol,
                                          double* c, double* Lo /* n x ld + NMAX doubles */) {
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
   double* col = Lo + n * ld;             // NMAX: the pivot column, zero beyond n -- the loops over it have no bounds checks
@@ -308,7 +308,7 @@ __device__ int psd_pivoted_cholesky_wave(double* A, int n, int ld, int* perm, in
   return rank;
 }
 
-__device__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* lam, double* red, int* iflag,
+__device__ __forceinline__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* lam, double* red, int* iflag,
                                    double rel_tol, double* Lo /* n x ld scratch */) {
   const int tid = threadIdx.x, T = blockDim.x;
   const int rank = n <= 16 ? psd_pivoted_cholesky_wave<16>(A, n, ld, perm, iflag, rel_tol, 0.0, nullptr, Lo)
@@ -381,32 +381,38 @@ static_assert(MAXKEEP <= 80, "psd_spectral_factor keeps 10 rows per lane (8 lane
 
 // LDS layout of k_marg (doubles), shared by host (size) and device (offsets)
 struct MargLayout {
-  int ldm, EB, nd, ldd, total, mtrows;
+  int ldm, EB, nd, ldd, total, mtrows, loff;
 };
-__host__ __device__ inline MargLayout marg_layout(int n) {
+// small = the 256-thread form of k_marg: at most 79 KB, so that two work-groups share a CU (most of the kernel is a lone
+// wave factoring a 15 x 15 and the kept block while the other waves wait: a second window on the CU uses the idle SIMDs);
+// its landmark lists hold 256 entries per kind
+constexpr size_t MARG_LDS_BIG = 150 * 1024, MARG_LDS_SMALL = 79 * 1024;
+__host__ __device__ inline MargLayout marg_layout(int n, bool small = false) {
   MargLayout L;
+  L.loff = small ? 256 : 1024;
   const int nn = n < 2 ? 2 : n;
   L.ldm = nn | 1;                       // odd row stride
   L.EB = nn * L.ldm;
   L.nd = 15 + n;
   L.ldd = L.nd | 1;
   // G (kept block) | Ad (nd x ldd) | tile | E15 (15 x 17) | bv(nd) | tmp(nd*16) | lam(nn) | red(24) | ints
-  const int fixed = L.EB + L.nd * L.ldd + 16 * 17 + L.nd + (L.nd * 16 < 640 ? 640 : L.nd * 16) + nn + 16 + 24 + (nn + L.nd + 2048 + 16) / 2 + 4;
+  const int fixed = L.EB + L.nd * L.ldd + 16 * 17 + L.nd + (L.nd * 16 < 640 ? 640 : L.nd * 16) + nn + 16 + 24 + (nn + L.nd + 2 * L.loff + 16) / 2 + 4;
   L.mtrows = MTROWS_MAX;
-  while (L.mtrows > 32 && (size_t)(fixed + L.mtrows * 74) * sizeof(double) > 150 * 1024) L.mtrows -= 32;
+  while (L.mtrows > 32 && (size_t)(fixed + L.mtrows * 74) * sizeof(double) > (small ? MARG_LDS_SMALL : MARG_LDS_BIG)) L.mtrows -= 32;
   L.total = fixed + L.mtrows * 74;
   return L;
 }
 
+template <int T>
 __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double* sm) {
-  const int tid = threadIdx.x, T = MARG_THREADS;
+  const int tid = threadIdx.x;
   const int nP = B.nP[w], nL = B.nL[w];
   const int nb = B.mg_nb[w];
   const int n = B.mg_n[w];
   if (n == 0) return;   // MARGIN_SECOND_NEW without pose[WINDOW_SIZE-1] in the prior: nothing to do (estimator.cpp:1385)
   const bool second_new = B.opt.marginalization_flag == 1;
   const int md = second_new ? 6 : 15;    // dims marginalised through the pseudo-inverse
-  const MargLayout L = marg_layout(n);
+  const MargLayout L = marg_layout(n, T == 256);
   const int nd = md + n, ldd = L.ldd, ldm = L.ldm;
   double* G = sm;                        // n x ldm : kept block -> spectral factor
   double* Ad = G + L.EB;                 // nd x ldd dense pre-marginalisation matrix
@@ -419,8 +425,8 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   double* red = lam + (n < 2 ? 2 : n) + 16;   // 24
   int* perm = (int*)(red + 24);          // max(n, 15)
   int* dmap = perm + (n < 16 ? 16 : n) + (n & 1);   // nd
-  int* lst = dmap + nd + (nd & 1);       // 2 x 1024
-  constexpr int LOFF = 1024;
+  int* lst = dmap + nd + (nd & 1);       // 2 x LOFF
+  const int LOFF = L.loff;
   __shared__ int s_np0, s_nl0, s_flag[4];
 
   // dense order: [sb_0 (9), pose_0 (6) | kept blocks in canonical order]  (the reference moves the
@@ -604,9 +610,7 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
       const int lane = tid & 63, wv = tid >> 6, m = lane & 15, kk = lane >> 4;
       const int ksteps = (nrows + 3) >> 2;
 #pragma unroll 1
-      for (int q = 0; q < 2; ++q) {
-        const int tix2 = wv + 8 * q;
-        if (tix2 >= 15) break;
+      for (int tix2 = wv; tix2 < 15; tix2 += T / 64) {
         int ta, tb;
         tri_decode(tix2, ta, tb);
         const int ca = 16 * ta + m, cb = 16 * tb + m;
@@ -768,9 +772,10 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   }
   VPL_STAMP(B, w, 37);
 }
-__global__ __launch_bounds__(MARG_THREADS) void k_marg(DevBatch B) {
+template <int T>
+__global__ __launch_bounds__(T) void k_marg(DevBatch B) {
   extern __shared__ double sm[];
-  marg_body(B, blockIdx.x, sm);
+  marg_body<T>(B, blockIdx.x, sm);
 }
 
 // Prior handoff on the device (vpl_ba_upload_chained): the prior the previous solve's marginalisation left in mg_* becomes the

@@ -61,6 +61,7 @@ struct vpl_ctx {
   std::vector<int> h_nP, h_nL;
   std::vector<std::vector<int>> h_lmap;          // per window: device line index -> index in the vpl_window arrays
   size_t marg_smem = 0;
+  bool marg_small = false;                       // k_marg<256> (two work-groups per CU) instead of k_marg<512>
   int maxPriorN = 0;                             // largest prior of the uploaded batch (k_prep stages J0 in LDS)
   // asynchronous variants of the line-map entry points: the host-side completion (wait for the stream, scatter the staged
   // results into the caller's arrays) of the call that was enqueued last; run by vpl_ba_collect or by the next call that
@@ -310,7 +311,8 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   hipFuncSetAttribute((const void*)k_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_SMEM);
   hipFuncSetAttribute((const void*)k_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)back_max);
   hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SMEM);
-  hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+  hipFuncSetAttribute((const void*)k_marg<MARG_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+  hipFuncSetAttribute((const void*)k_marg<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS_SMALL);
   (void)hipGetLastError();
   vpl_ba_default_options(&c->opt);
   if (const char* gv = std::getenv("VPL_BA_GRAPH")) c->use_graph = std::atoi(gv) != 0;
@@ -766,7 +768,10 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   {
     int nmax = 0;
     for (size_t w = 0; w < W; ++w) nmax = std::max(nmax, mg_n[w]);
-    c->marg_smem = (size_t)marg_layout(nmax).total * sizeof(double);
+    // kept blocks of up to 48 dims (the one-wave factorisations) whose workspace fits 79 KB: 256 threads, two work-groups per CU
+    c->marg_small = nmax <= 48 && B.maxP <= 256 && B.maxL <= 256 &&
+                    (size_t)marg_layout(nmax, true).total * sizeof(double) <= MARG_LDS_SMALL && std::getenv("VPL_BA_MARG_BIG") == nullptr;
+    c->marg_smem = (size_t)marg_layout(nmax, c->marg_small).total * sizeof(double);
     if (c->marg_smem > 159 * 1024) return fail(c, VPL_E_CAPACITY, "marginalisation workspace exceeds LDS");
   }
   HIPCHK(c, up(c, B.pose, pose)); HIPCHK(c, up(c, B.sb, sb)); HIPCHK(c, up(c, B.ex, ex)); HIPCHK(c, up(c, B.invd, invd));
@@ -1125,11 +1130,11 @@ static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
   if (c->opt.marginalization_flag == VPL_MARGIN_OLD) {
     { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<1>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
     ++B.launch;
-    { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
+    { KTimer t(c, "k_marg"); if (c->marg_small) hipLaunchKernelGGL(k_marg<256>, grid, dim3(256), c->marg_smem, s, B); else hipLaunchKernelGGL(k_marg<MARG_THREADS>, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   } else if (c->any_second_new) {
     { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<2>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
     ++B.launch;
-    { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
+    { KTimer t(c, "k_marg"); if (c->marg_small) hipLaunchKernelGGL(k_marg<256>, grid, dim3(256), c->marg_smem, s, B); else hipLaunchKernelGGL(k_marg<MARG_THREADS>, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   }
 }
 
@@ -1302,7 +1307,7 @@ static int marginalize_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl
     { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<2>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
     ran = true;
   }
-  if (ran) { KTimer t(c, "k_marg"); hipLaunchKernelGGL(k_marg, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
+  if (ran) { KTimer t(c, "k_marg"); if (c->marg_small) hipLaunchKernelGGL(k_marg<256>, grid, dim3(256), c->marg_smem, s, B); else hipLaunchKernelGGL(k_marg<MARG_THREADS>, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   HIPCHK(c, hipGetLastError());
   // (the priors are fetched from the device when the call completes: any later call on the context completes this one first)
   return finish_or_defer(c, async, [c, nW, priors, m_out, n_out]() -> int {
