@@ -3,8 +3,10 @@
 //   EDLineDetector::EdgeDrawing          line_matching/src/edline_detector.cpp:81-710
 //   EDLineDetectorParallel::operator()   :960-1174   (LeastSquaresLineFit :729-891, LineValidation :893-958)
 //   EDLineDetector::EDline               :1176-1198  ; nfa / log_gamma  edline_detector.h:186-348
-// Only the production configuration is restated: smoothed = true (no Gaussian blur,
-// feature_tracker/src/line_feature_tracker.cpp:87 -> edline_detector.cpp:82-86).
+// Production passes smoothed = true (no Gaussian blur, feature_tracker/src/line_feature_tracker.cpp:87 ->
+// edline_detector.cpp:82-86); the reference's default and both of its demo programs pass smoothed = false
+// (edline_detector.h:79-81, test_edline_detector.cpp:27, test_line_matching.cpp:54,74): cv::GaussianBlur(image, image_,
+// Size(ksize, ksize), sigma) first -- ed_gaussian_blur below.
 //
 // OpenCV 3.4 (third party, not in the tree) supplies Sobel / absdiff / add / threshold / Mat division /
 // compare / the float GEMM of the line fit.  Their arithmetic is restated from the published behaviour:
@@ -12,7 +14,21 @@
 //   threshold(THRESH_TOZERO) on CV_16S: dst = src > thresh ? src : 0;
 //   Mat / 4 on CV_16S: saturate_cast<short>(src * 0.25) = round half to even;
 //   Mat_<float> products (gemm, small sizes): products and sums in double, result cast to float.
-// PARITY UNPINNED: the reference holds no numeric fixture for this path (only rendered pictures).
+//   GaussianBlur on CV_8UC1 (imgproc/smooth.cpp, the bit-exact fixed-point path OpenCV takes for 8-bit images since
+//   3.4.1 when no IPP / OpenVX / HAL replacement is compiled in): the 1-D kernel in unsigned 8.8 fixed point, a row pass
+//   into 8.8 values (ufixedpoint16), a column pass into 16.16 (ufixedpoint32), (v + 0x8000) >> 16 saturated to 8 bits,
+//   BORDER_REFLECT_101.  Two published roundings of the kernel exist:
+//     3.4.1 .. 3.4.8 / 4.0 .. 4.1:  k_i = cvRound(256 g_i)                         (5, sigma 1: 14 63 103 63 14, sum 257)
+//     3.4.9+ / 4.2+ (getGaussianKernelFixedPoint_ED):  error diffusion from the ends to the centre, the centre tap takes
+//                    what is left of 256                                          (5, sigma 1: 14 62 104 62 14)
+//   The reference's README names OpenCV 3.4.2; its own rendered output (below) is reproduced only by the SECOND kernel,
+//   which is therefore the default here (ED_BLUR_NORMALISED); the first is kept as ED_BLUR_OPENCV_341.
+// PINNED (front-end, smoothed = false path): line_matching/data/edline_result.png is the reference's own output of
+// test_edline_detector.cpp (mh04/imgs/1.png, {5, 1, 30, 5, 2, 25, 1.8}, smoothed = false).  The segments recovered from
+// that picture (tests/golden/make_edline_result_segments.py -> tests/golden/edline_result_segments.npz) are checked
+// against this restatement in tests/test_edline_reference_picture.py: same number of lines, every pixel of every
+// restated line painted in the picture, every painted pixel of the picture explained by a restated line or its arrows.
+// Nothing else of the front-end has a reference-held expected output.
 #include <array>
 #include <cmath>
 #include <cfloat>
@@ -43,6 +59,80 @@ static inline int refl101(int i, int n) {   // BORDER_REFLECT_101
   return i;
 }
 static inline short div4_half_even(short v) { return (short)std::nearbyint((double)v * 0.25); }
+
+// ---- cv::GaussianBlur on 8-bit images (edline_detector.cpp:82-84) ------------------------------------------------------
+enum { ED_BLUR_NORMALISED = 0, ED_BLUR_OPENCV_341 = 1 };
+
+static inline int border101(int p, int len) {   // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
+  if ((unsigned)p < (unsigned)len) return p;
+  if (len == 1) return 0;
+  do { p = p < 0 ? -p : 2 * len - p - 2; } while ((unsigned)p >= (unsigned)len);
+  return p;
+}
+
+// createGaussianKernels + getFixedpointGaussianKernel<ufixedpoint16> (smooth.cpp): ksize <= 0 with sigma > 0 picks
+// cvRound(sigma * 3 * 2 + 1) | 1 (8-bit depth); sigma <= 0 takes the fixed tables for n = 1, 3, 5, 7 and
+// sigma = 0.15 n + 0.35 otherwise.  Returns the kernel size (odd), or -1 for an even / non-positive size.
+// OpenCV evaluates exp() in its softfloat double; the libm value can differ from it in the last place, which moves a tap
+// only if 256 g_i sits within 1e-13 of a rounding boundary.
+int ed_gauss_kernel_q8(int ksize, double sigma, int mode, int* k /* >= ksize entries */, int cap) {
+  if (sigma < 0) sigma = 0;
+  if (ksize <= 0 && sigma > 0) ksize = (int)std::nearbyint(sigma * 3 * 2 + 1) | 1;
+  if (ksize <= 0 || (ksize & 1) == 0 || ksize > cap) return -1;
+  const int n = ksize;
+  std::vector<double> v(n);
+  if (sigma <= 0 && n <= 7) {
+    static const double t1[] = {1.0}, t3[] = {0.25, 0.5, 0.25}, t5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625},
+                        t7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
+    const double* t = n == 1 ? t1 : n == 3 ? t3 : n == 5 ? t5 : t7;
+    for (int i = 0; i < n; ++i) v[i] = t[i];
+  } else {
+    const double sx = sigma > 0 ? sigma : 0.15 * n + 0.35;
+    const double scale2X = -0.5 * 0.25 / (sx * sx);
+    double sum = 0;
+    for (int i = 0, x = 1 - n; i < n; ++i, x += 2) { v[i] = std::exp((double)(x * x) * scale2X); sum += v[i]; }
+    sum = 1.0 / sum;
+    for (int i = 0; i < n; ++i) v[i] *= sum;
+  }
+  if (mode == ED_BLUR_OPENCV_341) {
+    for (int i = 0; i < n; ++i) k[i] = (int)std::nearbyint(v[i] * 256.0);   // ufixedpoint16(softdouble): cvRound(v * 256)
+  } else {   // getGaussianKernelFixedPoint_ED(result, kernel, 8)
+    const int h = n / 2;
+    double err = 0;
+    int sum = 0;
+    for (int i = 0; i < h; ++i) {
+      const double adj = v[i] * 256.0 + err;
+      const int v0 = (int)std::nearbyint(adj);
+      err = adj - v0;
+      k[i] = k[n - 1 - i] = v0;
+      sum += v0;
+    }
+    k[h] = 256 - 2 * sum;
+  }
+  return n;
+}
+
+// fixedSmoothInvoker<uint8_t, ufixedpoint16>: rows then columns, every product and sum exact in 16 / 32 bits
+// (ufixedpoint16 saturates at 0xFFFF, which a kernel summing to <= 257/256 reaches only as the exact value)
+void ed_gaussian_blur(const uint8_t* img, int W, int H, const int* k, int n, uint8_t* out) {
+  const int r = n / 2;
+  std::vector<uint16_t> rows((size_t)W * H);
+  for (int y = 0; y < H; ++y) {
+    const uint8_t* s = img + (size_t)y * W;
+    for (int x = 0; x < W; ++x) {
+      uint32_t a = 0;
+      for (int j = 0; j < n; ++j) a += (uint32_t)k[j] * s[border101(x + j - r, W)];
+      rows[(size_t)y * W + x] = (uint16_t)(a > 0xFFFFu ? 0xFFFFu : a);
+    }
+  }
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      uint64_t a = 0;
+      for (int j = 0; j < n; ++j) a += (uint64_t)k[j] * rows[(size_t)border101(y + j - r, H) * W + x];
+      const uint64_t v = (a + 0x8000u) >> 16;
+      out[(size_t)y * W + x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+}
 
 // edline_detector.cpp:125-136
 void ed_gradient(const uint8_t* img, int W, int H, int gradTh, short* dx, short* dy, short* gImg, uint8_t* dirImg) {
@@ -408,4 +498,30 @@ int orc_edlines(const uint8_t* img, int W, int H, int gradTh, int anchorTh, int 
   return (int)lines.size();
 }
 double orc_nfa(int n, int k, double p, double logNT) { return ed_nfa(n, k, p, logNT); }
+
+// cv::GaussianBlur(image, image_, Size(ksize, ksize), sigma) of EdgeDrawing (edline_detector.cpp:82-84) on its own.
+// kernel_out (may be NULL): the 8.8 fixed-point taps.  Returns the kernel size or -1.
+int orc_gaussian_blur_u8(const uint8_t* img, int W, int H, int ksize, double sigma, int mode, uint8_t* out, int* kernel_out) {
+  int k[64];
+  const int n = ed_gauss_kernel_q8(ksize, sigma, mode, k, 63);
+  if (n < 0) return -1;
+  if (kernel_out) for (int i = 0; i < n; ++i) kernel_out[i] = k[i];
+  if (n == 1) { std::memcpy(out, img, (size_t)W * H); return n; }   // GaussianBlur: a 1 x 1 kernel copies
+  ed_gaussian_blur(img, W, H, k, n, out);
+  return n;
+}
+
+// EDline(image, lines, smoothed): smoothed == 0 blurs first (the reference's default), then the same path
+int orc_edlines_ex(const uint8_t* img, int W, int H, int smoothed, int ksize, double sigma, int blur_mode, int gradTh, int anchorTh,
+                   int scan, int minLineLen, double fitErr, short* dx_o, short* dy_o, short* g_o, uint8_t* dir_o,
+                   unsigned* anchors_o, int* nAnchors_o, unsigned* chainX_o, unsigned* chainY_o, unsigned* sId_o, int* nEdges_o,
+                   int cap_px, double* lines_o, int cap_lines) {
+  if (smoothed)
+    return orc_edlines(img, W, H, gradTh, anchorTh, scan, minLineLen, fitErr, dx_o, dy_o, g_o, dir_o, anchors_o, nAnchors_o,
+                       chainX_o, chainY_o, sId_o, nEdges_o, cap_px, lines_o, cap_lines);
+  std::vector<uint8_t> b((size_t)W * H);
+  if (orc_gaussian_blur_u8(img, W, H, ksize, sigma, blur_mode, b.data(), nullptr) < 0) return -1;
+  return orc_edlines(b.data(), W, H, gradTh, anchorTh, scan, minLineLen, fitErr, dx_o, dy_o, g_o, dir_o, anchors_o, nAnchors_o,
+                     chainX_o, chainY_o, sId_o, nEdges_o, cap_px, lines_o, cap_lines);
+}
 }

@@ -202,11 +202,34 @@ def solve_windows(windows, opt, threads=1):
 
 
 # ---- line front-end (EDLines) ---------------------------------------------------------------------------
-def edlines(img, grad_th=30, anchor_th=5, scan=2, min_len=35, fit_err=1.8, want_stages=False, cap_lines=4096):
-    """EDLineDetector::EDline with smoothed=true on one uint8 image. Returns lines [n,10] (x1,y1,x2,y2,eq0..2,cx,cy,len)
-    and, if want_stages, a dict of the intermediate images / anchors / chains."""
+BLUR_NORMALISED, BLUR_OPENCV_341 = 0, 1
+
+
+def gaussian_blur(img, ksize=5, sigma=1.0, mode=BLUR_NORMALISED, want_kernel=False):
+    """cv::GaussianBlur(img, Size(ksize, ksize), sigma) on one uint8 image as EdgeDrawing calls it
+    (edline_detector.cpp:82-84); mode: which published rounding of OpenCV's 8.8 fixed-point kernel (oracle/edlines.cpp)."""
     lib = load()
     img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    out = np.empty_like(img)
+    k = np.zeros(64, np.int32)
+    lib.orc_gaussian_blur_u8.restype = C.c_int
+    n = lib.orc_gaussian_blur_u8(img.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, int(ksize), C.c_double(sigma), int(mode),
+                                 out.ctypes.data_as(C.POINTER(C.c_uint8)), k.ctypes.data_as(C.POINTER(C.c_int)))
+    if n < 0:
+        raise ValueError("kernel size %d" % ksize)
+    return (out, k[:n].copy()) if want_kernel else out
+
+
+def edlines(img, grad_th=30, anchor_th=5, scan=2, min_len=35, fit_err=1.8, want_stages=False, cap_lines=4096,
+            smoothed=True, ksize=5, sigma=1.0, blur_mode=BLUR_NORMALISED):
+    """EDLineDetector::EDline on one uint8 image (smoothed=False: the reference's default, Gaussian pre-blur first).
+    Returns lines [n,10] (x1,y1,x2,y2,eq0..2,cx,cy,len) and, if want_stages, a dict of the intermediate images /
+    anchors / chains."""
+    lib = load()
+    img = np.ascontiguousarray(img, np.uint8)
+    if not smoothed:
+        img = gaussian_blur(img, ksize, sigma, blur_mode)
     H, W = img.shape
     N = W * H
     cap = N // 5
