@@ -227,13 +227,24 @@ int vpl_ba_upload(vpl_ctx* ctx, int n_windows, const vpl_window* windows, const 
 /* The next windows of a sequence: as vpl_ba_upload, but window i takes the prior that the context's PREVIOUS solve left for
  * window i (MarginalizationInfo of that solve, estimator.cpp:1229-1447 -> last_marginalization_info) -- it stays in HBM,
  * handed from the marginalisation's output to the next solve's input on the device; windows[i].prior / has_prior are
- * ignored.  Needs a previous solve of the same batch size with a marginalisation flag other than VPL_MARGIN_NONE. */
+ * ignored.  Needs a previous solve (or vpl_ba_marginalize) of the same batch size with a marginalisation flag other than
+ * VPL_MARGIN_NONE and NO upload on the context since (vpl_ba_triangulate_*, vpl_ba_only_line_opt, vpl_ba_slide_window and the
+ * stages of vpl_ba_solve_odometry upload too): VPL_E_INVALID otherwise. */
 int vpl_ba_upload_chained(vpl_ctx* ctx, int n_windows, const vpl_window* windows, const vpl_ba_options* opt);
 int vpl_ba_solve(vpl_ctx* ctx);           /* enqueue one batched solve of the uploaded windows */
 int vpl_ba_reset_state(vpl_ctx* ctx);     /* restore the uploaded initial states on device (for repeated timing) */
 int vpl_ba_download(vpl_ctx* ctx, int n_windows, vpl_window* windows, vpl_prior* priors_out,
                     vpl_solve_report* reports);
 int vpl_ctx_synchronize(vpl_ctx* ctx);
+/* Host <-> device traffic of upload / download: the arrays are packed into one PINNED staging arena per context; an upload is
+ * one host-to-device copy + one scatter kernel, a download one gather kernel + one device-to-host copy.  No pageable memory
+ * (neither the library's nor the caller's) is handed to the HIP runtime on the upload / solve / download path.
+ * Leg timing: with it enabled the three calls bracket their device work with hipEvents on the context's stream;
+ * vpl_ctx_leg_times returns {upload (copy + scatter), solve (all launches), download (gather + copy)} of the last calls in
+ * milliseconds of DEVICE time (-1 for a leg that has not run), to be read next to the wall clock of the calls.  While it is on,
+ * vpl_ba_solve launches kernel by kernel (no graph replay). */
+int vpl_ctx_enable_leg_timing(vpl_ctx* ctx, int enable);
+int vpl_ctx_leg_times(vpl_ctx* ctx, double* ms3);
 /* States of the solved batch into a caller-owned DEVICE buffer, [n_windows][183] doubles per window: pose[11][7],
  * speed_bias[11][9], ex_pose[7] -- after double2vector2.  Asynchronous on the context's stream.  This is what a multi-GPU
  * run hands to its collective (RCCL all-gather of the batch's results) without a host staging copy. */

@@ -9,9 +9,9 @@
  * row-major uint8 buffers (cv::Mat::data of a continuous CV_8UC1 matrix); lines leave in the numeric
  * layout of struct Line (line_matching/src/line.h:8-17).
  *
- * Only smoothed = true is implemented (the production path); the Gaussian pre-blur of the demo path
- * (edline_detector.cpp:82-84) is not.  Functions return 0 or a negative VPL_E_* code
- * (same codes as vplines_ba.h); nothing falls back to a CPU path.
+ * smoothed = false -- the reference's default (edline_detector.h:79-81) and the path of its two demo programs -- runs
+ * cv::GaussianBlur(image, Size(ksize, ksize), sigma) first (edline_detector.cpp:82-84): vpl_edlines_detect_ex.
+ * Functions return 0 or a negative VPL_E_* code (same codes as vplines_ba.h); nothing falls back to a CPU path.
  */
 #ifndef VPLINES_FRONTEND_H
 #define VPLINES_FRONTEND_H
@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-/* EDLineParam, edline_detector.h:33-41 (ksize/sigma are carried for layout compatibility; unused with smoothed=true) */
+/* EDLineParam, edline_detector.h:33-41 (ksize / sigma: the Gaussian pre-blur of smoothed = false; unused with smoothed = true) */
 typedef struct vpl_edline_param {
   int ksize;
   float sigma;
@@ -76,11 +76,42 @@ int vpl_edlines_upload(vpl_fe_ctx* ctx, int n_images, const uint8_t* images /* [
 int vpl_edlines_detect(vpl_fe_ctx* ctx, const vpl_edline_param* param);   /* enqueue; asynchronous */
 int vpl_edlines_download(vpl_fe_ctx* ctx, int n_images, vpl_line* lines /* [n][max_lines] */, int* counts /* [n] */);
 
+/* EDline(image, lines, smoothed) with the flag as an argument.  smoothed == 0: the Gaussian pre-blur of EdgeDrawing
+ * (edline_detector.cpp:82-84) runs first, fused with the gradient stage -- OpenCV's bit-exact 8-bit GaussianBlur: taps in 8.8
+ * fixed point, rows then columns, BORDER_REFLECT_101.  ksize must be odd and <= 7 (ksize <= 0 with sigma > 0: OpenCV's automatic
+ * size); frames of at least 8 x 8.
+ * OpenCV published two roundings of the taps; vpl_fe_set_blur_kernel selects one per context:
+ *   VPL_BLUR_NORMALISED (default): 3.4.9+ / 4.2+, taps sum to 256 (5, sigma 1: 14 62 104 62 14) -- the one that reproduces the
+ *                                  reference's own output line_matching/data/edline_result.png (tests/golden/README.md);
+ *   VPL_BLUR_OPENCV_341:           3.4.1 - 3.4.8 / 4.0 - 4.1, cvRound(256 g_i) (14 63 103 63 14; the README's 3.4.2). */
+#define VPL_BLUR_NORMALISED 0
+#define VPL_BLUR_OPENCV_341 1
+int vpl_fe_set_blur_kernel(vpl_fe_ctx* ctx, int mode);
+int vpl_edlines_detect_ex(vpl_fe_ctx* ctx, const vpl_edline_param* param, int smoothed);   /* enqueue; asynchronous */
+int vpl_edlines_detect_batch_ex(vpl_fe_ctx* ctx, int n_images, const uint8_t* images, const vpl_edline_param* param, int smoothed,
+                                vpl_line* lines, int* counts);
+/* test access: keep a copy of the blurred frames of smoothed == 0 detections (off by default: the blurred frame otherwise
+ * never leaves the work-group's LDS) and read one back */
+int vpl_fe_keep_blurred(vpl_fe_ctx* ctx, int enable);
+int vpl_edlines_debug_blurred(vpl_fe_ctx* ctx, int img, uint8_t* blurred /* [H*W] */);
+
 /* EDline(image, lines, smoothed=true) for a batch: upload + detect + synchronize + download.
  * Lines of one image are returned in edge-chain order (the reference's order is the nondeterministic
  * arrival order of its worker threads, edline_detector.cpp:1080-1084). */
 int vpl_edlines_detect_batch(vpl_fe_ctx* ctx, int n_images, const uint8_t* images, const vpl_edline_param* param,
                              vpl_line* lines, int* counts);
+
+/* LineMatching::LineFilter(lines, distance_threshold, parallel_threshold = sin 3 deg) (line_matching.h:35-37,
+ * line_matching.cpp:167-264; the reference's demo calls it between detector and matcher, test_line_matching.cpp:57,74): in
+ * order of decreasing length, a line removes every shorter one that is nearly parallel to it and has an end point closer than
+ * distance_threshold.  Lines of equal length are taken in index order (the reference's std::sort leaves their order open).
+ * _detected: on the lines of the last detect where they lie in HBM (asynchronous; vpl_edlines_download / vpl_match_from_detected
+ * then see the filtered lists).  _batch: caller-owned lists [n][max_lines], counts [n], both in / out (uses the context's
+ * line table: the last detect's lines are overwritten).  max_lines_per_image <= 8192. */
+#define VPL_LINE_FILTER_PARALLEL_DEFAULT 0.0348994967f
+int vpl_line_filter_detected(vpl_fe_ctx* ctx, float distance_threshold, float parallel_threshold);
+int vpl_line_filter_batch(vpl_fe_ctx* ctx, int n_images, vpl_line* lines, int* counts, float distance_threshold,
+                          float parallel_threshold);
 
 /* test access to the intermediate stages of image `img` of the last detect (any pointer may be NULL):
  * dx, dy, gImg [H*W int16]; dirImg [H*W uint8]; anchors [2*cap uint32 x,y] ; chains xC,yC [cap uint32], sId [cap/20+2] */

@@ -20,6 +20,7 @@
 #include <cfloat>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 namespace orc {
@@ -311,11 +312,47 @@ static bool sideness(const LMLine& l1r, const LMLine& l2r, const LMLine& l1c, co
   return !(d1 * d2 < 0);
 }
 
+// LineMatching::LineFilter :167-264 (called by the reference's demo test_line_matching.cpp:57,74 between detector and matcher):
+// lines by decreasing length; a longer line removes every shorter one that is nearly parallel to it (|u x v| <= |u||v| sin 3 deg
+// with the stored `length` members as |u|, |v|) and has an end point closer than distance_threshold to it.
+// The reference orders with std::sort (unstable): lines of EQUAL length are taken in index order here.
+int lm_line_filter(LMLine* lines, int num, float distance_threshold, float parallel_threshold) {
+  std::vector<int> idx(num);
+  for (int i = 0; i < num; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return lines[a].length > lines[b].length; });
+  for (int i = 0; i < num; ++i) {
+    const int i1 = idx[i];
+    const float u_dist = lines[i1].length;
+    if (u_dist == -1) continue;
+    const float* e1 = lines[i1].endpoint;
+    const float ux = e1[2] - e1[0], uy = e1[3] - e1[1];
+    for (int j = i + 1; j < num; ++j) {
+      const int i2 = idx[j];
+      const float v_dist = lines[i2].length;
+      if (v_dist == -1) continue;
+      const float* e2 = lines[i2].endpoint;
+      const float vx = e2[2] - e2[0], vy = e2[3] - e2[1];
+      if (fabsf(ux * vy - vx * uy) > (u_dist * v_dist * parallel_threshold)) continue;
+      const float d1 = point_line_distance(e2[0], e2[1], e1);
+      const float d2 = point_line_distance(e2[2], e2[3], e1);
+      if (d1 < distance_threshold || d2 < distance_threshold) lines[i2].length = -1;
+    }
+  }
+  int m = 0;
+  for (int i = 0; i < num; ++i)
+    if (lines[i].length != -1) lines[m++] = lines[i];
+  return m;
+}
+
 }  // namespace orc
 
 using namespace orc;
 
 extern "C" {
+
+int orc_line_filter(LMLine* lines, int n, float distance_threshold, float parallel_threshold) {
+  return lm_line_filter(lines, n, distance_threshold, parallel_threshold);
+}
 
 int orc_lm_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst) { lm_pyr_down(src, w, h, dst); return 0; }
 int orc_lm_scharr(const uint8_t* src, int w, int h, short* dst) { lm_scharr(src, w, h, dst); return 0; }

@@ -25,7 +25,18 @@ int main(int argc, char** argv) {
   LineMatching lm(dev);
   std::vector<Line> la, lb;
   if (det.EDline(a.data(), la, true) != 1 || det.EDline(b.data(), lb, true) != 1) return 3;
-  if (det.EDline(a.data(), la, false) != -1) return 4;      // the un-smoothed demo path is not on the device
+  // the reference's demo (test_edline_detector.cpp:15,27; test_line_matching.cpp:57): EDline with its default smoothed = false
+  // (Gaussian pre-blur first), then LineFilter(lines, 3.0)
+  EDLineParam demo = {5, 1.0f, 30.f, 5.f, 2, 25, 1.8};
+  EDLineDetector det2(dev, demo);
+  std::vector<Line> ld;
+  if (det2.EDline(a.data(), ld) != 1) return 4;
+  const size_t n_demo = ld.size();
+  lm.LineFilter(ld, 3.0f);
+  std::printf("demo %zu %zu\n", n_demo, ld.size());
+  std::printf("demolines");
+  for (const Line& l : ld) std::printf(" %.9g %.9g %.9g %.9g", l.line_endpoint[0], l.line_endpoint[1], l.line_endpoint[2], l.line_endpoint[3]);
+  std::printf("\n");
   for (int k = 0; k < 2; ++k) {
     const std::vector<Line>& L = k ? lb : la;
     std::printf("lines%d", k);

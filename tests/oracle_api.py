@@ -412,3 +412,18 @@ def vp_detect(hyp_ends, all_ends, f, cx, cy, seed, first_frame, full=False):
     if full:
         return vps, ids, it, dict(hyp=hyp, grid=grid, scores=scores, best_idx=best.value, pairs=pairs, drawn=drawn)
     return vps, ids, it
+
+
+def line_filter(lines10, distance_threshold, parallel_threshold=0.0348994967):
+    """LineMatching::LineFilter (line_matching.cpp:167-264) on [n,10] lines; returns the kept lines in their order"""
+    lib = load()
+    arr = lines_to_struct(lines10)
+    lib.orc_line_filter.restype = C.c_int
+    m = lib.orc_line_filter(arr, len(lines10), C.c_float(distance_threshold), C.c_float(parallel_threshold))
+    out = np.zeros((m, 10))
+    for i in range(m):
+        out[i, 0:4] = arr[i].endpoint[:]
+        out[i, 4:7] = arr[i].equation[:]
+        out[i, 7:9] = arr[i].center[:]
+        out[i, 9] = arr[i].length
+    return out

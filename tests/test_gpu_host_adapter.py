@@ -69,6 +69,12 @@ def test_frontend_adapter_classes_match_oracle(tmp_path):
     assert vals["match"][0] == 1 and ok
     assert np.array_equal(vals["match"][1:].astype(int), r2c)
     assert list(vals["empty"]) == [0, 55, 55]          # Matching() == false leaves the output vector alone
+    # EDline with the reference's default smoothed = false (Gaussian pre-blur) + LineFilter, as its demo programs call them;
+    # 258 lines is what the reference's own edline_result.png shows for this frame (tests/test_edline_reference_picture.py)
+    ld = o.edlines(imgs[0], min_len=25, smoothed=False)
+    lf = o.line_filter(ld, 3.0)
+    assert list(vals["demo"]) == [258, len(lf)] and len(ld) == 258
+    assert np.abs(vals["demolines"].reshape(-1, 4) - lf[:, :4]).max() < 1e-3
 
 
 def _quat_R(q):

@@ -602,12 +602,19 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   }
   if (ROLE == 1) {
     // this work-group's part of the visual Hessian / gradient and of the cost go to the window's other work-group with
-    // device-coherent stores (write-through; the flag follows when they have completed): no L2 write-back / invalidate,
-    // which every work-group of the XCD would pay for
+    // device-coherent stores (agent scope: global_store ... sc1, written through to the L2 both work-groups share -- they sit
+    // on the same XCD).  RELEASE, spelled out: every thread waits until ITS stores have been acknowledged (s_waitcnt
+    // vmcnt(0): on gfx9 stores count in vmcnt, and a write-through store is acknowledged by the L2), THEN the barrier, THEN
+    // the flag.  s_barrier alone does not wait for outstanding stores (the payload of another wave could still
+    // be on its way to a different L2 channel when the flag landed).  __builtin_amdgcn_fence(release, "agent") would do the
+    // wait too but adds buffer_wbl2 sc1, a write-back of the whole L2 per wave that every work-group of the XCD pays for
+    // (measured in round 3: 490 us against 270 for the 512-window launch); with write-through stores there is nothing
+    // to write back.
     double* part = B.lin_part + (size_t)w * LIN_PART;
     for (int i = tid; i < HV_DOUBLES + NV; i += T) __hip_atomic_store(&part[i], sm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) __hip_atomic_store(&part[HV_DOUBLES + NV], cost_pts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();      // (waits for every wave's stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (expcnt 7, lgkmcnt 15: not waited for)
+    __syncthreads();
     if (tid == 0) __hip_atomic_store(&B.lin_flag[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
@@ -928,6 +935,11 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
   if (ROLE == 2) {
     // the point factors' part (the other work-group of this window): Hv = (lines) + (points), gv likewise -- the sum the
     // single work-group forms, in the other order of its two terms
+    // ACQUIRE, spelled out: the flag is polled with agent-scope loads (sc1: served by the L2, never by this CU's vector
+    // cache); the payload loads below are agent-scope loads too, issued after the barrier that follows the successful
+    // poll (a wave issues its memory instructions in order and none of them before s_barrier completes), so they reach the
+    // L2 after the flag store did -- and the writer's stores were acknowledged by that L2 before the flag was written.
+    // No buffer_inv is needed because no load of this payload may hit the vector cache.
     if (tid == 0) {
       while (__hip_atomic_load(&B.lin_flag[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(32);
       __hip_atomic_store(&B.lin_flag[w], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

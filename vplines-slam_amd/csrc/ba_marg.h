@@ -793,6 +793,23 @@ __global__ void k_prior_handoff(DevBatch B, const int* keep) {
   for (int i = threadIdx.x; i < MAXPB * 9; i += blockDim.x) B.pr_x0[(size_t)w * MAXPB * 9 + i] = B.mg_x0[(size_t)w * MAXPB * 9 + i];
 }
 
+// Chained upload whose batch stride of pr_J0 changed: the windows that KEEP their prior have J0 at w * old_prS.  phase 0 copies
+// their n x n into tmp[w][MAXPN^2], phase 1 (next launch) back to w * B.prS.  pr_n still holds the kept prior's size (the new
+// tables are scattered after this).
+__global__ void k_prior_restride(DevBatch B, const int* keep, int old_prS, double* tmp, int phase) {
+  const int w = blockIdx.x;
+  if (!keep[w]) return;
+  const int n = B.pr_n[w];
+  double* T = tmp + (size_t)w * MAXPN * MAXPN;
+  if (phase == 0) {
+    const double* J = B.pr_J0 + (size_t)w * old_prS;
+    for (int i = threadIdx.x; i < n * n; i += blockDim.x) T[i] = J[i];
+  } else {
+    double* J = B.pr_J0 + (size_t)w * B.prS;
+    for (int i = threadIdx.x; i < n * n; i += blockDim.x) J[i] = T[i];
+  }
+}
+
 // Per-window states of the solved batch as one [nW][183] device array (pose 77 | speed/bias 99 | extrinsic 7): what the
 // multi-GPU run all-gathers over RCCL, packed on the device so that the collective reads HBM, not a host staging copy.
 __global__ void k_pack_states(DevBatch B, double* out) {

@@ -1,6 +1,9 @@
 // HIP kernels of the EDLines extractor (line front-end), batch of N frames of one size.
 //   k_ed_grad   : Sobel 3x3 (BORDER_REFLECT_101) -> |dx|+|dy| -> threshold -> /4 (half-to-even) -> direction
 //                 (edline_detector.cpp:125-136); streaming, HBM-bound: 1 byte read, 7 bytes written per pixel
+//   k_ed_blur_grad : the same with cv::GaussianBlur(image, Size(ksize, ksize), sigma) in front (EdgeDrawing with
+//                 smoothed = false, edline_detector.cpp:81-86: the reference's default): raw tile + halo in LDS, OpenCV's
+//                 8.8 fixed-point row / column passes, Sobel of the blurred tile -- the blurred frame never goes to HBM
 //   k_ed_anchor : anchor test on the scan lattice + ORDERED compaction (w outer, h inner, :148-164)
 //   k_ed_code   : per-pixel routing byte (walkable, direction, arg-max forward neighbour for both senses of travel)
 //   k_ed_route  : smart routing (:166-707): inherently serial and order dependent per frame -> one wave per
@@ -35,6 +38,11 @@ struct EdBatch {
   double* lines;           // [N][maxLines][10]
   uint32_t* lkey;          // [N][maxLines]  (chain id << 8 | ordinal) for a deterministic order
   int* nLines;             // [N]
+  // Gaussian pre-blur (smoothed = false): 2 * blurR + 1 taps in 8.8 fixed point (host: gauss_kernel_q8), optional copy of
+  // the blurred frames for the tests
+  int blurR;
+  int blurK[7];
+  uint8_t* blurOut;        // [N][H][W] or nullptr
 };
 
 __device__ __forceinline__ int refl101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -63,6 +71,89 @@ __global__ __launch_bounds__(256) void k_ed_grad(EdBatch B) {
   B.dy[o] = (int16_t)gy;
   B.g[o] = (int16_t)gq;
   B.dir[o] = ax < ay ? 255 : 0;
+}
+
+// EdgeDrawing with smoothed = false: GaussianBlur (fixedSmoothInvoker<uint8_t, ufixedpoint16> of OpenCV's smooth.cpp: taps in
+// 8.8 fixed point, row pass into 16 bits saturating at 0xFFFF, column pass into 32 bits, (v + 0x8000) >> 16 saturated to 8 bits,
+// BORDER_REFLECT_101) fused with the gradient stage.  One work-group per 64 x 16 tile of the frame:
+//   raw  [16 + 2 + 2R][64 + 2 + 2R]  the tile with the halo of blur (R <= 3) and Sobel (1), image coordinates only (a reflected
+//                                    coordinate of a border pixel always lies inside the tile's own range)
+//   rows [16 + 2 + 2R][66]           row pass at the REFLECTED column of every blurred position (the Sobel halo of a border tile
+//                                    is the blurred image mirrored, not the blur of a mirrored image: both reflections kept apart)
+//   blr  [18][66]                    blurred tile + Sobel halo
+constexpr int EDB_TW = 64, EDB_TH = 16, EDB_RMAX = 3;
+__global__ __launch_bounds__(256) void k_ed_blur_grad(EdBatch B) {
+  constexpr int RW = EDB_TW + 2 + 2 * EDB_RMAX, RH = EDB_TH + 2 + 2 * EDB_RMAX, BW = EDB_TW + 2, BH = EDB_TH + 2;
+  __shared__ uint8_t raw[RH][RW + 2];
+  __shared__ uint16_t rows[RH][BW];
+  __shared__ uint8_t blr[BH][BW + 2];
+  const int n = blockIdx.z, tid = threadIdx.x;
+  const int W = B.W, H = B.H, R = B.blurR;
+  const int x0 = blockIdx.x * EDB_TW, y0 = blockIdx.y * EDB_TH;
+  const int xb = x0 - 1 - R, yb = y0 - 1 - R;             // image coordinates of raw[0][0]
+  const int rw = EDB_TW + 2 + 2 * R, rh = EDB_TH + 2 + 2 * R;
+  const uint8_t* im = B.img + (size_t)n * W * H;
+  for (int i = tid; i < rh * rw; i += 256) {
+    const int ry = i / rw, rx = i - ry * rw;
+    const int y = yb + ry, x = xb + rx;
+    raw[ry][rx] = (x >= 0 && x < W && y >= 0 && y < H) ? im[(size_t)y * W + x] : 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < rh * BW; i += 256) {
+    const int ry = i / BW, bx = i - ry * BW;
+    const int y = yb + ry, x = x0 - 1 + bx;
+    if (y < 0 || y >= H || x > W) continue;
+    const int cx = refl101(x, W);
+    uint32_t a = 0;
+    for (int j = -R; j <= R; ++j) a += (uint32_t)B.blurK[j + R] * raw[ry][refl101(cx + j, W) - xb];
+    rows[ry][bx] = (uint16_t)min(a, 0xFFFFu);
+  }
+  __syncthreads();
+  for (int i = tid; i < BH * BW; i += 256) {
+    const int by = i / BW, bx = i - by * BW;
+    const int y = y0 - 1 + by, x = x0 - 1 + bx;
+    if (y > H || x > W) continue;
+    const int cy = refl101(y, H);
+    uint32_t a = 0;
+    for (int j = -R; j <= R; ++j) a += (uint32_t)B.blurK[j + R] * rows[refl101(cy + j, H) - yb][bx];
+    // a <= 257 * 0xFFFF: the rounding add cannot wrap
+    blr[by][bx] = (uint8_t)min((a + 0x8000u) >> 16, 255u);
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = (tid & 15) * 4;
+  const int y = y0 + ty;
+  if (y >= H) return;
+  const size_t fo = (size_t)n * W * H + (size_t)y * W + x0 + tx;
+  short vx[4], vy[4], vg[4];
+  uint8_t vd[4], vb[4];
+  for (int q = 0; q < 4; ++q) {
+    const int by = ty + 1, bx = tx + q + 1;
+    const int gx = (blr[by - 1][bx + 1] + 2 * blr[by][bx + 1] + blr[by + 1][bx + 1]) -
+                   (blr[by - 1][bx - 1] + 2 * blr[by][bx - 1] + blr[by + 1][bx - 1]);
+    const int gy = (blr[by + 1][bx - 1] + 2 * blr[by + 1][bx] + blr[by + 1][bx + 1]) -
+                   (blr[by - 1][bx - 1] + 2 * blr[by - 1][bx] + blr[by - 1][bx + 1]);
+    const int ax = gx < 0 ? -gx : gx, ay = gy < 0 ? -gy : gy;
+    const int sum = ax + ay;
+    const int t = sum > B.gradTh + 1 ? sum : 0;
+    const int qq = t >> 2, r = t & 3;
+    vx[q] = (short)gx;
+    vy[q] = (short)gy;
+    vg[q] = (short)(r == 3 ? qq + 1 : (r == 2 ? qq + (qq & 1) : qq));
+    vd[q] = ax < ay ? 255 : 0;
+    vb[q] = blr[by][bx];
+  }
+  if ((W & 3) == 0 && x0 + tx + 3 < W) {   // rows start 8-byte aligned when W is a multiple of 4
+    *reinterpret_cast<short4*>(B.dx + fo) = make_short4(vx[0], vx[1], vx[2], vx[3]);
+    *reinterpret_cast<short4*>(B.dy + fo) = make_short4(vy[0], vy[1], vy[2], vy[3]);
+    *reinterpret_cast<short4*>(B.g + fo) = make_short4(vg[0], vg[1], vg[2], vg[3]);
+    *reinterpret_cast<uchar4*>(B.dir + fo) = make_uchar4(vd[0], vd[1], vd[2], vd[3]);
+    if (B.blurOut) *reinterpret_cast<uchar4*>(B.blurOut + fo) = make_uchar4(vb[0], vb[1], vb[2], vb[3]);
+  } else {
+    for (int q = 0; q < 4 && x0 + tx + q < W; ++q) {
+      B.dx[fo + q] = vx[q]; B.dy[fo + q] = vy[q]; B.g[fo + q] = vg[q]; B.dir[fo + q] = vd[q];
+      if (B.blurOut) B.blurOut[fo + q] = vb[q];
+    }
+  }
 }
 
 // one workgroup of 1024 per frame; thread t owns a contiguous slice of the scan order

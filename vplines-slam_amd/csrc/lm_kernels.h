@@ -8,6 +8,7 @@
 //                             window an LDS column.  The float accumulations run in the reference's pixel order, so
 //                             the tracked positions are bit-identical to the CPU path.
 //   k_lm_vote               : ClosestLine / Point2Line / TopologicalFilter (:48-133, :266-436), one workgroup per pair
+//   k_lm_line_filter        : LineMatching::LineFilter (:167-264), one workgroup per frame, on the detector's lines in HBM
 // Streaming kernels are HBM-bound; k_lm_klt is latency bound (byte gathers from L2-resident pyramids).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -507,6 +508,68 @@ __global__ __launch_bounds__(256) void k_lm_vote(LmBatch B) {
   }
   int* out = B.r2c + (size_t)p * B.maxLines;
   for (int i = threadIdx.x; i < nr; i += 256) out[i] = r2c[i];
+}
+
+// LineMatching::LineFilter (line_matching.cpp:167-264) on the line table of a batch of frames (vpl_line [N][ML], counts [N]),
+// in place.  One work-group per frame.  Lines by decreasing length (equal lengths in index order: the reference's std::sort
+// leaves that open); the outer loop over the longer line is sequential (a removed line removes nothing), the inner loop over
+// the shorter lines is the work-group's.  Dynamic LDS: order[ML] ints + len[ML] floats.  Same float expressions as the
+// reference (file-scope contract(off) above).
+__global__ __launch_bounds__(256) void k_lm_line_filter(vpl_line* lines, int* counts, int ML, float distTh, float parTh) {
+  extern __shared__ int lf_smem[];
+  int* order = lf_smem;
+  float* len = reinterpret_cast<float*>(lf_smem + ML);
+  const int n = blockIdx.x, tid = threadIdx.x;
+  vpl_line* L = lines + (size_t)n * ML;
+  const int m = min(counts[n], ML);
+  for (int k = tid; k < m; k += 256) len[k] = L[k].length;
+  __syncthreads();
+  for (int k = tid; k < m; k += 256) {   // rank = lines that come before k
+    const float lk = len[k];
+    int rank = 0;
+    for (int j = 0; j < m; ++j) rank += (len[j] > lk || (len[j] == lk && j < k)) ? 1 : 0;
+    order[rank] = k;
+  }
+  __syncthreads();
+  for (int i = 0; i < m; ++i) {
+    const int i1 = order[i];
+    const float u_dist = len[i1];
+    if (u_dist != -1.f) {   // uniform
+      const float e1[4] = {L[i1].line_endpoint[0], L[i1].line_endpoint[1], L[i1].line_endpoint[2], L[i1].line_endpoint[3]};
+      const float ux = e1[2] - e1[0], uy = e1[3] - e1[1];
+      for (int j = i + 1 + tid; j < m; j += 256) {
+        const int i2 = order[j];
+        const float v_dist = len[i2];
+        if (v_dist == -1.f) continue;
+        const float* e2 = L[i2].line_endpoint;
+        const float vx = e2[2] - e2[0], vy = e2[3] - e2[1];
+        if (fabsf(ux * vy - vx * uy) > (u_dist * v_dist * parTh)) continue;
+        const float d1 = lm_point_line_distance(e2[0], e2[1], e1);
+        const float d2 = lm_point_line_distance(e2[2], e2[3], e1);
+        if (d1 < distTh || d2 < distTh) len[i2] = -1.f;
+      }
+    }
+    __syncthreads();
+  }
+  // compaction in the original order; a line only ever moves towards the front, chunks of 256 in increasing order
+  for (int base = 0; base < m; base += 256) {
+    const int k = base + tid;
+    vpl_line v;
+    int dst = -1;
+    if (k < m && len[k] != -1.f) {
+      v = L[k];
+      dst = 0;
+      for (int j = 0; j < k; ++j) dst += len[j] != -1.f ? 1 : 0;
+    }
+    __syncthreads();
+    if (dst >= 0) L[dst] = v;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int c = 0;
+    for (int j = 0; j < m; ++j) c += len[j] != -1.f ? 1 : 0;
+    counts[n] = c;
+  }
 }
 
 }  // namespace vpl

@@ -28,6 +28,117 @@
 
 using namespace vpl;
 
+// ---- staging ------------------------------------------------------------------------------------------------------------
+// Host <-> device traffic of the window entry points goes through ONE pinned host arena and ONE device arena per context:
+//   upload   : the host packs every array into the pinned arena, ONE hipMemcpyAsync moves it to the device arena, ONE kernel
+//              (k_copy_segments) scatters the pieces into the batch's arrays;
+//   download : one kernel gathers the result arrays into the device arena, ONE hipMemcpyAsync brings it to the pinned arena,
+//              the host scatters into the caller's structs.
+// Round 3 issued ~45 hipMemcpyAsync per upload and ~17 per download straight from / into pageable std::vectors and the
+// caller's vpl_prior structs: each pageable copy above the runtime's staging threshold pins and unpins its pages (a kernel
+// driver call that can quiesce the process's queues), which showed up as 26 ms instead of 1.4 in the solve leg of a
+// 64-window call on the round-3 driver box.  The library now hands pageable memory to the runtime nowhere
+// on the upload / solve / download path.
+struct CopySeg {
+  const char* src;
+  char* dst;
+  unsigned bytes;
+  unsigned u0;   // index of the segment's first 16-byte unit in the launch
+};
+static_assert(sizeof(CopySeg) == 24, "CopySeg layout");
+
+// one thread per 16-byte unit; the segment of a unit by binary search over the (<= few thousand) prefix entries
+__global__ __launch_bounds__(256) void k_copy_segments(const CopySeg* tab, int nseg, unsigned total_units) {
+  for (unsigned u = blockIdx.x * 256u + threadIdx.x; u < total_units; u += gridDim.x * 256u) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tab[mid].u0 <= u) lo = mid; else hi = mid - 1;
+    }
+    const CopySeg sg = tab[lo];
+    const unsigned off = (u - sg.u0) * 16u;
+    const unsigned rem = sg.bytes - off;
+    const char* src = sg.src + off;
+    char* dst = sg.dst + off;
+    if (rem >= 16u && (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    } else {   // tails and 4- / 8-byte aligned pieces (every array is made of 4- or 8-byte elements)
+      const unsigned nb = rem < 16u ? rem : 16u;
+      for (unsigned b = 0; b < nb; b += 4) *reinterpret_cast<uint32_t*>(dst + b) = *reinterpret_cast<const uint32_t*>(src + b);
+    }
+  }
+}
+
+template <typename T>
+struct Span {   // a piece of the pinned arena with the few std::vector members the packing code uses
+  T* p = nullptr;
+  size_t n = 0;
+  T& operator[](size_t i) const { return p[i]; }
+  T* data() const { return p; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T* begin() const { return p; }
+  T* end() const { return p + n; }
+};
+
+struct Stage {
+  char* h = nullptr;   // hipHostMalloc
+  char* d = nullptr;   // hipMalloc
+  size_t cap = 0, used = 0;
+  std::vector<CopySeg> segs;
+  unsigned units = 0;
+  bool overflow = false;
+
+  hipError_t reserve(size_t need) {
+    used = 0; segs.clear(); units = 0; overflow = false;
+    if (need <= cap) return hipSuccess;
+    if (h) hipHostFree(h);
+    if (d) hipFree(d);
+    h = d = nullptr; cap = 0;
+    const size_t want = need + need / 4 + (1u << 16);
+    hipError_t e = hipHostMalloc((void**)&h, want, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    e = hipMalloc((void**)&d, want);
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (h) hipHostFree(h);
+    if (d) hipFree(d);
+    h = d = nullptr; cap = 0;
+  }
+  template <typename T>
+  Span<T> take(size_t n) {   // uninitialised
+    used = (used + 63) & ~(size_t)63;
+    Span<T> sp;
+    if (used + n * sizeof(T) > cap) { overflow = true; static T dummy; sp.p = &dummy; sp.n = 0; return sp; }
+    sp.p = reinterpret_cast<T*>(h + used);
+    sp.n = n;
+    used += n * sizeof(T);
+    return sp;
+  }
+  template <typename T>
+  Span<T> take(size_t n, T fill) {
+    Span<T> sp = take<T>(n);
+    std::fill(sp.begin(), sp.end(), fill);
+    return sp;
+  }
+  char* dev_of(const void* host_ptr) const { return d + (reinterpret_cast<const char*>(host_ptr) - h); }
+  void seg(const void* src, void* dst, size_t bytes) {
+    if (!bytes) return;
+    CopySeg c{reinterpret_cast<const char*>(src), reinterpret_cast<char*>(dst), (unsigned)bytes, units};
+    units += (unsigned)((bytes + 15) / 16);
+    segs.push_back(c);
+  }
+  // upload: a piece of the arena (host address) to a device array
+  template <typename T>
+  void to_device(T* dev_dst, const T* host_src, size_t n) { seg(dev_of(host_src), dev_dst, n * sizeof(T)); }
+  // download: a device array to a piece of the arena (host address)
+  template <typename T>
+  void from_device(T* host_dst, const T* dev_src, size_t n) { seg(dev_src, dev_of(host_dst), n * sizeof(T)); }
+};
+
 struct vpl_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -67,7 +178,37 @@ struct vpl_ctx {
   // results into the caller's arrays) of the call that was enqueued last; run by vpl_ba_collect or by the next call that
   // touches the batch
   std::function<int()> pending;
+  bool prior_resident = false;                   // the last solve / marginalisation of the uploaded batch left its priors in mg_* (vpl_ba_upload_chained)
+  int prior_resident_nW = 0;
+  Stage stage;                                   // pinned + device staging arenas of upload / download
+  std::vector<int> h_mg_n;                       // kept dims of the next prior as the host computed them (>= the device's)
+  // device time of the last upload / solve / download (hipEvents on the context's stream), vpl_ctx_enable_leg_timing
+  bool leg_timing = false;
+  hipEvent_t leg_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
+
+// appends the segment table to the arena, moves arena (upload: data + table, download: table only) and runs the copy kernel
+static hipError_t stage_run(vpl_ctx* c, bool upload) {
+  Stage& S = c->stage;
+  if (S.overflow) return hipErrorOutOfMemory;
+  if (S.segs.empty()) return hipSuccess;
+  const size_t data_end = S.used;
+  Span<CopySeg> tab = S.take<CopySeg>(S.segs.size());
+  if (S.overflow) return hipErrorOutOfMemory;
+  std::memcpy(tab.p, S.segs.data(), S.segs.size() * sizeof(CopySeg));
+  const size_t tab_off = reinterpret_cast<char*>(tab.p) - S.h;
+  hipError_t e;
+  if (upload) e = hipMemcpyAsync(S.d, S.h, S.used, hipMemcpyHostToDevice, c->stream);
+  else e = hipMemcpyAsync(S.d + tab_off, S.h + tab_off, S.segs.size() * sizeof(CopySeg), hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) return e;
+  const unsigned blocks = std::min<unsigned>((S.units + 255) / 256, 2048u);
+  hipLaunchKernelGGL(k_copy_segments, dim3(blocks), dim3(256), 0, c->stream, reinterpret_cast<const CopySeg*>(S.d + tab_off),
+                     (int)S.segs.size(), S.units);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (!upload) e = hipMemcpyAsync(S.h, S.d, data_end, hipMemcpyDeviceToHost, c->stream);
+  return e;
+}
 
 static void drop_graph(vpl_ctx* c) {
   if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
@@ -126,6 +267,11 @@ static void to_dev_preint(const vpl_preintegration& p, DevPreint& d) {
   std::memset(d.sqrt_info, 0, sizeof(d.sqrt_info));
 }
 
+template <typename T>
+static hipError_t up(vpl_ctx* c, T* dst, const Span<T>& src) {   // a piece of the pinned arena: joins the upload's one copy
+  c->stage.to_device(dst, src.p, src.n);
+  return hipSuccess;
+}
 template <typename T>
 static hipError_t up(vpl_ctx* c, T* dst, const std::vector<T>& src) {
   if (src.empty()) return hipSuccess;
@@ -327,6 +473,8 @@ void vpl_ctx_destroy(vpl_ctx* c) {
   hipDeviceSynchronize();
   drop_graph(c);
   for (void* p : c->allocs) hipFree(p);
+  c->stage.release();
+  for (hipEvent_t& e : c->leg_ev) if (e) hipEventDestroy(e);
   delete c;
 }
 
@@ -337,6 +485,28 @@ int vpl_ctx_set_stream(vpl_ctx* c, void* s) {
   return VPL_OK;
 }
 const char* vpl_last_error(const vpl_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// device time of the legs of the last vpl_ba_upload / vpl_ba_solve / vpl_ba_download (hipEvents on the context's stream around
+// each call's device work: copy + scatter | the solve's launches | gather + copy), next to the wall clock a caller measures
+int vpl_ctx_enable_leg_timing(vpl_ctx* c, int enable) {
+  if (!c) return VPL_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (enable)
+    for (hipEvent_t& e : c->leg_ev) if (!e) HIPCHK(c, hipEventCreate(&e));
+  c->leg_timing = enable != 0;
+  return VPL_OK;
+}
+int vpl_ctx_leg_times(vpl_ctx* c, double* ms3) {
+  if (!c || !ms3 || !c->leg_timing) return VPL_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 3; ++k) {
+    float ms = 0.f;
+    const hipError_t e = hipEventElapsedTime(&ms, c->leg_ev[2 * k], c->leg_ev[2 * k + 1]);
+    ms3[k] = e == hipSuccess ? (double)ms : -1.0;   // -1: that leg has not run with timing on
+  }
+  return VPL_OK;
+}
 
 int vpl_ctx_synchronize(vpl_ctx* c) {
   if (!c) return VPL_E_INVALID;
@@ -483,6 +653,13 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     return fail(c, VPL_E_INVALID, "unknown marginalization_flag");
   HIPCHK(c, hipSetDevice(c->device));
   { const int rs = settle(c); if (rs) return rs; }   // an asynchronous call whose results have not been collected yet
+  // chained: the priors of THIS batch size must be resident, i.e. the context's last upload was solved (or marginalised) with a
+  // marginalisation and nothing was uploaded since (any upload rewrites mg_n / mg_nb / mg_kind, the tables of the NEXT prior)
+  if (chained && (!c->prior_resident || c->prior_resident_nW != nW))
+    return fail(c, VPL_E_INVALID, "upload_chained: needs a previous solve of the same batch size with a marginalisation, and no upload since");
+  const int prev_prS = c->B.prS;
+  c->prior_resident = false;
+  if (c->leg_timing) HIPCHK(c, hipEventRecord(c->leg_ev[0], c->stream));
   drop_graph(c);
   c->opt = *opt;
   c->nW = nW;
@@ -499,31 +676,50 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   B.opt.huber_delta = opt->huber_delta;
 
   const size_t W = nW;
-  std::vector<double> pose(W * 77), sb(W * 99), ex(W * 7), invd(W * B.maxP, 1.0), plk(W * B.maxL * 6, 0.0);
-  std::vector<int> nP(W), nL(W), pt_start(W * B.maxP, 0), pt_nobs(W * B.maxP, 0), pt_off(W * B.maxP, 0);
-  std::vector<int> ln_start(W * B.maxL, 0), ln_nobs(W * B.maxL, 0), ln_off(W * B.maxL, 0), ln_tri(W * B.maxL, 1);
-  // (no value-initialisation: only the rounds a window uses are filled and uploaded)
+  // Every array that travels is packed straight into the context's pinned arena (Stage); the bound below is the sum of the
+  // pieces taken from it (+ 64-byte alignment per piece, + the segment table).
+  Stage& SG = c->stage;
+  {
+    size_t j0 = 0;
+    if (!chained)
+      for (size_t w = 0; w < W; ++w)
+        if (win[w].has_prior && win[w].prior && win[w].prior->n > 0 && win[w].prior->n <= MAXPN) j0 += (size_t)win[w].prior->n * win[w].prior->n * 8 + 64;
+    const size_t dbl = 77 + 99 + 7 + B.maxP + 6 * B.maxL + 3 * B.maxPO + 8 * B.maxLO + 13 + 4 * B.maxL + 9 * MAXPB + MAXPN;
+    const size_t ints = 2 + 3 * B.maxP + 4 * B.maxL + 2 + 4 * B.maxKS + 8 * SK_WSTRIDE + 1 + 1 + B.maxLO + 2 * B.llSlots + 1 + B.maxP + (NF + 1) +
+                        1 + 2 + 3 * MAXPB + 2 + 4 * MAXPB + 1 + 1 + B.maxPR * 1536;
+    const size_t perW = dbl * 8 + ints * 4 + NF * sizeof(DevPreint);
+    const size_t need = W * perW + j0 + 96 * 64 + (96 + 4 * W) * sizeof(CopySeg) + 4096;
+    HIPCHK(c, SG.reserve(need));
+  }
+  Span<double> pose = SG.take<double>(W * 77), sb = SG.take<double>(W * 99), ex = SG.take<double>(W * 7), invd = SG.take<double>(W * B.maxP, 1.0),
+               plk = SG.take<double>(W * B.maxL * 6, 0.0);
+  Span<int> nP = SG.take<int>(W), nL = SG.take<int>(W), pt_start = SG.take<int>(W * B.maxP, 0), pt_nobs = SG.take<int>(W * B.maxP, 0),
+            pt_off = SG.take<int>(W * B.maxP, 0);
+  Span<int> ln_start = SG.take<int>(W * B.maxL, 0), ln_nobs = SG.take<int>(W * B.maxL, 0), ln_off = SG.take<int>(W * B.maxL, 0),
+            ln_tri = SG.take<int>(W * B.maxL, 1);
+  // (plain heap, no value-initialisation: only the rounds a window uses are filled; the used rounds are packed into the arena
+  // after the loop)
   std::unique_ptr<int[]> pu_lane(new int[W * B.maxPR * 1024]), pu_sub(new int[W * B.maxPR * 512]);
-  std::vector<int> pu_cnt(W, 0), pu_cnt0(W, 0);
-  std::vector<int> sk_tab(W * B.maxKS * 4, 0), sk_wave(W * 8 * SK_WSTRIDE, -1), path(W, 0);
-  std::vector<int> nLO(W, 0), lo_ln(W * B.maxLO, 0), ll_tab(W * B.llSlots * 2, -1), ll_np(W, 0);
-  std::vector<int> ps_list(W * B.maxP, 0), ps_cnt(W * (NF + 1), 0);
-  std::vector<double> pt_obs(W * B.maxPO * 3, 0.0), ln_obs(W * B.maxLO * 8, 0.0);
-  std::vector<DevPreint> pre(W * NF);
-  std::vector<double> fail_ref(W * 13, 0.0), orth(W * B.maxL * 4, 0.0);
-  std::vector<int> orth_in(W, 0);
-  std::vector<int> pr_n(W, 0), pr_nb(W, 0), pr_kind(W * MAXPB, 0), pr_frame(W * MAXPB, 0), pr_idx(W * MAXPB, 0);
-  std::vector<double> pr_x0(W * MAXPB * 9, 0.0), pr_r0(W * MAXPN, 0.0);
-  std::vector<int> mg_n(W, 0), mg_nb(W, 0), mg_kind(W * MAXPB, 0), mg_frame(W * MAXPB, 0), mg_idx(W * MAXPB, 0),
-      mg_cam(W * MAXPB, 0);
+  Span<int> pu_cnt = SG.take<int>(W, 0), pu_cnt0 = SG.take<int>(W, 0);
+  Span<int> sk_tab = SG.take<int>(W * B.maxKS * 4, 0), sk_wave = SG.take<int>(W * 8 * SK_WSTRIDE, -1), path = SG.take<int>(W, 0);
+  Span<int> nLO = SG.take<int>(W, 0), lo_ln = SG.take<int>(W * B.maxLO, 0), ll_tab = SG.take<int>(W * B.llSlots * 2, -1), ll_np = SG.take<int>(W, 0);
+  Span<int> ps_list = SG.take<int>(W * B.maxP, 0), ps_cnt = SG.take<int>(W * (NF + 1), 0);
+  Span<double> pt_obs = SG.take<double>(W * B.maxPO * 3, 0.0), ln_obs = SG.take<double>(W * B.maxLO * 8, 0.0);
+  Span<DevPreint> pre = SG.take<DevPreint>(W * NF);
+  Span<double> fail_ref = SG.take<double>(W * 13, 0.0), orth = SG.take<double>(W * B.maxL * 4, 0.0);
+  Span<int> orth_in = SG.take<int>(W, 0);
+  Span<int> pr_n = SG.take<int>(W, 0), pr_nb = SG.take<int>(W, 0), pr_kind = SG.take<int>(W * MAXPB, 0), pr_frame = SG.take<int>(W * MAXPB, 0),
+            pr_idx = SG.take<int>(W * MAXPB, 0);
+  Span<double> pr_x0 = SG.take<double>(W * MAXPB * 9, 0.0), pr_r0 = SG.take<double>(W * MAXPN, 0.0);
+  Span<int> mg_n = SG.take<int>(W, 0), mg_nb = SG.take<int>(W, 0), mg_kind = SG.take<int>(W * MAXPB, 0), mg_frame = SG.take<int>(W * MAXPB, 0),
+            mg_idx = SG.take<int>(W * MAXPB, 0), mg_cam = SG.take<int>(W * MAXPB, 0);
+  if (SG.overflow) return fail(c, VPL_E_CAPACITY, "internal: staging arena bound too small");
   // chained mode: window w takes the prior the context's previous solve left for window w (device resident); only its block
   // table comes through the host
   struct HostTab { int n = 0, nb = 0, kind[MAXPB], frame[MAXPB], idx[MAXPB]; };
   std::vector<HostTab> ctab;
   std::vector<int> keep_prior(W, 0);
   if (chained) {
-    if (nW != c->nW || c->opt.marginalization_flag == VPL_MARGIN_NONE)
-      return fail(c, VPL_E_INVALID, "upload_chained: needs a previous solve of the same batch size with a marginalisation");
     ctab.resize(W);
     std::vector<int> t_n(W), t_nb(W), t_kind(W * MAXPB), t_frame(W * MAXPB), t_idx(W * MAXPB), p_n(W), p_nb(W), p_kind(W * MAXPB),
         p_frame(W * MAXPB), p_idx(W * MAXPB);
@@ -544,6 +740,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       HostTab& T = ctab[w];
       T.n = keep ? p_n[w] : t_n[w];
       T.nb = keep ? p_nb[w] : t_nb[w];
+      if (T.n < 0 || T.n > MAXPN || T.nb < 0 || T.nb > MAXPB) return fail(c, VPL_E_INVALID, "upload_chained: resident prior table out of range");
       for (int b = 0; b < T.nb; ++b) {
         T.kind[b] = (keep ? p_kind : t_kind)[w * MAXPB + b];
         T.frame[b] = (keep ? p_frame : t_frame)[w * MAXPB + b];
@@ -728,7 +925,12 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
           return fail(c, VPL_E_INVALID, "bad prior block");
       }
       std::memcpy(&pr_r0[w * MAXPN], pr.r0, (size_t)pr.n * 8);
-      HIPCHK(c, hipMemcpyAsync(B.pr_J0 + w * (size_t)B.prS, pr.J0, (size_t)pr.n * pr.n * 8, hipMemcpyHostToDevice, c->stream));
+      if (pr.n > 0) {
+        Span<double> j0 = SG.take<double>((size_t)pr.n * pr.n);
+        if (SG.overflow) return fail(c, VPL_E_CAPACITY, "internal: staging arena bound too small");
+        std::memcpy(j0.p, pr.J0, (size_t)pr.n * pr.n * 8);
+        SG.to_device(B.pr_J0 + w * (size_t)B.prS, j0.p, j0.n);
+      }
     }
     // kept blocks of the next prior in the canonical (address) order of the reference's para_* layout
     {
@@ -784,18 +986,22 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.nP, nP)); HIPCHK(c, up(c, B.nL, nL));
   HIPCHK(c, up(c, B.pt_start, pt_start)); HIPCHK(c, up(c, B.pt_nobs, pt_nobs)); HIPCHK(c, up(c, B.pt_off, pt_off));
   HIPCHK(c, up(c, B.ps_list, ps_list)); HIPCHK(c, up(c, B.ps_cnt, ps_cnt));
-  {   // the first max-over-the-batch rounds of every window
+  {   // the first max-over-the-batch rounds of every window, packed into the arena
     int rmax = 0;
     for (size_t q = 0; q < W; ++q) rmax = std::max(rmax, pu_cnt[q]);
-    for (size_t q = 0; q < W; ++q) {   // rounds a window does not use are uploaded too: idle lanes, empty slots
-      std::fill(&pu_lane[(q * B.maxPR + pu_cnt[q]) * 1024], &pu_lane[(q * B.maxPR + rmax) * 1024], -1);
-      std::fill(&pu_sub[(q * B.maxPR + pu_cnt[q]) * 512], &pu_sub[(q * B.maxPR + rmax) * 512], 0);
-    }
     if (rmax > 0) {
-      HIPCHK(c, hipMemcpy2DAsync(B.pu_lane, (size_t)B.maxPR * 4096, pu_lane.get(), (size_t)B.maxPR * 4096, (size_t)rmax * 4096, W,
-                                 hipMemcpyHostToDevice, c->stream));
-      HIPCHK(c, hipMemcpy2DAsync(B.pu_sub, (size_t)B.maxPR * 2048, pu_sub.get(), (size_t)B.maxPR * 2048, (size_t)rmax * 2048, W,
-                                 hipMemcpyHostToDevice, c->stream));
+      Span<int> pl = SG.take<int>(W * (size_t)rmax * 1024), psb = SG.take<int>(W * (size_t)rmax * 512);
+      if (SG.overflow) return fail(c, VPL_E_CAPACITY, "internal: staging arena bound too small");
+      for (size_t q = 0; q < W; ++q) {   // rounds a window does not use travel too: idle lanes, empty slots
+        int* l = pl.p + q * (size_t)rmax * 1024;
+        int* u = psb.p + q * (size_t)rmax * 512;
+        std::memcpy(l, &pu_lane[q * B.maxPR * 1024], (size_t)pu_cnt[q] * 4096);
+        std::memcpy(u, &pu_sub[q * B.maxPR * 512], (size_t)pu_cnt[q] * 2048);
+        std::fill(l + (size_t)pu_cnt[q] * 1024, l + (size_t)rmax * 1024, -1);
+        std::fill(u + (size_t)pu_cnt[q] * 512, u + (size_t)rmax * 512, 0);
+        SG.to_device(B.pu_lane + q * (size_t)B.maxPR * 1024, l, (size_t)rmax * 1024);
+        SG.to_device(B.pu_sub + q * (size_t)B.maxPR * 512, u, (size_t)rmax * 512);
+      }
     }
   } HIPCHK(c, up(c, B.pu_cnt, pu_cnt)); HIPCHK(c, up(c, B.pu_cnt0, pu_cnt0));
   HIPCHK(c, up(c, B.ln_start, ln_start)); HIPCHK(c, up(c, B.ln_nobs, ln_nobs)); HIPCHK(c, up(c, B.ln_off, ln_off));
@@ -809,20 +1015,39 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   HIPCHK(c, up(c, B.pr_frame, pr_frame)); HIPCHK(c, up(c, B.pr_idx, pr_idx));
   if (!chained) { HIPCHK(c, up(c, B.pr_x0, pr_x0)); HIPCHK(c, up(c, B.pr_r0, pr_r0)); }
   else {
-    // values of the priors: device to device, before the next solve overwrites mg_*
+    // values of the priors: device to device, before the scatter below overwrites mg_* with the next solve's tables
     DevBuf dkeep;
     HIPCHK(c, dkeep.alloc(W * 4));
     HIPCHK(c, hipMemcpyAsync(dkeep.p, keep_prior.data(), W * 4, hipMemcpyHostToDevice, c->stream));
+    if (B.prS != prev_prS && std::any_of(keep_prior.begin(), keep_prior.end(), [](int k) { return k != 0; })) {
+      // windows that keep their prior (MARGIN_SECOND_NEW pass-through) have J0 at the PREVIOUS batch stride: move them through
+      // a scratch copy (old and new locations of different windows overlap) -- ADVICE r3
+      DevBuf tmp;
+      HIPCHK(c, tmp.alloc(W * (size_t)MAXPN * MAXPN * 8));
+      hipLaunchKernelGGL(k_prior_restride, dim3(nW), dim3(256), 0, c->stream, B, (const int*)dkeep.p, prev_prS, tmp.d(), 0);
+      hipLaunchKernelGGL(k_prior_restride, dim3(nW), dim3(256), 0, c->stream, B, (const int*)dkeep.p, prev_prS, tmp.d(), 1);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     hipLaunchKernelGGL(k_prior_handoff, dim3(nW), dim3(256), 0, c->stream, B, (const int*)dkeep.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   HIPCHK(c, up(c, B.mg_n, mg_n)); HIPCHK(c, up(c, B.mg_nb, mg_nb)); HIPCHK(c, up(c, B.mg_kind, mg_kind));
   HIPCHK(c, up(c, B.mg_frame, mg_frame)); HIPCHK(c, up(c, B.mg_idx, mg_idx)); HIPCHK(c, up(c, B.mg_cam, mg_cam));
-  HIPCHK(c, up(c, B.mg_m, c->h_mg_m));
+  {
+    Span<int> mm = SG.take<int>(W);
+    if (SG.overflow) return fail(c, VPL_E_CAPACITY, "internal: staging arena bound too small");
+    std::memcpy(mm.p, c->h_mg_m.data(), W * 4);
+    HIPCHK(c, up(c, B.mg_m, mm));
+  }
+  c->h_mg_n.assign(mg_n.begin(), mg_n.end());
   if (c->force_general) std::fill(path.begin(), path.end(), 1);
   HIPCHK(c, up(c, B.path, path));
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // host staging vectors die here
+  // ONE host-to-device copy of the arena, ONE kernel that scatters its pieces into the batch's arrays
+  HIPCHK(c, stage_run(c, true));
+  if (c->leg_timing) HIPCHK(c, hipEventRecord(c->leg_ev[1], c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // the arena is free for the next call from here on
   c->layout_valid = true;
   return VPL_OK;
 }
@@ -1143,6 +1368,14 @@ int vpl_ba_solve(vpl_ctx* c) {
   if (c) { const int rs = settle(c); if (rs) return rs; }
   if (!c || c->nW < 1) return VPL_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->opt.marginalization_flag != VPL_MARGIN_NONE) { c->prior_resident = true; c->prior_resident_nW = c->nW; }
+  if (c->leg_timing) {
+    HIPCHK(c, hipEventRecord(c->leg_ev[2], c->stream));
+    launch_solve(c, 0, c->nW, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->leg_ev[3], c->stream));
+    return VPL_OK;
+  }
   if (c->use_graph && !c->timing && c->stream != nullptr) {   // (the legacy default stream cannot be captured)
     if (!c->graph_exec) {
       hipGraph_t graph = nullptr;
@@ -1161,23 +1394,47 @@ int vpl_ba_solve(vpl_ctx* c) {
   return VPL_OK;
 }
 
-// priors of the last marginalisation (k_marg) of the uploaded batch -> host; mn[2 w] = m, mn[2 w + 1] = n
-static int fetch_priors(vpl_ctx* c, int nW, vpl_prior* priors, std::vector<int>& mn) {
+// priors of the last marginalisation (k_marg) of the uploaded batch -> host; mn[2 w] = m, mn[2 w + 1] = n.
+// Two steps around ONE device-to-host copy of the staging arena: plan (pieces of the arena + gather segments), then -- after
+// stage_run(c, false) and a stream synchronisation -- finish (scatter into the caller's vpl_prior structs).
+struct PriorFetch {
+  Span<int> mg_n, mg_nb, mg_kind, mg_frame, mg_idx, mg_m;
+  Span<double> mg_x0, mg_r0;
+  std::vector<Span<double>> J0;   // per window: the host-side bound of the kept dims, squared
+};
+static size_t prior_fetch_bytes(vpl_ctx* c, int nW) {
+  size_t b = (size_t)nW * ((3 + 3 * MAXPB) * 4 + (9 * MAXPB + MAXKEEP) * 8 + 64 + sizeof(CopySeg)) + 16 * 64;
+  for (int w = 0; w < nW; ++w) {
+    const int n = (size_t)w < c->h_mg_n.size() ? std::min(std::max(c->h_mg_n[w], 0), (int)MAXKEEP) : (int)MAXKEEP;
+    b += (size_t)n * n * 8;
+  }
+  return b;
+}
+static int prior_fetch_plan(vpl_ctx* c, int nW, PriorFetch& F) {
+  DevBatch& B = c->B;
+  Stage& S = c->stage;
+  const size_t W = nW;
+  F.mg_m = S.take<int>(W); F.mg_n = S.take<int>(W); F.mg_nb = S.take<int>(W);
+  F.mg_kind = S.take<int>(W * MAXPB); F.mg_frame = S.take<int>(W * MAXPB); F.mg_idx = S.take<int>(W * MAXPB);
+  F.mg_x0 = S.take<double>(W * MAXPB * 9); F.mg_r0 = S.take<double>(W * MAXKEEP);
+  S.from_device(F.mg_m.p, B.mg_m, W); S.from_device(F.mg_n.p, B.mg_n, W); S.from_device(F.mg_nb.p, B.mg_nb, W);
+  S.from_device(F.mg_kind.p, B.mg_kind, W * MAXPB); S.from_device(F.mg_frame.p, B.mg_frame, W * MAXPB);
+  S.from_device(F.mg_idx.p, B.mg_idx, W * MAXPB);
+  S.from_device(F.mg_x0.p, B.mg_x0, W * MAXPB * 9); S.from_device(F.mg_r0.p, B.mg_r0, W * MAXKEEP);
+  F.J0.resize(W);
+  for (size_t w = 0; w < W; ++w) {
+    const int n = w < c->h_mg_n.size() ? std::min(std::max(c->h_mg_n[w], 0), (int)MAXKEEP) : (int)MAXKEEP;
+    F.J0[w] = S.take<double>((size_t)n * n);
+    S.from_device(F.J0[w].p, B.mg_J0 + w * (size_t)MAXKEEP * MAXKEEP, (size_t)n * n);
+  }
+  if (S.overflow) return fail(c, VPL_E_CAPACITY, "internal: staging arena bound too small");
+  return VPL_OK;
+}
+static int prior_fetch_finish(vpl_ctx* c, int nW, const PriorFetch& F, vpl_prior* priors, std::vector<int>& mn) {
   DevBatch& B = c->B;
   const size_t W = nW;
-  hipStream_t s = c->stream;
-  std::vector<int> mg_n(W), mg_nb(W), mg_kind(W * MAXPB), mg_frame(W * MAXPB), mg_idx(W * MAXPB), mg_m(W);
-  std::vector<double> mg_x0(W * MAXPB * 9), mg_J0(W * MAXKEEP * MAXKEEP), mg_r0(W * MAXKEEP);
-  HIPCHK(c, hipMemcpyAsync(mg_m.data(), B.mg_m, W * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(mg_n.data(), B.mg_n, W * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(mg_nb.data(), B.mg_nb, W * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(mg_kind.data(), B.mg_kind, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(mg_frame.data(), B.mg_frame, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(mg_idx.data(), B.mg_idx, W * MAXPB * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(mg_x0.data(), B.mg_x0, W * MAXPB * 9 * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(mg_J0.data(), B.mg_J0, W * MAXKEEP * MAXKEEP * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(mg_r0.data(), B.mg_r0, W * MAXKEEP * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
+  const Span<int>&mg_n = F.mg_n, &mg_nb = F.mg_nb, &mg_kind = F.mg_kind, &mg_frame = F.mg_frame, &mg_idx = F.mg_idx, &mg_m = F.mg_m;
+  const Span<double>& mg_x0 = F.mg_x0, &mg_r0 = F.mg_r0;
   mn.assign(2 * W, 0);
   for (size_t w = 0; w < W; ++w) {
     mn[2 * w] = mg_m[w];
@@ -1209,10 +1466,20 @@ static int fetch_priors(vpl_ctx* c, int nW, vpl_prior* priors, std::vector<int>&
       p.block_idx[b] = mg_idx[w * MAXPB + b];
       std::memcpy(p.x0[b], &mg_x0[(w * MAXPB + b) * 9], 9 * 8);
     }
-    std::memcpy(p.J0, &mg_J0[w * MAXKEEP * MAXKEEP], (size_t)n * n * 8);
+    if ((size_t)n * n > F.J0[w].n) return fail(c, VPL_E_HIP, "internal: the device kept more prior dims than the host's bound");
+    std::memcpy(p.J0, F.J0[w].p, (size_t)n * n * 8);
     std::memcpy(p.r0, &mg_r0[w * MAXKEEP], (size_t)n * 8);
   }
   return VPL_OK;
+}
+static int fetch_priors(vpl_ctx* c, int nW, vpl_prior* priors, std::vector<int>& mn) {
+  HIPCHK(c, c->stage.reserve(prior_fetch_bytes(c, nW) + 4096));
+  PriorFetch F;
+  int rc = prior_fetch_plan(c, nW, F);
+  if (rc) return rc;
+  HIPCHK(c, stage_run(c, false));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return prior_fetch_finish(c, nW, F, priors, mn);
 }
 
 // States of the uploaded batch -> caller's DEVICE buffer [nW][183], asynchronous on the context's stream
@@ -1231,22 +1498,29 @@ int vpl_ba_download(vpl_ctx* c, int nW, vpl_window* win, vpl_prior* priors, vpl_
   HIPCHK(c, hipSetDevice(c->device));
   DevBatch& B = c->B;
   const size_t W = nW;
-  std::vector<double> pose(W * 77), sb(W * 99), ex(W * 7), invd(W * B.maxP), plk(W * B.maxL * 6);
-  std::vector<TrState> tr(W);
-  hipStream_t s = c->stream;
-  HIPCHK(c, hipMemcpyAsync(pose.data(), B.pose, W * 77 * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(sb.data(), B.sb, W * 99 * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(ex.data(), B.ex, W * 7 * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(invd.data(), B.invd, W * B.maxP * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(plk.data(), B.plk, W * B.maxL * 6 * 8, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(tr.data(), B.tr, W * sizeof(TrState), hipMemcpyDeviceToHost, s));
   const bool marg = priors != nullptr && c->opt.marginalization_flag != VPL_MARGIN_NONE;
-  std::vector<int> mg_m(W), removed(W * B.maxL), mn;
-  HIPCHK(c, hipMemcpyAsync(mg_m.data(), B.mg_m, W * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(removed.data(), B.ln_removed, W * B.maxL * 4, hipMemcpyDeviceToHost, s));
+  hipStream_t s = c->stream;
+  if (c->leg_timing) HIPCHK(c, hipEventRecord(c->leg_ev[4], s));
+  // one gather kernel into the device arena, ONE device-to-host copy into the pinned arena
+  Stage& S = c->stage;
+  HIPCHK(c, S.reserve(W * ((77 + 99 + 7 + B.maxP + 6 * B.maxL) * 8 + sizeof(TrState) + 4 + B.maxL * 4) + 16 * 64 + 16 * sizeof(CopySeg) +
+                      (marg ? prior_fetch_bytes(c, nW) : 0) + 4096));
+  Span<double> pose = S.take<double>(W * 77), sb = S.take<double>(W * 99), ex = S.take<double>(W * 7), invd = S.take<double>(W * B.maxP),
+               plk = S.take<double>(W * B.maxL * 6);
+  Span<TrState> tr = S.take<TrState>(W);
+  Span<int> mg_m = S.take<int>(W), removed = S.take<int>(W * B.maxL);
+  std::vector<int> mn;
+  S.from_device(pose.p, B.pose, W * 77); S.from_device(sb.p, B.sb, W * 99); S.from_device(ex.p, B.ex, W * 7);
+  S.from_device(invd.p, B.invd, W * B.maxP); S.from_device(plk.p, B.plk, W * B.maxL * 6); S.from_device(tr.p, B.tr, W);
+  S.from_device(mg_m.p, B.mg_m, W); S.from_device(removed.p, B.ln_removed, W * B.maxL);
+  PriorFetch F;
+  if (marg) { const int rc = prior_fetch_plan(c, nW, F); if (rc) return rc; }
+  if (S.overflow) return fail(c, VPL_E_CAPACITY, "internal: staging arena bound too small");
+  HIPCHK(c, stage_run(c, false));
+  if (c->leg_timing) HIPCHK(c, hipEventRecord(c->leg_ev[5], s));
   HIPCHK(c, hipStreamSynchronize(s));
   if (marg) {
-    const int rc = fetch_priors(c, nW, priors, mn);
+    const int rc = prior_fetch_finish(c, nW, F, priors, mn);
     if (rc) return rc;
   }
   for (size_t w = 0; w < W; ++w) {
@@ -1307,6 +1581,7 @@ static int marginalize_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl
     { KTimer t(c, "k_lin_marg"); hipLaunchKernelGGL(k_lin<2>, grid, dim3(LIN_THREADS), lin_smem(c->maxP, c->maxL), s, B); }
     ran = true;
   }
+  c->prior_resident = true; c->prior_resident_nW = nW;
   if (ran) { KTimer t(c, "k_marg"); if (c->marg_small) hipLaunchKernelGGL(k_marg<256>, grid, dim3(256), c->marg_smem, s, B); else hipLaunchKernelGGL(k_marg<MARG_THREADS>, grid, dim3(MARG_THREADS), c->marg_smem, s, B); }
   HIPCHK(c, hipGetLastError());
   // (the priors are fetched from the device when the call completes: any later call on the context completes this one first)

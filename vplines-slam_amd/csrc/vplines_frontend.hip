@@ -29,6 +29,8 @@ struct vpl_fe_ctx {
   bool lmReserved = false;
   int *d_refImg = nullptr, *d_curImg = nullptr, *d_nRef = nullptr, *d_nCur = nullptr;
   vpl_line *d_linesRef = nullptr, *d_linesCur = nullptr;
+  int blurMode = VPL_BLUR_NORMALISED; // vpl_fe_set_blur_kernel
+  uint8_t* d_blur = nullptr;          // [maxN][H][W] copy of the blurred frames (vpl_fe_keep_blurred; tests)
   vpl_line* d_sorted = nullptr;       // [maxN][maxLines] the detected lines in the reference's order (k_ed_sort_lines)
   int* d_sortedCnt = nullptr;         // [maxN]
   // image preparation (remap + CLAHE)
@@ -290,7 +292,63 @@ int vpl_pre_batch(vpl_fe_ctx* c, int n, const uint8_t* raw, int equalize, double
   return images ? vpl_pre_download(c, n, images) : vpl_fe_synchronize(c);
 }
 
-int vpl_edlines_detect(vpl_fe_ctx* c, const vpl_edline_param* p) {
+// The taps of cv::GaussianBlur's 8-bit path in 8.8 fixed point (imgproc/smooth.cpp: createGaussianKernels +
+// getFixedpointGaussianKernel<ufixedpoint16>): ksize <= 0 with sigma > 0 picks cvRound(6 sigma + 1) | 1; sigma <= 0 takes the
+// fixed tables (n = 1, 3, 5, 7) or sigma = 0.15 n + 0.35.  VPL_BLUR_OPENCV_341: k_i = cvRound(256 g_i) (3.4.1 - 3.4.8, 4.0 - 4.1);
+// VPL_BLUR_NORMALISED: getGaussianKernelFixedPoint_ED (3.4.9+, 4.2+): the rounding error is carried from the ends towards the
+// centre, the centre tap takes what is left of 256.  Returns the kernel size, or -1 (even, or larger than `cap`).
+static int gauss_kernel_q8(int ksize, double sigma, int mode, int* k, int cap) {
+  if (sigma < 0) sigma = 0;
+  if (ksize <= 0 && sigma > 0) ksize = (int)std::nearbyint(sigma * 3 * 2 + 1) | 1;
+  if (ksize <= 0 || (ksize & 1) == 0 || ksize > cap) return -1;
+  const int n = ksize, h = n / 2;
+  double v[16];
+  if (sigma <= 0 && n <= 7) {
+    static const double t1[] = {1.0}, t3[] = {0.25, 0.5, 0.25}, t5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625},
+                        t7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
+    const double* t = n == 1 ? t1 : n == 3 ? t3 : n == 5 ? t5 : t7;
+    for (int i = 0; i < n; ++i) v[i] = t[i];
+  } else {
+    const double sx = sigma > 0 ? sigma : 0.15 * n + 0.35;
+    const double scale2X = -0.5 * 0.25 / (sx * sx);
+    double sum = 0;
+    for (int i = 0, x = 1 - n; i < n; ++i, x += 2) { v[i] = std::exp((double)(x * x) * scale2X); sum += v[i]; }
+    sum = 1.0 / sum;
+    for (int i = 0; i < n; ++i) v[i] *= sum;
+  }
+  if (mode == VPL_BLUR_OPENCV_341) {
+    for (int i = 0; i < n; ++i) k[i] = (int)std::nearbyint(v[i] * 256.0);
+  } else {
+    double err = 0;
+    int sum = 0;
+    for (int i = 0; i < h; ++i) {
+      const double adj = v[i] * 256.0 + err;
+      const int v0 = (int)std::nearbyint(adj);
+      err = adj - v0;
+      k[i] = k[n - 1 - i] = v0;
+      sum += v0;
+    }
+    k[h] = 256 - 2 * sum;
+  }
+  return n;
+}
+
+int vpl_fe_set_blur_kernel(vpl_fe_ctx* c, int mode) {
+  if (!c || (mode != VPL_BLUR_NORMALISED && mode != VPL_BLUR_OPENCV_341)) return VPL_E_INVALID;
+  c->blurMode = mode;
+  return VPL_OK;
+}
+
+int vpl_fe_keep_blurred(vpl_fe_ctx* c, int enable) {
+  if (!c) return VPL_E_INVALID;
+  FECHK(c, hipSetDevice(c->device));
+  if (enable && !c->d_blur) FECHK(c, fe_alloc(c, &c->d_blur, (size_t)c->maxN * c->W * c->H));
+  c->B.blurOut = enable ? c->d_blur : nullptr;
+  return VPL_OK;
+}
+
+// EDLineDetector::EDline(image, lines, smoothed) for the uploaded batch (edline_detector.cpp:1176-1198 -> EdgeDrawing :81-710)
+int vpl_edlines_detect_ex(vpl_fe_ctx* c, const vpl_edline_param* p, int smoothed) {
   if (!c || !p || c->n < 1) return VPL_E_INVALID;
   if (p->scanIntervals < 1 || p->minLineLen < 2) return fe_fail(c, VPL_E_INVALID, "bad EDLine parameters");
   FECHK(c, hipSetDevice(c->device));
@@ -304,13 +362,39 @@ int vpl_edlines_detect(vpl_fe_ctx* c, const vpl_edline_param* p) {
   const int PX = c->W * c->H;
   hipStream_t s = c->stream;
   FECHK(c, hipMemsetAsync(B.nLines, 0, c->n * sizeof(int), s));
-  { FeTimer t(c, "k_ed_grad"); hipLaunchKernelGGL(k_ed_grad, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B); }
+  int ksz = 1;
+  if (!smoothed) {   // cv::GaussianBlur(image, image_, cv::Size(ksize_, ksize_), sigma_), edline_detector.cpp:82-84
+    ksz = gauss_kernel_q8(p->ksize, (double)p->sigma, c->blurMode, B.blurK, 2 * EDB_RMAX + 1);
+    if (ksz < 0) return fe_fail(c, VPL_E_INVALID, "Gaussian kernel size must be odd and at most 7");
+    if (c->W < 8 || c->H < 8) return fe_fail(c, VPL_E_INVALID, "frames smaller than 8 x 8 are not supported with smoothed = false");
+    B.blurR = ksz / 2;
+  }
+  if (smoothed || ksz == 1) {   // a 1 x 1 kernel copies (GaussianBlur's early return)
+    FeTimer t(c, "k_ed_grad");
+    hipLaunchKernelGGL(k_ed_grad, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B);
+    if (!smoothed && B.blurOut) FECHK(c, hipMemcpyAsync(B.blurOut, B.img, (size_t)c->n * PX, hipMemcpyDeviceToDevice, s));
+  } else {
+    FeTimer t(c, "k_ed_blur_grad");
+    hipLaunchKernelGGL(k_ed_blur_grad, dim3((c->W + EDB_TW - 1) / EDB_TW, (c->H + EDB_TH - 1) / EDB_TH, c->n), dim3(256), 0, s, B);
+  }
   { FeTimer t(c, "k_ed_anchor"); hipLaunchKernelGGL(k_ed_anchor, dim3(c->n), dim3(1024), 0, s, B); }
   { FeTimer t(c, "k_ed_code"); hipLaunchKernelGGL(k_ed_code, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B); }
   { FeTimer t(c, "k_ed_route"); hipLaunchKernelGGL(k_ed_route, dim3(c->n), dim3(64 * ED_ROUTE_WAVES), c->routeSmem, s, B); }
   { FeTimer t(c, "k_ed_fit"); hipLaunchKernelGGL(k_ed_fit, dim3(ED_FIT_BLOCKS, c->n), dim3(64), 0, s, B); }
   { FeTimer t(c, "k_ed_sort_lines"); hipLaunchKernelGGL(k_ed_sort_lines, dim3(c->n), dim3(256), 0, s, B, c->d_sorted, c->d_sortedCnt, c->maxLines); }
   FECHK(c, hipGetLastError());
+  return VPL_OK;
+}
+
+// the production call: smoothed = true (feature_tracker/src/line_feature_tracker.cpp:87)
+int vpl_edlines_detect(vpl_fe_ctx* c, const vpl_edline_param* p) { return vpl_edlines_detect_ex(c, p, 1); }
+
+int vpl_edlines_debug_blurred(vpl_fe_ctx* c, int img, uint8_t* out) {
+  if (!c || !out || img < 0 || img >= c->n || !c->B.blurOut) return VPL_E_INVALID;
+  FECHK(c, hipSetDevice(c->device));
+  const size_t PX = (size_t)c->W * c->H;
+  FECHK(c, hipMemcpyAsync(out, c->B.blurOut + img * PX, PX, hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipStreamSynchronize(c->stream));
   return VPL_OK;
 }
 
@@ -326,15 +410,51 @@ int vpl_edlines_download(vpl_fe_ctx* c, int n, vpl_line* lines, int* counts) {
   return VPL_OK;
 }
 
-int vpl_edlines_detect_batch(vpl_fe_ctx* c, int n, const uint8_t* images, const vpl_edline_param* p, vpl_line* lines,
-                             int* counts) {
+int vpl_edlines_detect_batch_ex(vpl_fe_ctx* c, int n, const uint8_t* images, const vpl_edline_param* p, int smoothed,
+                                vpl_line* lines, int* counts) {
   int rc = vpl_edlines_upload(c, n, images);
   if (rc) return rc;
-  rc = vpl_edlines_detect(c, p);
+  rc = vpl_edlines_detect_ex(c, p, smoothed);
   if (rc) return rc;
   rc = vpl_fe_synchronize(c);
   if (rc) return rc;
   return vpl_edlines_download(c, n, lines, counts);
+}
+int vpl_edlines_detect_batch(vpl_fe_ctx* c, int n, const uint8_t* images, const vpl_edline_param* p, vpl_line* lines,
+                             int* counts) {
+  return vpl_edlines_detect_batch_ex(c, n, images, p, 1, lines, counts);
+}
+
+// LineMatching::LineFilter (line_matching.cpp:167-264) on the lines of the last detect, where they lie (asynchronous):
+// vpl_edlines_download and vpl_match_from_detected then see the filtered lists
+int vpl_line_filter_detected(vpl_fe_ctx* c, float distance_threshold, float parallel_threshold) {
+  if (!c || c->n < 1) return VPL_E_INVALID;
+  if (c->maxLines > 8192) return fe_fail(c, VPL_E_INVALID, "LineFilter: max_lines_per_image above 8192");
+  FECHK(c, hipSetDevice(c->device));
+  FeTimer t(c, "k_lm_line_filter");
+  hipLaunchKernelGGL(k_lm_line_filter, dim3(c->n), dim3(256), (size_t)c->maxLines * 8, c->stream, c->d_sorted, c->d_sortedCnt,
+                     c->maxLines, distance_threshold, parallel_threshold);
+  FECHK(c, hipGetLastError());
+  return VPL_OK;
+}
+
+// the same for caller-owned line lists [n][max_lines] (in / out), through the context's line table
+int vpl_line_filter_batch(vpl_fe_ctx* c, int n, vpl_line* lines, int* counts, float distance_threshold, float parallel_threshold) {
+  if (!c || !lines || !counts || n < 1 || n > c->maxN) return VPL_E_INVALID;
+  if (c->maxLines > 8192) return fe_fail(c, VPL_E_INVALID, "LineFilter: max_lines_per_image above 8192");
+  for (int i = 0; i < n; ++i)
+    if (counts[i] < 0 || counts[i] > c->maxLines) return fe_fail(c, VPL_E_INVALID, "line count beyond max_lines_per_image");
+  FECHK(c, hipSetDevice(c->device));
+  const size_t ML = c->maxLines;
+  FECHK(c, hipMemcpyAsync(c->d_sorted, lines, (size_t)n * ML * sizeof(vpl_line), hipMemcpyHostToDevice, c->stream));
+  FECHK(c, hipMemcpyAsync(c->d_sortedCnt, counts, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_lm_line_filter, dim3(n), dim3(256), ML * 8, c->stream, c->d_sorted, c->d_sortedCnt, (int)ML,
+                     distance_threshold, parallel_threshold);
+  FECHK(c, hipGetLastError());
+  FECHK(c, hipMemcpyAsync(counts, c->d_sortedCnt, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipMemcpyAsync(lines, c->d_sorted, (size_t)n * ML * sizeof(vpl_line), hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipStreamSynchronize(c->stream));
+  return VPL_OK;
 }
 
 int vpl_edlines_debug_stage(vpl_fe_ctx* c, int img, int16_t* dx, int16_t* dy, int16_t* g, uint8_t* dir, uint32_t* anchors,

@@ -57,6 +57,10 @@ def records_to_lines(rec):
     return out
 
 
+BLUR_NORMALISED, BLUR_OPENCV_341 = 0, 1
+LINE_FILTER_PARALLEL_DEFAULT = 0.0348994967   # sin(3 degrees), line_matching.h:37
+
+
 def default_param():
     """production values: line_feature_tracker_node.cpp:203 / config/euroc/euroc_config.yaml:84-87"""
     p = EdlineParam()
@@ -92,6 +96,14 @@ def _bind(lib):
     lib.vpl_pre_download.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8)]
     lib.vpl_pre_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     lib.vpl_edlines_detect.argtypes = [vp, C.POINTER(EdlineParam)]
+    lib.vpl_edlines_detect_ex.argtypes = [vp, C.POINTER(EdlineParam), C.c_int]
+    lib.vpl_edlines_detect_batch_ex.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8), C.POINTER(EdlineParam), C.c_int,
+                                                C.POINTER(Line), C.POINTER(C.c_int)]
+    lib.vpl_fe_set_blur_kernel.argtypes = [vp, C.c_int]
+    lib.vpl_fe_keep_blurred.argtypes = [vp, C.c_int]
+    lib.vpl_edlines_debug_blurred.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8)]
+    lib.vpl_line_filter_detected.argtypes = [vp, C.c_float, C.c_float]
+    lib.vpl_line_filter_batch.argtypes = [vp, C.c_int, C.POINTER(Line), C.POINTER(C.c_int), C.c_float, C.c_float]
     lib.vpl_edlines_download.argtypes = [vp, C.c_int, C.POINTER(Line), C.POINTER(C.c_int)]
     lib.vpl_edlines_detect_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8), C.POINTER(EdlineParam), C.POINTER(Line),
                                              C.POINTER(C.c_int)]
@@ -214,9 +226,41 @@ class FrontendContext:
                     "vpl_vp_debug")
         return grid, pairs, best.value, drawn.value
 
-    def detect(self, param=None):
+    def detect(self, param=None, smoothed=True):
+        """EDline(image, lines, smoothed) for the uploaded batch; smoothed=False (the reference's default) runs the Gaussian
+        pre-blur of EdgeDrawing first (edline_detector.cpp:82-84)"""
         self._param = param or default_param()
-        self._check(self.lib.vpl_edlines_detect(self.h, C.byref(self._param)), "vpl_edlines_detect")
+        self._check(self.lib.vpl_edlines_detect_ex(self.h, C.byref(self._param), 1 if smoothed else 0), "vpl_edlines_detect_ex")
+
+    def set_blur_kernel(self, mode):
+        """BLUR_NORMALISED (default, OpenCV 3.4.9+ / 4.2+) or BLUR_OPENCV_341"""
+        self._check(self.lib.vpl_fe_set_blur_kernel(self.h, int(mode)), "vpl_fe_set_blur_kernel")
+
+    def keep_blurred(self, on=True):
+        self._check(self.lib.vpl_fe_keep_blurred(self.h, 1 if on else 0), "vpl_fe_keep_blurred")
+
+    def debug_blurred(self, img):
+        out = np.empty((self.H, self.W), np.uint8)
+        self._check(self.lib.vpl_edlines_debug_blurred(self.h, img, out.ctypes.data_as(C.POINTER(C.c_uint8))),
+                    "vpl_edlines_debug_blurred")
+        return out
+
+    def line_filter_detected(self, distance_threshold, parallel_threshold=LINE_FILTER_PARALLEL_DEFAULT):
+        """LineMatching::LineFilter (line_matching.cpp:167-264) on the lines of the last detect, in HBM"""
+        self._check(self.lib.vpl_line_filter_detected(self.h, distance_threshold, parallel_threshold), "vpl_line_filter_detected")
+
+    def line_filter_batch(self, lines, distance_threshold, parallel_threshold=LINE_FILTER_PARALLEL_DEFAULT):
+        """LineFilter on caller-owned lists: lines = list of [k,10] arrays; returns the filtered lists"""
+        n, ML = len(lines), self.max_lines
+        rec = np.zeros(n * ML, LINE_DTYPE)
+        cnt = np.zeros(n, np.int32)
+        for i, l in enumerate(lines):
+            cnt[i] = len(l)
+            lines_to_records(l, rec[i * ML:i * ML + len(l)])
+        self._check(self.lib.vpl_line_filter_batch(self.h, n, rec.ctypes.data_as(C.POINTER(Line)),
+                                                   cnt.ctypes.data_as(C.POINTER(C.c_int)), distance_threshold,
+                                                   parallel_threshold), "vpl_line_filter_batch")
+        return [records_to_lines(rec[i * ML:i * ML + cnt[i]]) for i in range(n)]
 
     def enable_kernel_timing(self, on=True):
         self._check(self.lib.vpl_fe_enable_kernel_timing(self.h, 1 if on else 0), "vpl_fe_enable_kernel_timing")
@@ -242,9 +286,9 @@ class FrontendContext:
                     "vpl_edlines_download")
         return [records_to_lines(rec[i * self.max_lines:i * self.max_lines + counts[i]]) for i in range(self.n)]
 
-    def detect_batch(self, images, param=None):
+    def detect_batch(self, images, param=None, smoothed=True):
         self.upload(images)
-        self.detect(param)
+        self.detect(param, smoothed)
         self.synchronize()
         return self.download()
 

@@ -96,19 +96,20 @@ class EDLineDetector {
     p_.anchorThreshold = param.anchorThreshold; p_.scanIntervals = param.scanIntervals;
     p_.minLineLen = param.minLineLen; p_.lineFitErrThreshold = param.lineFitErrThreshold;
   }
-  // int EDLineDetector::EDline(cv::Mat& image, std::vector<Line>& lines, bool smoothed): returns 1, or -1 on error
-  // (edline_detector.cpp:1176-1198).  Only smoothed = true (the production call) exists on the device.
-  int EDline(const uint8_t* image, std::vector<Line>& lines, bool smoothed = true) {
-    if (!smoothed || !image) return -1;
+  // int EDLineDetector::EDline(cv::Mat& image, std::vector<Line>& lines, bool smoothed = false): returns 1, or -1 on error
+  // (edline_detector.h:79-81, edline_detector.cpp:1176-1198).  smoothed = false, the reference's default, runs the Gaussian
+  // pre-blur of EdgeDrawing first (edline_detector.cpp:82-84); production passes true (line_feature_tracker.cpp:87).
+  int EDline(const uint8_t* image, std::vector<Line>& lines, bool smoothed = false) {
+    if (!image) return -1;
     std::vector<vpl_line> out(dev_.max_lines());
     int n = 0;
-    if (vpl_edlines_detect_batch(dev_.ctx(), 1, image, &p_, out.data(), &n) != 0) return -1;
+    if (vpl_edlines_detect_batch_ex(dev_.ctx(), 1, image, &p_, smoothed ? 1 : 0, out.data(), &n) != 0) return -1;
     lines.clear();
     for (int i = 0; i < n; ++i) lines.push_back(to_line(out[i]));
     return 1;
   }
 #ifdef VPL_USE_OPENCV
-  int EDline(cv::Mat& image, std::vector<Line>& lines, bool smoothed = true) {
+  int EDline(cv::Mat& image, std::vector<Line>& lines, bool smoothed = false) {
     if (image.type() != CV_8UC1 || !image.isContinuous() || image.cols != dev_.width() || image.rows != dev_.height()) return -1;
     return EDline(image.data, lines, smoothed);
   }
@@ -157,6 +158,19 @@ class LineMatching {
     if (!matched) return false;
     line_ref_to_line_cur.assign(r2c.begin(), r2c.begin() + nr);
     return true;
+  }
+  // void LineMatching::LineFilter(std::vector<Line>& lines, float distance_threshold, float parallel_threshold = sin 3 deg)
+  // (line_matching.h:35-37, line_matching.cpp:167-264); throws on device errors
+  void LineFilter(std::vector<Line>& lines, float distance_threshold, float parallel_threshold = 0.0348994967f) {
+    const int ML = dev_.max_lines();
+    if ((int)lines.size() > ML) throw std::runtime_error("more lines than max_lines");
+    std::vector<vpl_line> l(ML);
+    for (size_t i = 0; i < lines.size(); ++i) l[i] = from_line(lines[i]);
+    int n = (int)lines.size();
+    if (vpl_line_filter_batch(dev_.ctx(), 1, l.data(), &n, distance_threshold, parallel_threshold) != 0)
+      throw std::runtime_error(std::string("vpl_line_filter_batch: ") + vpl_fe_last_error(dev_.ctx()));
+    lines.clear();
+    for (int i = 0; i < n; ++i) lines.push_back(to_line(l[i]));
   }
 #ifdef VPL_USE_OPENCV
   bool Matching(const cv::Mat& img_ref, const cv::Mat& img_cur, const std::vector<Line>& lines_ref,
