@@ -2,7 +2,9 @@
 // Estimator::optimizationwithLine() (estimator.cpp:1043-1453) with vpl_ba_solve_windows() pays per call, for 1, 8 and 64
 // windows of the benchmark shape (11 frames, 200 points + 80 lines + VP observations, prior of the previous solve).
 // Prints one JSON object: median wall-clock milliseconds of upload / solve (+ synchronize) / download and of the whole
-// call.  Built and run by tests/test_gpu_latency.py and by bench.py.
+// call, and next to them the DEVICE time of each leg (hipEvents on the context's stream: vpl_ctx_leg_times) from a second
+// series of calls with leg timing on -- a leg whose wall clock is far above its device time is waiting on the host side
+// (runtime, driver), not on the GPU.  Built and run by tests/test_gpu_latency.py and by bench.py.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -100,8 +102,28 @@ int main() {
       const auto t3 = clk::now();
       if (r >= 3) { t_up.push_back(ms(t0, t1)); t_solve.push_back(ms(t1, t2)); t_down.push_back(ms(t2, t3)); t_all.push_back(ms(t0, t3)); }
     }
-    std::printf("%s\"nW%d\": {\"upload_ms\": %.4f, \"solve_ms\": %.4f, \"download_ms\": %.4f, \"total_ms\": %.4f, \"iterations\": %d, \"prior_n\": %d}",
-                si ? ", " : "", nW, med(t_up), med(t_solve), med(t_down), med(t_all), rep[0].iterations, rep[0].prior_n);
+    // the same calls with the legs bracketed by events on the device
+    std::vector<double> d_up, d_solve, d_down;
+    if (vpl_ctx_enable_leg_timing(ctx, 1) != VPL_OK) return 8;
+    for (int r = 0; r < 9; ++r) {
+      for (int i = 0; i < nW; ++i) {
+        Bw[i].invd = invd0[i]; Bw[i].lplk = plk0[i];
+        wb[i] = Bw[i].w;
+        wb[i].inv_depth = Bw[i].invd.data(); wb[i].line_plk = Bw[i].lplk.data();
+        wb[i].has_prior = 1; wb[i].prior = &priorA[i];
+      }
+      if (vpl_ba_upload(ctx, nW, wb.data(), &opt) != VPL_OK) return 5;
+      if (vpl_ba_solve(ctx) != VPL_OK || vpl_ctx_synchronize(ctx) != VPL_OK) return 6;
+      if (vpl_ba_download(ctx, nW, wb.data(), priorOut.data(), rep.data()) != VPL_OK) return 7;
+      double ms3[3];
+      if (vpl_ctx_leg_times(ctx, ms3) != VPL_OK) return 9;
+      if (r >= 2) { d_up.push_back(ms3[0]); d_solve.push_back(ms3[1]); d_down.push_back(ms3[2]); }
+    }
+    vpl_ctx_enable_leg_timing(ctx, 0);
+    std::printf("%s\"nW%d\": {\"upload_ms\": %.4f, \"solve_ms\": %.4f, \"download_ms\": %.4f, \"total_ms\": %.4f, "
+                "\"device_upload_ms\": %.4f, \"device_solve_ms\": %.4f, \"device_download_ms\": %.4f, \"iterations\": %d, \"prior_n\": %d}",
+                si ? ", " : "", nW, med(t_up), med(t_solve), med(t_down), med(t_all), med(d_up), med(d_solve), med(d_down),
+                rep[0].iterations, rep[0].prior_n);
     vpl_ctx_destroy(ctx);
   }
   std::printf("}\n");

@@ -154,3 +154,86 @@ def test_device_resident_priors_reproduce_the_host_chain(gpu_ctx):
     for c in range(NCH):
         assert pri[c].n == prior[c].n and np.array_equal(pri[c].J(), prior[c].J()) and np.array_equal(pri[c].r(), prior[c].r())
     ctx.close()
+
+
+def test_chained_upload_needs_resident_priors():
+    """vpl_ba_upload_chained on a context whose priors are not resident -- a fresh context, another batch size, a
+    MARGIN_NONE solve, or any upload in between (the line-map entry points upload too) -- is VPL_E_INVALID, not a silent
+    prior-less solve or an out-of-range read."""
+    opt = v.default_options()
+    cfg = v.workload.config(60, 20, True)
+    ws = [v.workload.generate(v.workload.seed_for(3, 7900 + k), cfg, 0.3 + k * cfg.kf_dt) for k in range(3)]
+    o.preintegrate_windows(ws, opt)
+    ctx = v.Context(device=0, max_windows=2, max_points=60, max_point_obs=360, max_lines=20, max_line_obs=120)
+    with pytest.raises(RuntimeError):                       # nothing solved yet
+        ctx.upload([ws[0].copy()], opt, chained=True)
+    ctx.upload([ws[0].copy()], opt)
+    with pytest.raises(RuntimeError):                       # uploaded, not solved
+        ctx.upload([ws[1].copy()], opt, chained=True)
+    ctx.upload([ws[0].copy()], opt)
+    ctx.solve(); ctx.synchronize()
+    with pytest.raises(RuntimeError):                       # other batch size
+        ctx.upload([ws[1].copy(), ws[2].copy()], opt, chained=True)
+    ctx.upload([ws[0].copy()], opt)
+    ctx.solve(); ctx.synchronize()
+    ctx.triangulate_points([ws[0].copy()])                  # uploads with MARGIN_NONE: the next prior's tables are gone
+    with pytest.raises(RuntimeError):
+        ctx.upload([ws[1].copy()], opt, chained=True)
+    none = v.default_options()
+    none.marginalization_flag = v.capi.MARGIN_NONE
+    ctx.upload([ws[0].copy()], none)
+    ctx.solve(); ctx.synchronize()
+    with pytest.raises(RuntimeError):                       # a solve without marginalisation leaves no prior
+        ctx.upload([ws[1].copy()], opt, chained=True)
+    # and the positive case still works after all of that
+    ctx.upload([ws[0].copy()], opt)
+    ctx.solve(); ctx.synchronize()
+    w1 = ws[1].copy()
+    ctx.upload([w1], opt, chained=True)
+    ctx.solve(); ctx.synchronize()
+    pri, rep = ctx.download()
+    assert rep[0].iterations >= 1 and pri[0].n > 0
+    ctx.close()
+
+
+def test_chained_upload_with_kept_priors_and_a_changing_stride():
+    """MARGIN_SECOND_NEW leaves the prior of a window without pose WINDOW_SIZE-1 as it is; in a chained batch
+    such a window sits next to one whose prior shrinks, so the batch stride of pr_J0 changes while the kept prior must not
+    move.  Batch of two chains: chain 0 has a 45-dim prior that passes through, chain 1 a prior that holds poses 0..9 and
+    loses pose 9.  The device-resident chain must equal the chain through host-side vpl_prior structs, bit for bit."""
+    opt = v.default_options()
+    cfg = v.workload.config(150, 40, True)
+    cfgA = v.workload.config(150, 40, True)
+    cfgA.track_len = 11
+    A = [v.workload.generate(v.workload.seed_for(3, 8100), cfg, 0.0), v.workload.generate(v.workload.seed_for(3, 8101), cfgA, 0.4)]
+    Bw = [v.workload.generate(v.workload.seed_for(3, 8110 + i), cfg, 0.4 * i + cfg.kf_dt) for i in range(2)]
+    Cw = [v.workload.generate(v.workload.seed_for(3, 8120 + i), cfg, 0.4 * i + 2 * cfg.kf_dt) for i in range(2)]
+    o.preintegrate_windows(A + Bw + Cw, opt)
+    second = v.default_options()
+    second.marginalization_flag = v.capi.MARGIN_SECOND_NEW
+
+    def run(chained):
+        ctx = v.Context(device=0, max_windows=2, max_points=150, max_point_obs=150 * 11, max_lines=40, max_line_obs=40 * 11)
+        out = []
+        a = [w.copy() for w in A]
+        ctx.upload(a, opt); ctx.solve(); ctx.synchronize()
+        pri, _ = ctx.download()
+        assert pri[0].n == 45 and pri[1].n > 60             # different sizes: the stride is the larger one's
+        prev = [_copy_prior(p) for p in pri]
+        for stage in (Bw, Cw):
+            ws = [w.copy() for w in stage]
+            if not chained:
+                for i in range(2):
+                    ws[i].prior = prev[i]
+            ctx.upload(ws, second, chained=chained); ctx.solve(); ctx.synchronize()
+            pri, rep = ctx.download()
+            prev = [_copy_prior(p) for p in pri]
+            out.append((ws, prev))
+        ctx.close()
+        return out
+    host, dev = run(False), run(True)
+    for (wh, ph), (wd, pd) in zip(host, dev):
+        for i in range(2):
+            assert np.array_equal(wh[i].pose, wd[i].pose) and np.array_equal(wh[i].speed_bias, wd[i].speed_bias), i
+            assert ph[i].n == pd[i].n and np.array_equal(ph[i].J(), pd[i].J()) and np.array_equal(ph[i].r(), pd[i].r())
+    assert host[0][1][0].n == 45 and host[0][1][1].n == host[1][1][1].n   # chain 0 passed through, chain 1 lost pose 9 once

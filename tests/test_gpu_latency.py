@@ -27,4 +27,10 @@ def test_single_window_latency_through_the_c_abi(tmp_path):
         assert abs(d[k]["upload_ms"] + d[k]["solve_ms"] + d[k]["download_ms"] - d[k]["total_ms"]) < 0.5
     print("C-ABI latency [ms]:", d)
     assert d["nW1"]["total_ms"] <= 3.0
-    assert d["nW64"]["total_ms"] <= 64 * d["nW1"]["total_ms"]
+    # the 64-window call (measured 2.9 ms on the build's box, 29.9 ms on the round-3 driver box with
+    # dozens of pageable copies per call; now one pinned H2D + one pinned D2H)
+    assert d["nW64"]["total_ms"] <= 6.0
+    assert d["nW64"]["upload_ms"] + d["nW64"]["download_ms"] <= 2.0
+    # the wall clock of a leg stays near its device time: nothing waits on the host side
+    for k in ("nW1", "nW8", "nW64"):
+        assert d[k]["device_solve_ms"] > 0 and d[k]["solve_ms"] <= d[k]["device_solve_ms"] + 1.0, d[k]
