@@ -122,6 +122,34 @@ __device__ __forceinline__ void prep_body(const DevBatch& B, const int w, double
     const double* J0 = B.pr_J0 + (size_t)w * B.prS;
     double* H = B.pr_H + (size_t)w * B.prS;
     const double* Js = fits ? Jl : J0;   // (staged at the top; the barrier after the states made it visible)
+    if (fits) {
+      // on the FP64 matrix cores (round 4): the lower 16 x 16 tiles of J0^T J0 dealt to the waves, K-steps of four rows of J0;
+      // lane (kk, m) supplies J0[4 ks + kk][16 t + m] for both operands and holds C[kk + 4 v][m].  One scalar dot product of
+      // length n per entry cost 0.25 ms per 512 windows at the reference's steady-state size n = 75 (0.10 at n = 45).
+      const int NT = (n + 15) >> 4, NLT = NT * (NT + 1) / 2, KS = (n + 3) >> 2;
+      const int m = lane & 15, kk = lane >> 4;
+      for (int t = wv; t < NLT; t += NWV) {
+        int ta, tb;
+        tri_decode(t, ta, tb);
+        const int ca = 16 * ta + m, cb = 16 * tb + m;
+        v4d_lin acc = {0, 0, 0, 0};
+        for (int ks = 0; ks < KS; ++ks) {
+          const int k = 4 * ks + kk;
+          const double av = (k < n && ca < n) ? Js[k * n + ca] : 0.0;
+          const double bv = (k < n && cb < n) ? Js[k * n + cb] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+        const double vals[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = 16 * ta + kk + 4 * v, c2 = cb;
+          if (r < n && c2 < n && (ta != tb || r >= c2)) {
+            H[(size_t)r * n + c2] = vals[v];
+            H[(size_t)c2 * n + r] = vals[v];
+          }
+        }
+      }
+    } else
     for (int idx = tid; idx < n * n; idx += blockDim.x) {
       int a = idx / n, b = idx % n;
       double s = 0;

@@ -177,18 +177,25 @@ inline bool point_unit_chains_finish(const int* st, const PointUnitLayout& L, bo
 // committed in ticket order, sorted by the K-steps the wave has done when it reaches the add (ties: by wave): the waves
 // start together and advance at about the same rate, so a wave seldom finds its ticket not yet due -- and the order is a
 // fixed function of the table.
-//   tab  [maxKS][4] : {group (0..10: points of that start frame, 32 | f: lines), id0 | id1 << 16, id2 | id3 << 16, 0}, 0xffff = none
+//   tab  [maxKS][4] : {group (0..10: points of that start frame, 32 | f: lines, 64: WIDE), id0 | id1 << 16, id2 | id3 << 16, 0}, 0xffff = none
 //   wave [8][SK_WSTRIDE] : {number of chunks n, then n x (first entry, end, ticket)}
+// Mixed track lengths (narrow_frames > 0: the batch's rows are wider than narrow_frames frames, round 4): an entry that holds a
+// track of more than narrow_frames observations is WIDE (bit 6 of the group; its product needs every column tile of the
+// compact row), the others are narrow (3 column tiles); wide and narrow entries of a start frame are different groups, so a
+// chunk is one or the other.  The points of a start frame come sorted by length (ps_list), so its wide entries are a prefix;
+// the lines of a start frame are dealt in two passes.  point_nobs / ln_nobs are only read when narrow_frames > 0.
 // Returns the number of entries or -1 when a table is too small.
 inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL, const int* ln_start, int maxKS, int* tab,
-                             int* wave, int NWV) {
+                             int* wave, int NWV, const int* point_nobs = nullptr, const int* ln_nobs = nullptr, int narrow_frames = 0) {
   std::vector<int> grp, wgt;
   int nks = 0;
+  const bool mixed = narrow_frames > 0;
   auto push = [&](int g, const int* id) {
     if (nks >= maxKS) return false;
     tab[4 * nks] = g; tab[4 * nks + 1] = id[0] | id[1] << 16; tab[4 * nks + 2] = id[2] | id[3] << 16; tab[4 * nks + 3] = 0;
     grp.push_back(g);
-    wgt.push_back((g & 32) ? 4 : 1);
+    // weight = matrix-core instructions of the entry, up to a factor: 6 tiles narrow, 15 wide (x 4 K-steps for lines)
+    wgt.push_back(((g & 32) ? 4 : 1) * (mixed ? ((g & 64) ? 5 : 2) : 1));
     ++nks;
     return true;
   };
@@ -196,21 +203,28 @@ inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL,
   for (int f = 0; f < NF; ++f)
     for (int q = cnt[f]; q < cnt[f + 1]; q += 4) {
       int id[4];
-      for (int i = 0; i < 4; ++i) id[i] = q + i < cnt[f + 1] ? ps_list[q + i] : 0xffff;
-      if (!push(f, id)) return -1;
-    }
-  for (int f = 0; f < NF; ++f) {
-    int id[4], n = 0;
-    for (int l = 0; l < nL; ++l)
-      if (ln_start[l] == f) {
-        id[n++] = l;
-        if (n == 4) { if (!push(32 | f, id)) return -1; n = 0; }
+      bool wide = false;
+      for (int i = 0; i < 4; ++i) {
+        id[i] = q + i < cnt[f + 1] ? ps_list[q + i] : 0xffff;
+        if (mixed && id[i] != 0xffff && point_nobs[id[i]] > narrow_frames) wide = true;
       }
-    if (n) {
-      for (int i = n; i < 4; ++i) id[i] = 0xffff;
-      if (!push(32 | f, id)) return -1;
+      if (!push(f | (wide ? 64 : 0), id)) return -1;
     }
-  }
+  for (int f = 0; f < NF; ++f)
+    for (int pass = mixed ? 0 : 1; pass < 2; ++pass) {   // pass 0: the long tracks of the start frame (mixed only)
+      int id[4], n = 0;
+      const int g = 32 | f | (pass == 0 ? 64 : 0);
+      for (int l = 0; l < nL; ++l) {
+        if (ln_start[l] != f) continue;
+        if (mixed && (ln_nobs[l] > narrow_frames) != (pass == 0)) continue;
+        id[n++] = l;
+        if (n == 4) { if (!push(g, id)) return -1; n = 0; }
+      }
+      if (n) {
+        for (int i = n; i < 4; ++i) id[i] = 0xffff;
+        if (!push(g, id)) return -1;
+      }
+    }
   // Chunks: a group, or a piece of one when the group is heavier than a wave's fair share.  A chunk is worked by ONE wave
   // and ends with ONE add into the shared system; chunks go to the waves longest-first onto the least loaded wave.
   std::vector<long> pre(nks + 1, 0);

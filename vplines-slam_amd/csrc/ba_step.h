@@ -51,8 +51,134 @@ __device__ __forceinline__ int compact2vis(int c, int s, int WS) {
 // shape): 6 lower tiles = 48 accumulator registers per lane; NTC = 5 covers every track length (15 tiles).
 constexpr int CSQ_LD = 80;                   // row stride of the compact system in k_schur's LDS
 constexpr int CSQ_N = 74 * CSQ_LD + 32;      // (+ slack: adds of exact zeros for frame slots past the window land behind a row's end)
-template <int NTC>
+// A WIDE chunk of k_schur_mixed (entries that hold a track of more than SCHUR_NARROW_FRAMES frames), out of line: its
+// register allocation is its own, the narrow product loop of the caller keeps its zero scratch.
+struct SchurWide {
+  const int4* etab;
+  const double *Wp, *Wl;
+  int WS;
+  const double *lC, *lS, *lE, *lG, *pS, *pE, *pG;
+  double* Cacc;
+  int* tick;
+};
+__device__ __noinline__ void schur_wide_chunk(const SchurWide& A, const int k0, const int k1, const int seq) {
+  const int lane = threadIdx.x & 63, m = lane & 15, kk = lane >> 4;
+  const int4* etab = A.etab;
+  const double *Wp = A.Wp, *Wl = A.Wl, *lC = A.lC, *lS = A.lS, *lE = A.lE, *lG = A.lG, *pS = A.pS, *pE = A.pE, *pG = A.pG;
+  double* Cacc = A.Cacc;
+  int* tick = A.tick;
+  const int WS = A.WS;
+  auto fetch = [&](int k) {
+    int4 e = etab[k];
+    e.x = __builtin_amdgcn_readfirstlane(e.x); e.y = __builtin_amdgcn_readfirstlane(e.y); e.z = __builtin_amdgcn_readfirstlane(e.z);
+    return e;
+  };
+  auto lm_id = [&](const int4 e) { return ((kk & 2 ? e.z : e.y) >> (16 * (kk & 1))) & 0xffff; };
+  {
+        // ---- a WIDE chunk: all NTW = 5 column tiles of the WS + 2 columns, ONE ROW OF TILES PER PASS over the chunk's entries
+        // (pass ta: tiles (ta, 0 .. 4), the A operand is column tile ta, loaded as a sixth column): 5 accumulator tiles, 6
+        // raw and 6 transformed columns = fewer registers than the narrow product loop, which therefore keeps its zero
+        // scratch (all 15 tiles at once: 1.2 KB of scratch per lane for the whole kernel).  Wide chunks are the few entries
+        // with long tracks; their rows are read five times.  Flush targets by arithmetic (no second 15 KB table in LDS).
+        // The ticket is taken at the first pass's adds and passed on after the last's.
+        constexpr int NTW = 5;
+        const int sfr = fetch(k0).x & 15, s6 = 6 * sfr;
+#pragma unroll 1
+        for (int ta = 0; ta < NTW && 16 * ta < WS + 2; ++ta) {
+          v4d accw[NTW];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) accw[t] = v4d{0, 0, 0, 0};
+          auto col_of = [&](int t) { return 16 * (t < NTW ? t : ta) + m; };
+          auto load_w = [&](const int4 e, double (&raw)[NTW + 1][4]) {
+            const bool isl = (e.x & 32) != 0;
+            const int idr = lm_id(e);
+            const int id = idr != 0xffff ? idr : 0;
+            const double* row = isl ? Wl + (unsigned)(id * 4 * WS) : Wp + (unsigned)(id * WS);
+#pragma unroll
+            for (int t = 0; t <= NTW; ++t) {
+              const int c = min(col_of(t), WS - 1);
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) raw[t][qd] = (qd == 0 || isl) ? row[(unsigned)((isl ? qd * WS : 0) + c)] : 0.0;
+            }
+          };
+          auto xform_w = [&](const int4 e, const double (&raw)[NTW + 1][4], double (&x)[NTW + 1][4]) {
+            const bool isl = (e.x & 32) != 0;
+            const int idr = lm_id(e);
+            const int id = idr != 0xffff ? idr : 0;
+            const double pm = idr != 0xffff ? 1.0 : 0.0;
+            double s4[4] = {0, 0, 0, 0}, ev[4] = {0, 0, 0, 0}, gv[4] = {0, 0, 0, 0};
+            double c10 = 0, c20 = 0, c21 = 0, c30 = 0, c31 = 0, c32 = 0;
+            if (isl) {
+              const double* C = lC + id * 10;
+#pragma unroll
+              for (int a = 0; a < 4; ++a) { s4[a] = lS[4 * id + a] * pm; ev[a] = lE[4 * id + a] * pm; gv[a] = lG[4 * id + a] * pm; }
+              c10 = C[1]; c20 = C[3]; c21 = C[4]; c30 = C[6]; c31 = C[7]; c32 = C[8];
+            } else {
+              s4[0] = pS[id] * pm; ev[0] = pE[id] * pm; gv[0] = pG[id] * pm;
+            }
+#pragma unroll
+            for (int t = 0; t <= NTW; ++t) {
+              const int c = col_of(t);
+              const double wmv = c < WS ? 1.0 : 0.0, gmv = c == WS ? 1.0 : 0.0, emv = c == WS + 1 ? 1.0 : 0.0;
+              // (same operations per element as the table-driven path: s * raw first, the triangular solve for the lines)
+              const double x0 = s4[0] * raw[t][0];
+              const double x1 = s4[1] * raw[t][1] - c10 * x0;
+              const double x2 = s4[2] * raw[t][2] - c20 * x0 - c21 * x1;
+              const double x3 = s4[3] * raw[t][3] - c30 * x0 - c31 * x1 - c32 * x2;
+              x[t][0] = x0 * wmv + gv[0] * gmv + ev[0] * emv;
+              x[t][1] = isl ? x1 * wmv + gv[1] * gmv + ev[1] * emv : 0.0;
+              x[t][2] = isl ? x2 * wmv + gv[2] * gmv + ev[2] * emv : 0.0;
+              x[t][3] = isl ? x3 * wmv + gv[3] * gmv + ev[3] * emv : 0.0;
+            }
+          };
+          double rw[NTW + 1][4];
+          load_w(fetch(k0), rw);
+#pragma unroll 1
+          for (int k = k0; k < k1; ++k) {
+            const int4 e = fetch(k);
+            double x[NTW + 1][4];
+            xform_w(e, rw, x);
+            load_w(fetch(min(k + 1, k1 - 1)), rw);
+            const bool isl = (e.x & 32) != 0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              if (a == 0 || isl) {
+#pragma unroll
+                for (int tb = 0; tb < NTW; ++tb) accw[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[NTW][a], x[tb][a], accw[tb], 0, 0, 0);
+              }
+            }
+          }
+          if (ta == 0) lds_ticket_wait(&tick[0], seq);
+#pragma unroll
+          for (int tb = 0; tb < NTW; ++tb) {
+            const double vals[4] = {accw[tb].x, accw[tb].y, accw[tb].z, accw[tb].w};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int ca = 16 * ta + kk + 4 * v, cb = 16 * tb + m;
+              if (tb <= ta && ca >= cb && ca < WS + 2 && cb < WS) {
+                const int a0 = compact2vis(ca, 0, WS), b0 = compact2vis(cb, 0, WS);
+                const int stp = (ca < WS - 6 ? CSQ_LD : 0) + (cb < WS - 6 ? 1 : 0);
+                // columns of frames past the window (6 s + c >= 66) hold exact zeros: kept out of the square
+                const bool in_a = ca >= WS - 6 || s6 + ca < 66, in_b = cb >= WS - 6 || s6 + cb < 66;
+                if (in_a && in_b) lds_add(&Cacc[a0 * CSQ_LD + b0 + s6 * stp], vals[v]);
+              }
+            }
+          }
+        }
+        lds_ticket_pass(&tick[0], seq, lane);
+  }
+}
+
+// MIXED (round 4; NTC = 3): the batch holds tracks of more than SCHUR_NARROW_FRAMES frames, so the compact rows in HBM are WS > 42
+// doubles wide -- but most entries still hold 6-frame tracks only.  Their chunks run the 3-tile product in a NARROW VIEW of the
+// row (the 36 pose columns of frames s .. s + 5, then the extrinsic block found at memory column WS - 6, g, e: 44 columns);
+// the chunks the host flagged wide (bit 6 of the group) run all 15 tiles of the WS + 2 columns.  Before, one long track in the
+// batch sent every entry through k_schur<5>: 120 accumulator + 120 prefetch registers (spills), 86 KB of LDS (one work-group
+// per CU), 5 x the time.
+constexpr int SCHUR_NARROW_FRAMES = 6;
+template <int NTC, bool MIXED = false>
 __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, double* sm) {
+  static_assert(!MIXED || NTC == 3, "the narrow view is three column tiles");
   constexpr int NLT = NTC * (NTC + 1) / 2;
   const int tid = threadIdx.x, T = SCHUR_THREADS;
   const int lane = tid & 63, wv = tid >> 6;
@@ -61,6 +187,9 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
   count_active(B, 1);
   const int nP = B.nP[w], nL = B.nL[w];
   const int WS = B.WS;
+  // the view the table-driven product works in: logical row width WSv, memory column of logical column c >= WSv - 6 is c + coff
+  const int WSv = MIXED ? 6 * SCHUR_NARROW_FRAMES + 6 : WS;
+  const int coff = WS - WSv;
   const int r1 = max(4 * B.maxP + 28 * B.maxL, CSQ_N);
   double* kP = sm;                          // nP x 4: s, d, g, H_pp            (scaling -> landmark constants)
   double* kL = sm + 4 * B.maxP;             // nL x 28: s(4), d(4), g(4), H_ll(16)
@@ -278,9 +407,9 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
     tri_decode(t, ta, tb);
     const int ca = 16 * ta + (ln >> 4) + 4 * v, cb = 16 * tb + (ln & 15);
     int code = -1;
-    if (ca >= cb && ca < WS + 2 && cb < WS) {
-      const int a0 = compact2vis(ca, 0, WS), b0 = compact2vis(cb, 0, WS);
-      const int step = (ca < WS - 6 ? CSQ_LD : 0) + (cb < WS - 6 ? 1 : 0);
+    if (ca >= cb && ca < WSv + 2 && cb < WSv) {
+      const int a0 = compact2vis(ca, 0, WSv), b0 = compact2vis(cb, 0, WSv);
+      const int step = (ca < WSv - 6 ? CSQ_LD : 0) + (cb < WSv - 6 ? 1 : 0);
       code = (a0 * CSQ_LD + b0) | step << 16;
     }
     ftab[i] = code;
@@ -322,10 +451,10 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
       const int c = 16 * t + m;
-      wm[t] = c < WS ? 1.0 : 0.0;
-      gm[t] = c == WS ? 1.0 : 0.0;
-      em[t] = c == WS + 1 ? 1.0 : 0.0;
-      cl[t] = c < WS ? c : WS - 1;
+      wm[t] = c < WSv ? 1.0 : 0.0;
+      gm[t] = c == WSv ? 1.0 : 0.0;
+      em[t] = c == WSv + 1 ? 1.0 : 0.0;
+      cl[t] = c < WSv - 6 ? c : (c < WSv ? c + coff : WS - 1);
     }
     // A table entry is four landmarks of one start frame: four points = ONE K-step, four lines = FOUR K-steps (K-step a takes
     // row a of each line).  The lane (kk, m) works on landmark kk of the entry: a point lane loads one value per column tile,
@@ -424,6 +553,13 @@ __device__ __forceinline__ void schur_body(const DevBatch& B, const int w, doubl
       const int k1 = __builtin_amdgcn_readlane(wrow, __builtin_amdgcn_readfirstlane(2 + 3 * ch));
       const int seq = __builtin_amdgcn_readlane(wrow, __builtin_amdgcn_readfirstlane(3 + 3 * ch));
       nent += k1 - k0;
+      if (MIXED && (fetch(k0).x & 64)) {   // a WIDE chunk: out of line, with a register allocation of its own
+        SchurWide A;
+        A.etab = etab; A.Wp = Wp; A.Wl = Wl; A.WS = WS; A.lC = lC; A.lS = lS; A.lE = lE; A.lG = lG; A.pS = pS; A.pE = pE; A.pG = pG;
+        A.Cacc = Cacc; A.tick = tick;
+        schur_wide_chunk(A, k0, k1, seq);
+        continue;
+      }
       double raw0[NTC][4], raw1[NTC][4], raw2[NTC][4];
       constexpr int NPF = 3;
       load_raw(fetch(k0), raw0);
@@ -503,6 +639,11 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur(DevBatch B) {
   // the list k_cost of THIS iteration fills is emptied here (k_cost runs after this whole kernel)
   if (blockIdx.x == 0 && threadIdx.x == 0) { B.ord_cnt[2 * ((B.ord_it + 1) & 1)] = 0; B.ord_cnt[2 * ((B.ord_it + 1) & 1) + 1] = 0; }
   schur_body<NTC>(B, ordered_window(B), sm);
+}
+__global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_mixed(DevBatch B) {
+  extern __shared__ double sm[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { B.ord_cnt[2 * ((B.ord_it + 1) & 1)] = 0; B.ord_cnt[2 * ((B.ord_it + 1) & 1) + 1] = 0; }
+  schur_body<3, true>(B, ordered_window(B), sm);
 }
 inline size_t schur_smem(int maxP, int maxL, int ntc = 5) {
   const int r1 = std::max(4 * maxP + 28 * maxL, (int)CSQ_N);

@@ -163,6 +163,7 @@ struct vpl_ctx {
   unsigned long long layout_sig = 0;
   bool layout_valid = false;
   bool force_general = false;                    // VPL_BA_GENERAL=1: every window takes k_solve (A/B runs, tests of the general path)
+  bool schur_wide_all = false;                   // VPL_BA_SCHUR_WIDE=1: round 3's k_schur<5> for batches with long tracks (A/B runs, tests)
   std::vector<std::string> kname_store;
   // host-side marg structure of the uploaded windows
   std::vector<int> h_mg_m;
@@ -454,6 +455,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   if (schur_max > 159 * 1024 || back_max > 159 * 1024) { for (void* p : c->allocs) hipFree(p); delete c; return VPL_E_CAPACITY; }
   hipFuncSetAttribute((const void*)k_schur<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_max);
   hipFuncSetAttribute((const void*)k_schur<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_max);
+  hipFuncSetAttribute((const void*)k_schur_mixed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_max);
   hipFuncSetAttribute((const void*)k_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_SMEM);
   hipFuncSetAttribute((const void*)k_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)back_max);
   hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SMEM);
@@ -463,6 +465,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   vpl_ba_default_options(&c->opt);
   if (const char* gv = std::getenv("VPL_BA_GRAPH")) c->use_graph = std::atoi(gv) != 0;
   if (const char* gv = std::getenv("VPL_BA_GENERAL")) c->force_general = std::atoi(gv) != 0;
+  if (const char* gv = std::getenv("VPL_BA_SCHUR_WIDE")) c->schur_wide_all = std::atoi(gv) != 0;
   *out = c;
   return VPL_OK;
 }
@@ -874,8 +877,10 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     if (!same_layout) {   // K-steps of k_schur: landmark rows by start frame, dealt to the waves, flush tickets (ba_pack.h)
       int cnt[NF + 1];
       for (int f = 0; f <= NF; ++f) cnt[f] = ps_cnt[w * (NF + 1) + f];
+      // rows wider than the 6-frame view of k_schur<3>: entries with a longer track are flagged wide (k_schur_mixed)
       if (pack_schur_ksteps(v.n_points, &ps_list[w * B.maxP], cnt, nl, &ln_start[w * B.maxL], B.maxKS, &sk_tab[w * B.maxKS * 4],
-                            &sk_wave[w * 8 * SK_WSTRIDE], SCHUR_THREADS / 64) < 0)
+                            &sk_wave[w * 8 * SK_WSTRIDE], SCHUR_THREADS / 64, v.point_nobs, &ln_nobs[w * B.maxL],
+                            B.WS + 2 > 48 ? SCHUR_NARROW_FRAMES : 0) < 0)
         return fail(c, VPL_E_CAPACITY, "K-step table of the landmark elimination too small");
     }
     if (!same_layout) {   // lane layout of the line phase: llNLW whole tracks per wave, k-major; tracks in the caller's order (tracks that start
@@ -1332,7 +1337,9 @@ static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
     // back-substitution + dogleg + candidate.
     { KTimer t(c, "k_schur");
       if (B.WS + 2 <= 48) hipLaunchKernelGGL(k_schur<3>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 3), s, B);
-      else hipLaunchKernelGGL(k_schur<5>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 5), s, B); }
+      else if (c->schur_wide_all) hipLaunchKernelGGL(k_schur<5>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 5), s, B);
+      // rows wider than 6 frames: narrow view for the entries of short tracks, all tiles for the flagged ones (round 4)
+      else hipLaunchKernelGGL(k_schur_mixed, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 3), s, B); }
     ++B.launch;
     { KTimer t(c, "k_chol"); hipLaunchKernelGGL(k_chol, grid, dim3(CHOL_THREADS), CHOL_SMEM, s, B); }
     ++B.launch;

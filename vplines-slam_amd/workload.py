@@ -163,3 +163,65 @@ def primed_batch(ctx, global_ids, cfg, opt, config_id=3):
     for i, b in enumerate(B):
         b.prior = keep[i]
     return B, keep
+
+
+def graft_long_tracks(seed, cfg, t_start, every=10):
+    """The window generate(seed, cfg, t_start) with every `every`-th point track replaced by a track that starts in frame 0
+    and is observed in all 11 frames (the same seed generated with track_len = 11: same trajectory, IMU samples and initial
+    states).  With 6-frame tracks only, the frame that leaves is tied to poses 1..5 and the prior stays at 45 dims however
+    long the chain; a live tracker keeps some features over the whole window, every pose enters the prior and stays:
+    n = 75 = 10 poses + speed/bias 1 + extrinsic, the reference's steady state."""
+    w = generate(seed, cfg, t_start)
+    c11 = Config()
+    C.memmove(C.byref(c11), C.byref(cfg), C.sizeof(c11))
+    c11.track_len = NF
+    wl = generate(seed, c11, t_start)
+    assert np.array_equal(w.pose, wl.pose) and np.array_equal(w.extra["imu_samples"], wl.extra["imu_samples"])
+    P = len(w.point_nobs)
+    off = np.concatenate([[0], np.cumsum(w.point_nobs)])
+    offl = np.concatenate([[0], np.cumsum(wl.point_nobs)])
+    start, nobs, invd, obs = w.point_start.copy(), w.point_nobs.copy(), w.inv_depth.copy(), []
+    for k in range(P):
+        if k % every == 0:
+            start[k], nobs[k], invd[k] = wl.point_start[k], wl.point_nobs[k], wl.inv_depth[k]
+            obs.append(wl.point_obs[offl[k]:offl[k + 1]])
+        else:
+            obs.append(w.point_obs[off[k]:off[k + 1]])
+    r = Window(w.pose, w.speed_bias, w.ex_pose, start, nobs, np.concatenate(obs) if obs else w.point_obs[:0], invd,
+               w.line_start, w.line_nobs, w.line_obs, w.line_plk)
+    r.extra = dict(w.extra)
+    return r
+
+
+def steady_point_obs(cfg, every=10):
+    """point observations of one graft_long_tracks window"""
+    P = cfg.n_points
+    nlong = (P + every - 1) // every
+    return (P - nlong) * cfg.track_len + nlong * NF
+
+
+def steady_batch(ctx, global_ids, cfg, opt, config_id=3, chain=7, every=10):
+    """The timed windows of `global_ids` (seeds and times of primed_batch's B windows) with a tenth of their point tracks
+    living through the whole window (graft_long_tracks), behind a chain of `chain` preceding windows of the same kind one
+    keyframe apart, the prior handed from solve to solve on the device (vpl_ba_upload_chained).  Prior in AND prior out then
+    have the reference's steady-state size n = 75 (marginalization_factor.cpp:177-363) instead of the 45 dims that 6-frame
+    tracks leave.  The context needs max_point_obs >= steady_point_obs(cfg).  B is uploaded (chained) when this returns:
+    reset_state + solve re-run it.  Returns (B, n_prior)."""
+    from . import shard
+    seeds = [shard.window_seeds(config_id, g) for g in global_ids]
+    B = [graft_long_tracks(sb, cfg, t + cfg.kf_dt, every) for (sa, sb, t) in seeds]
+    chains = [[graft_long_tracks(seed_for(config_id, (1 << 18) + chain * g + k), cfg, t + cfg.kf_dt - (chain - k) * cfg.kf_dt, every)
+               for (g, (sa, sb, t)) in zip(global_ids, seeds)] for k in range(chain)]
+    allw = [w for step in chains for w in step] + B
+    # IntegrationBase of every interval on the device, in pieces
+    for i in range(0, len(allw), 2048):
+        piece = allw[i:i + 2048]
+        set_preintegrations(piece, ctx.preintegrate(*imu_batch_arrays(piece), opt))
+    for k, step in enumerate(chains):
+        ctx.upload(step, opt, chained=k > 0)
+        ctx.solve()
+        ctx.synchronize()
+    _, rep = ctx.download()
+    n_prior = int(round(sum(rep[i].prior_n for i in range(len(B))) / max(1, len(B))))
+    ctx.upload(B, opt, chained=True)
+    return B, n_prior
