@@ -51,7 +51,11 @@ def test_window_solve_parity_no_prior(gpu_ctx, P, L, vp):
         assert rep_g[i].iterations == rep_c.iterations
         assert rep_g[i].num_successful_steps == rep_c.num_successful_steps
         assert abs(rep_g[i].initial_cost - rep_c.initial_cost) <= 1e-9 * rep_c.initial_cost
-        assert abs(rep_g[i].final_cost - rep_c.final_cost) <= 1e-4 * max(1.0, rep_c.final_cost)
+        # measured (tools/parity_report.py, 20 windows of these shapes, round 4): <= 7e-7 relative on 19 of them, 2.2e-5 on one
+        # (points + lines without VP, cost 2121.04 vs 2120.99 with poses 2e-8 m apart: the cost of a 5-iteration solve that has
+        # not converged amplifies rounding-level differences of the weakly observed line directions); the
+        # accumulation is deterministic, so this is not noise of the device -- but it is what the bar has to allow
+        assert abs(rep_g[i].final_cost - rep_c.final_cost) <= 5e-5 * max(1.0, rep_c.final_cost)
         dp, dr = pose_err(wg[i], wc[i])
         assert dp <= POS_TOL and dr <= ROT_TOL, (dp, dr)
         assert np.abs(wg[i].speed_bias - wc[i].speed_bias).max() < 1e-4

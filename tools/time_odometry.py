@@ -9,10 +9,11 @@ opt = v.default_options()
 M = T.Measurements(T.NF + T.N_KEYFRAMES)
 ctx = T._ctx()
 be = T.Backend(ctx)
-acc = {"solve_odometry": [], "slide": []}
+acc = {"solve_odometry": [], "slide": [], "solve_odometry_c_call": []}
 so, sl = be.solve_odometry, be.slide
 def t_so(w, o):
-    t = time.perf_counter(); r = so(w, o); acc["solve_odometry"].append(time.perf_counter() - t); return r
+    t = time.perf_counter(); r = so(w, o); acc["solve_odometry"].append(time.perf_counter() - t)
+    acc["solve_odometry_c_call"].append(ctx.last_call_s); return r
 def t_sl(w, o):
     t = time.perf_counter(); r = sl(w, o); acc["slide"].append(time.perf_counter() - t); return r
 be.solve_odometry, be.slide = t_so, t_sl

@@ -1,5 +1,6 @@
 """ctypes bindings of include/vplines_ba.h (the C ABI of the HIP library)."""
 import ctypes as C
+import time
 import os
 
 import numpy as np
@@ -409,7 +410,10 @@ class Context:
         priors = (Prior * n)()
         lreps = (SolveReport * n)()
         reps = (SolveReport * n)()
-        self._check(self.lib.vpl_ba_solve_odometry(self.h, n, cw, C.byref(opt), init_depth, priors, lreps, reps), "vpl_ba_solve_odometry")
+        t0 = time.perf_counter()
+        rc = self.lib.vpl_ba_solve_odometry(self.h, n, cw, C.byref(opt), init_depth, priors, lreps, reps)
+        self.last_call_s = time.perf_counter() - t0      # the C call alone (tools/time_odometry.py)
+        self._check(rc, "vpl_ba_solve_odometry")
         for i, w in enumerate(windows):
             w.from_c(cw[i])
         return priors, lreps, reps
