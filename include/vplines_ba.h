@@ -313,6 +313,9 @@ int vpl_ba_only_line_opt(vpl_ctx* ctx, int n_windows, vpl_window* windows, const
  * and the kernels' layout tables are built on the host from that set. */
 int vpl_ba_solve_odometry(vpl_ctx* ctx, int n_windows, vpl_window* windows, const vpl_ba_options* opt, double init_depth,
                           vpl_prior* priors_out, vpl_solve_report* line_reports, vpl_solve_report* reports);
+/* wall clock of the three stages of the context's last vpl_ba_solve_odometry, in ms: the two triangulations | onlyLineOpt |
+ * optimizationwithLine (tools/time_odometry.py) */
+int vpl_ba_debug_odometry_ms(vpl_ctx* ctx, double* ms3);
 
 /* ---- asynchronous variants of the five entry points above -------------------------------------------------------------- *
  * Same arguments, same results, but the call returns as soon as its uploads, kernels and read-backs are ENQUEUED on the

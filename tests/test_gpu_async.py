@@ -140,6 +140,31 @@ def test_solve_odometry_is_the_four_stages_back_to_back_and_matches_the_oracle(g
         assert rep_a[i].iterations == rep_b[i].iterations and rep_a[i].final_cost == rep_b[i].final_cost
         assert lrep_a[i].iterations == lrep_b[i].iterations and lrep_a[i].n_lines_removed == lrep_b[i].n_lines_removed
         assert np.array_equal(pri_a[i].J(), pri_b[i].J())
+    # a window in which onlyLineOpt erases nothing is solved where the line stage left the batch (no third upload, round 4);
+    # one in which it does is uploaded again.  One window per call, both kinds, against the stages one by one.
+    kinds = set()
+    for i in range(4):
+        wq, _ = make(1300 + i, L=40, P=60, sigma_px=0.1 if i < 3 else 0.5, pose_noise=(i == 3), t=0.2 * i)
+        wq.inv_depth[i % 4::4] = -1.0
+        wq.line_triangulated[:] = 1
+        wq.line_removed[:] = 0
+        if i == 3:
+            wq.line_plk += np.random.default_rng(5).normal(0, 0.01, wq.line_plk.shape) * np.abs(wq.line_plk)
+        x, y = wq.copy(), wq.copy()
+        pri_x, lrep_x, rep_x = gpu_ctx.solve_odometry([x], opt, 5.0)
+        gpu_ctx.triangulate_points([y], 5.0)
+        gpu_ctx.triangulate_lines([y])
+        lrep_y = gpu_ctx.only_line_opt([y], opt)
+        y.line_triangulated[y.line_removed[:len(y.line_triangulated)] != 0] = 0
+        pri_y, rep_y = gpu_ctx.solve_windows([y], opt)
+        kinds.add(lrep_y[0].n_lines_removed == 0)
+        assert np.array_equal(x.pose, y.pose) and np.array_equal(x.speed_bias, y.speed_bias), i
+        assert np.array_equal(x.inv_depth, y.inv_depth) and np.array_equal(x.line_plk, y.line_plk), i
+        assert np.array_equal(x.line_triangulated, y.line_triangulated) and np.array_equal(x.line_removed, y.line_removed)
+        assert rep_x[0].iterations == rep_y[0].iterations and rep_x[0].final_cost == rep_y[0].final_cost
+        assert lrep_x[0].n_lines_removed == lrep_y[0].n_lines_removed
+        assert np.array_equal(pri_x[0].J(), pri_y[0].J()) and np.array_equal(pri_x[0].r(), pri_y[0].r())
+    assert kinds == {True, False}, "both the resident and the re-upload path should have been taken"
     # the oracle's stages
     for i, w in enumerate(ws):
         c = w.copy()

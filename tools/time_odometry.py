@@ -2,6 +2,7 @@
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ctypes as C
 import numpy as np
 import vplines_slam_amd as v
 import test_gpu_sequence as T
@@ -13,7 +14,12 @@ acc = {"solve_odometry": [], "slide": [], "solve_odometry_c_call": []}
 so, sl = be.solve_odometry, be.slide
 def t_so(w, o):
     t = time.perf_counter(); r = so(w, o); acc["solve_odometry"].append(time.perf_counter() - t)
-    acc["solve_odometry_c_call"].append(ctx.last_call_s); return r
+    acc["solve_odometry_c_call"].append(ctx.last_call_s)
+    ms3 = (C.c_double * 3)()
+    ctx.lib.vpl_ba_debug_odometry_ms(ctx.h, ms3)
+    for k, nm in enumerate(("stage_triangulate", "stage_only_line_opt", "stage_solve")):
+        acc.setdefault(nm, []).append(ms3[k] * 1e-3)
+    return r
 def t_sl(w, o):
     t = time.perf_counter(); r = sl(w, o); acc["slide"].append(time.perf_counter() - t); return r
 be.solve_odometry, be.slide = t_so, t_sl

@@ -186,7 +186,8 @@ inline bool point_unit_chains_finish(const int* st, const PointUnitLayout& L, bo
 // the lines of a start frame are dealt in two passes.  point_nobs / ln_nobs are only read when narrow_frames > 0.
 // Returns the number of entries or -1 when a table is too small.
 inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL, const int* ln_start, int maxKS, int* tab,
-                             int* wave, int NWV, const int* point_nobs = nullptr, const int* ln_nobs = nullptr, int narrow_frames = 0) {
+                             int* wave, int NWV, const int* point_nobs = nullptr, const int* ln_nobs = nullptr, int narrow_frames = 0,
+                             long* wide_weight = nullptr, long* total_weight = nullptr) {
   std::vector<int> grp, wgt;
   int nks = 0;
   const bool mixed = narrow_frames > 0;
@@ -230,6 +231,9 @@ inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL,
   std::vector<long> pre(nks + 1, 0);
   for (int k = 0; k < nks; ++k) pre[k + 1] = pre[k] + wgt[k];
   const long total = pre[nks];
+  if (total_weight) *total_weight += total;
+  if (wide_weight)
+    for (int k = 0; k < nks; ++k) if (grp[k] & 64) *wide_weight += wgt[k];
   const long fair = std::max(1L, (total + NWV - 1) / NWV);
   struct Chunk { int k0, k1; long w; };
   std::vector<Chunk> chunks;

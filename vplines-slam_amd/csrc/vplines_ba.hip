@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <cmath>
 #include <cstdio>
@@ -163,6 +164,7 @@ struct vpl_ctx {
   unsigned long long layout_sig = 0;
   bool layout_valid = false;
   bool force_general = false;                    // VPL_BA_GENERAL=1: every window takes k_solve (A/B runs, tests of the general path)
+  bool schur_mostly_wide = false;                // more than 35 % of the landmark elimination's weight sits in wide entries: k_schur<5>
   bool schur_wide_all = false;                   // VPL_BA_SCHUR_WIDE=1: round 3's k_schur<5> for batches with long tracks (A/B runs, tests)
   std::vector<std::string> kname_store;
   // host-side marg structure of the uploaded windows
@@ -181,6 +183,7 @@ struct vpl_ctx {
   std::function<int()> pending;
   bool prior_resident = false;                   // the last solve / marginalisation of the uploaded batch left its priors in mg_* (vpl_ba_upload_chained)
   int prior_resident_nW = 0;
+  double odo_ms[3] = {0, 0, 0};                  // vpl_ba_debug_odometry_ms
   Stage stage;                                   // pinned + device staging arenas of upload / download
   std::vector<int> h_mg_n;                       // kept dims of the next prior as the host computed them (>= the device's)
   // device time of the last upload / solve / download (hipEvents on the context's stream), vpl_ctx_enable_leg_timing
@@ -786,6 +789,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     B.wfill = (minTrack != maxTrack || opt->remove_line_outliers) ? 1 : 0;
   }
 
+  long schur_wide_w = 0, schur_total_w = 0;   // matrix-core weight of the wide entries / of all entries of k_schur's table
   bool same_layout = false;
   {
     unsigned long long h = 1469598103934665603ull;
@@ -880,7 +884,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       // rows wider than the 6-frame view of k_schur<3>: entries with a longer track are flagged wide (k_schur_mixed)
       if (pack_schur_ksteps(v.n_points, &ps_list[w * B.maxP], cnt, nl, &ln_start[w * B.maxL], B.maxKS, &sk_tab[w * B.maxKS * 4],
                             &sk_wave[w * 8 * SK_WSTRIDE], SCHUR_THREADS / 64, v.point_nobs, &ln_nobs[w * B.maxL],
-                            B.WS + 2 > 48 ? SCHUR_NARROW_FRAMES : 0) < 0)
+                            B.WS + 2 > 48 ? SCHUR_NARROW_FRAMES : 0, &schur_wide_w, &schur_total_w) < 0)
         return fail(c, VPL_E_CAPACITY, "K-step table of the landmark elimination too small");
     }
     if (!same_layout) {   // lane layout of the line phase: llNLW whole tracks per wave, k-major; tracks in the caller's order (tracks that start
@@ -1047,6 +1051,9 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
     HIPCHK(c, up(c, B.mg_m, mm));
   }
   c->h_mg_n.assign(mg_n.begin(), mg_n.end());
+  // k_schur_mixed pays five passes over the rows of a wide entry: measured (tools/bench_tracks.py, 512 windows) 0.52 ms per step
+  // with a tenth of the point tracks long, 3.2 ms with every track long, against 1.5 - 1.65 ms of k_schur<5> either way
+  if (!same_layout) c->schur_mostly_wide = schur_total_w > 0 && 20 * schur_wide_w > 7 * schur_total_w;
   if (c->force_general) std::fill(path.begin(), path.end(), 1);
   HIPCHK(c, up(c, B.path, path));
   // ONE host-to-device copy of the arena, ONE kernel that scatters its pieces into the batch's arrays
@@ -1260,15 +1267,21 @@ int vpl_ba_triangulate_points_async(vpl_ctx* c, int nW, vpl_window* win, double 
 
 // Estimator::onlyLineOpt for a batch: upload (triangulated lines), k_prep (world orth of the lines), k_line_opt (the LM
 // loop), k_gauge (setLineOrth + removeLineOutlier; the gauge transform is the identity, the poses did not move)
-static int only_line_opt_impl(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt_in, vpl_solve_report* reports, bool async) {
+// solve_opt != nullptr (vpl_ba_solve_odometry): the upload is made with the options of the solve that FOLLOWS, so that the
+// batch -- layout tables, observations, prior, kept-block tables -- can stay where it is for that solve when onlyLineOpt
+// erases no line; the line kernels run on a copy of the batch descriptor with onlyLineOpt's own flags.
+static int only_line_opt_impl(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_options* opt_in, vpl_solve_report* reports, bool async,
+                              const vpl_ba_options* solve_opt = nullptr) {
   if (!c || !win || !opt_in || nW < 1) return VPL_E_INVALID;
   if (c->maxL > LOPT_THREADS) return fail(c, VPL_E_CAPACITY, "onlyLineOpt handles at most 256 lines per window");
   vpl_ba_options opt = *opt_in;
   opt.marginalization_flag = VPL_MARGIN_NONE;
   opt.remove_line_outliers = 1;          // f_manager.removeLineOutlier at the end of onlyLineOpt (estimator.cpp:1037)
-  int rc = upload_impl(c, nW, win, &opt, false);
+  int rc = upload_impl(c, nW, win, solve_opt ? solve_opt : &opt, false);
   if (rc) return rc;
-  DevBatch& B = c->B;
+  DevBatch B = c->B;
+  B.opt.marginalization_flag = opt.marginalization_flag;
+  B.opt.remove_line_outliers = opt.remove_line_outliers;
   const dim3 grid(nW);
   hipStream_t s = c->stream;
   { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(PREP_THREADS), prep_smem(c->maxPriorN), s, B, std::min(c->maxPriorN, PREP_NMAX)); }
@@ -1337,7 +1350,7 @@ static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
     // back-substitution + dogleg + candidate.
     { KTimer t(c, "k_schur");
       if (B.WS + 2 <= 48) hipLaunchKernelGGL(k_schur<3>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 3), s, B);
-      else if (c->schur_wide_all) hipLaunchKernelGGL(k_schur<5>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 5), s, B);
+      else if (c->schur_wide_all || c->schur_mostly_wide) hipLaunchKernelGGL(k_schur<5>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 5), s, B);
       // rows wider than 6 frames: narrow view for the entries of short tracks, all tiles for the flagged ones (round 4)
       else hipLaunchKernelGGL(k_schur_mixed, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 3), s, B); }
     ++B.launch;
@@ -1673,19 +1686,56 @@ int vpl_ba_solve_odometry(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_opti
       if (!win[w].line_triangulated || !win[w].line_removed)
         return fail(c, VPL_E_INVALID, "solve_odometry: line_triangulated and line_removed are required for windows with lines");
     }
+  using oclk = std::chrono::steady_clock;
+  const auto t0 = oclk::now();
   int rc = any_lines ? triangulate_points_and_lines(c, nW, win, init_depth) : vpl_ba_triangulate_points(c, nW, win, init_depth);
   if (rc) return rc;
+  const auto t1 = oclk::now();
+  c->odo_ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  c->odo_ms[1] = 0.0;
+  bool batch_resident = false;
   if (any_lines) {
-    rc = vpl_ba_only_line_opt(c, nW, win, opt, line_reports);
+    bool orth_given = false;
+    for (int w = 0; w < nW; ++w) orth_given = orth_given || win[w].line_orth != nullptr;
+    // uploaded with the FINAL solve's options: when no line is erased the same batch is solved where it lies (round 4)
+    rc = only_line_opt_impl(c, nW, win, opt, line_reports, false, (orth_given || std::getenv("VPL_BA_ODO_REUPLOAD")) ? nullptr : opt);
+    c->odo_ms[1] = std::chrono::duration<double, std::milli>(oclk::now() - t1).count();
     if (rc) return rc;
     // f_manager.removeLineOutlier erased these tracks (estimator.cpp:1037): they take no part in the solve
+    bool erased = false;
     for (int w = 0; w < nW; ++w)
       for (int l = 0; l < win[w].n_lines; ++l)
-        if (win[w].line_removed[l]) win[w].line_triangulated[l] = 0;
+        if (win[w].line_removed[l]) { win[w].line_triangulated[l] = 0; erased = true; }
+    batch_resident = !erased && !orth_given && !std::getenv("VPL_BA_ODO_REUPLOAD");
   } else if (line_reports) {
     std::memset(line_reports, 0, sizeof(vpl_solve_report) * (size_t)nW);
   }
-  return vpl_ba_solve_windows(c, nW, win, opt, priors, reports);
+  const auto t2 = oclk::now();
+  if (batch_resident) {
+    // What a fresh upload of the caller's arrays would put on the device is there already: the layout tables, observations,
+    // prior and kept-block tables of this very line set, the optimised Pluecker vectors (the caller's copy was downloaded
+    // from B.plk), and -- after this restore -- the states k_prep re-normalised in place.  Same bits as the four-stage call.
+    DevBatch& B = c->B;
+    const size_t W = nW;
+    HIPCHK(c, hipMemcpyAsync(B.pose, B.pose_0, W * 77 * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B.sb, B.sb_0, W * 99 * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B.ex, B.ex_0, W * 7 * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B.invd, B.invd_0, W * B.maxP * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(B.ln_removed, 0, W * B.maxL * 4, c->stream));
+    rc = vpl_ba_solve(c);
+    if (!rc) rc = vpl_ctx_synchronize(c);
+    if (!rc) rc = vpl_ba_download(c, nW, win, priors, reports);
+  } else {
+    rc = vpl_ba_solve_windows(c, nW, win, opt, priors, reports);
+  }
+  c->odo_ms[2] = std::chrono::duration<double, std::milli>(oclk::now() - t2).count();
+  return rc;
+}
+// wall clock of the three stages of the last vpl_ba_solve_odometry: triangulation | onlyLineOpt | optimizationwithLine (ms)
+int vpl_ba_debug_odometry_ms(vpl_ctx* c, double* ms3) {
+  if (!c || !ms3) return VPL_E_INVALID;
+  for (int k = 0; k < 3; ++k) ms3[k] = c->odo_ms[k];
+  return VPL_OK;
 }
 
 // Debug/test access to the marginalisation invariants (A, b before the final eigen-decomposition),
