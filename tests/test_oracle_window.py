@@ -203,3 +203,26 @@ def test_oracle_failure_occur_restores_last_frame0():
     db = np.linalg.norm(b.pose[5, :3] - b.pose[0, :3])
     assert abs(da - db) < 1e-9
     assert np.abs(b.pose[0, :3] - w.pose[0, :3]).max() < 1e-12
+
+
+def test_long_tracks_give_the_steady_state_prior():
+    """bench.py's steady state: with 6-frame tracks only, the frame that leaves is tied to poses 1..5 and the prior has 45 dims
+    however long the chain; with a tenth of the point tracks living through the whole window every pose is tied to it:
+    n = 75 = 10 poses + speed/bias 1 + extrinsic (marginalization_factor.cpp:177-363), m = 15 + the landmarks of frame 0."""
+    import ctypes as C
+    import vplines_slam_amd as v
+    opt = v.default_options()
+    cfg = v.workload.config(60, 20, True)
+    for graft, want in ((False, 45), (True, 75)):
+        prior = None
+        for k in range(3):
+            seed, t = v.workload.seed_for(3, 7300 + k), 0.2 + k * cfg.kf_dt
+            w = v.workload.graft_long_tracks(seed, cfg, t) if graft else v.workload.generate(seed, cfg, t)
+            o.preintegrate_windows([w], opt)
+            w.prior = prior
+            p, rep = o.solve_window(w, opt)
+            q = v.Prior()
+            C.memmove(C.byref(q), C.byref(p), C.sizeof(q))
+            prior = q
+            assert rep.prior_n == want, (graft, k, rep.prior_n)
+    assert v.workload.steady_point_obs(cfg) == 54 * 6 + 6 * 11

@@ -162,6 +162,7 @@ struct vpl_ctx {
   // the host-built lane / unit / K-step tables and the index arrays already on the device are the right ones and are neither
   // rebuilt nor uploaded again
   unsigned long long layout_sig = 0;
+  std::vector<int> layout_key;                   // the integers the signature was made of (exact comparison on a hash match)
   bool layout_valid = false;
   bool force_general = false;                    // VPL_BA_GENERAL=1: every window takes k_solve (A/B runs, tests of the general path)
   bool schur_mostly_wide = false;                // more than 35 % of the landmark elimination's weight sits in wide entries: k_schur<5>
@@ -803,8 +804,23 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
       if (v.n_lines > 0 && v.line_start && v.line_nobs) { mix(v.line_start, 4 * (size_t)v.n_lines); mix(v.line_nobs, 4 * (size_t)v.n_lines); }
       if (v.n_lines > 0 && v.line_triangulated) mix(v.line_triangulated, 4 * (size_t)v.n_lines);
     }
-    same_layout = c->layout_valid && h == c->layout_sig && std::getenv("VPL_BA_NO_LAYOUT_CACHE") == nullptr;
+    // the hash only finds the candidate; the decision is an exact comparison of the hashed integers (a collision would reuse
+    // lane / unit / K-step tables of another track layout: out-of-range reads -- ADVICE r3)
+    std::vector<int> key;
+    key.reserve(16 + (size_t)W * 8);
+    key.insert(key.end(), hdr, hdr + 8);
+    for (size_t w = 0; w < W; ++w) {
+      const vpl_window& v = win[w];
+      key.push_back(v.n_points); key.push_back(v.n_lines);
+      const bool hp = v.n_points > 0 && v.point_start && v.point_nobs, hl = v.n_lines > 0 && v.line_start && v.line_nobs;
+      key.push_back((hp ? 1 : 0) | (hl ? 2 : 0) | ((v.n_lines > 0 && v.line_triangulated) ? 4 : 0));   // which arrays follow
+      if (hp) { key.insert(key.end(), v.point_start, v.point_start + v.n_points); key.insert(key.end(), v.point_nobs, v.point_nobs + v.n_points); }
+      if (hl) { key.insert(key.end(), v.line_start, v.line_start + v.n_lines); key.insert(key.end(), v.line_nobs, v.line_nobs + v.n_lines); }
+      if (v.n_lines > 0 && v.line_triangulated) key.insert(key.end(), v.line_triangulated, v.line_triangulated + v.n_lines);
+    }
+    same_layout = c->layout_valid && h == c->layout_sig && key == c->layout_key && std::getenv("VPL_BA_NO_LAYOUT_CACHE") == nullptr;
     c->layout_sig = h;
+    c->layout_key.swap(key);
     c->layout_valid = false;       // becomes valid when this upload has gone through
   }
   for (size_t w = 0; w < W; ++w) {

@@ -102,6 +102,9 @@ def gather_states_device(dist, ctx, n_local, total_windows, device):
     cap = max(hi - lo for lo, hi in sizes)
     assert n_local == sizes[rank][1] - sizes[rank][0]
     buf = torch.zeros((cap, STATE_DOUBLES), dtype=torch.float64, device=device)
+    # the zero fill runs on torch's current stream, the pack on the context's: order them explicitly (with a non-default torch
+    # stream or a non-blocking context stream nothing else does -- ADVICE r3)
+    torch.cuda.current_stream(device).synchronize()
     if n_local:
         ctx.pack_states_device(n_local, buf.data_ptr())
         ctx.synchronize()
