@@ -377,7 +377,13 @@ int vpl_edlines_detect_ex(vpl_fe_ctx* c, const vpl_edline_param* p, int smoothed
     FeTimer t(c, "k_ed_blur_grad");
     hipLaunchKernelGGL(k_ed_blur_grad, dim3((c->W + EDB_TW - 1) / EDB_TW, (c->H + EDB_TH - 1) / EDB_TH, c->n), dim3(256), 0, s, B);
   }
-  { FeTimer t(c, "k_ed_anchor"); hipLaunchKernelGGL(k_ed_anchor, dim3(c->n), dim3(1024), 0, s, B); }
+  {
+    FeTimer t(c, "k_ed_anchor");
+    const int nWs = (c->W - 2 + B.scan - 1) / B.scan, nHs = (c->H - 2 + B.scan - 1) / B.scan;
+    const size_t abytes = (size_t)nWs * ((nHs + 31) / 32) * 4;
+    if (abytes > 60 * 1024) return fe_fail(c, VPL_E_CAPACITY, "anchor bitmask exceeds LDS (frame too large for this scanIntervals)");
+    hipLaunchKernelGGL(k_ed_anchor, dim3(c->n), dim3(1024), abytes, s, B);
+  }
   { FeTimer t(c, "k_ed_code"); hipLaunchKernelGGL(k_ed_code, dim3((PX + 255) / 256, c->n), dim3(256), 0, s, B); }
   { FeTimer t(c, "k_ed_route"); hipLaunchKernelGGL(k_ed_route, dim3(c->n), dim3(64 * ED_ROUTE_WAVES), c->routeSmem, s, B); }
   { FeTimer t(c, "k_ed_fit"); hipLaunchKernelGGL(k_ed_fit, dim3(ED_FIT_BLOCKS, c->n), dim3(64), 0, s, B); }
