@@ -11,3 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fe -o fe -- python3
 cd $ROOT
 bash tools/pmc_collect.sh gpurun_out/$1/pmc gpurun_out/$1/pmc_traffic.json gpurun_out/$1/pmc_flops.json
 ls $OUT $OUT/ba $OUT/fe
+# steady-state / long-track shapes (k_schur_mixed, k_marg<512>, k_schur<5>): kernel stats of tools/bench_tracks.py
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tracks -o tracks -- python3 $ROOT/tools/bench_tracks.py 512 > $OUT/tracks.log 2>&1
+cd $ROOT
