@@ -7,7 +7,7 @@
 //   k_ed_anchor : anchor test on the scan lattice + ORDERED compaction (w outer, h inner, :148-164)
 //   k_ed_code   : per-pixel routing byte (walkable, direction, arg-max forward neighbour for both senses of travel)
 //   k_ed_route  : smart routing (:166-707): inherently serial and order dependent per frame -> one wave per
-//                 frame; edge bitmap + a 128x128 tile of routing words in LDS; throughput comes from the batch
+//                 frame; edge bitmap + a full-height 128-column strip of routing bytes in LDS; throughput comes from the batch
 //   k_ed_fit    : per edge chain least-squares fit / extension / Helmholtz validation (:729-1174), one wave per chain
 #pragma once
 #include <hip/hip_runtime.h>
@@ -25,8 +25,9 @@ struct EdBatch {
   const uint8_t* img;      // [N][H][W]
   int16_t *dx, *dy, *g;    // [N][H][W]
   uint8_t* dir;            // [N][H][W]
-  uint16_t* code;          // [N][H][Wc] routing words (k_ed_code)
-  int Wc;                  // W rounded up to the routing tile width (128)
+  uint8_t* code;           // [N][H][Wc] routing bytes (k_ed_code)
+  int Wc;                  // W rounded up to the routing strip width (128)
+  int routeHS;             // rows of the routing strip k_ed_route keeps in LDS (a multiple of 32; >= H: the full height)
   unsigned long long* rstats; // [N][4] routing counters: steps, tile loads, walks, cycles (diagnostic)
   uint32_t *anchX, *anchY; // [N][cap]
   int* nAnch;              // [N]
@@ -226,15 +227,17 @@ __global__ __launch_bounds__(1024) void k_ed_anchor(EdBatch B) {
 
 // ---- smart routing ---------------------------------------------------------------------------------------
 // Everything the walk needs to know about a pixel is static once gImg/dirImg exist: whether it is walkable (g > 0), its
-// direction, and -- for each of the two senses of travel -- the move to the forward neighbour with the largest gradient
+// direction, and -- for each of the two senses of travel -- WHICH of the three forward neighbours has the largest gradient
 // (compared as unsigned char, edline_detector.cpp:231-233) or that the image border stops the walk.  k_ed_code computes
-// that in parallel into one 16-bit word per pixel (row stride Wc = W rounded up to the tile width):
-//   bits 0-3 move when travelling forward (RIGHT on a horizontal pixel, DOWN on a vertical one): (dx+1) | (dy+1) << 2,
-//   bits 4-7 move when travelling backward (LEFT / UP); the "move" (0,0) = 5 means the border breaks the walk,
-//   bit 8 horizontal pixel, bit 9 walkable (g > 0)
+// that in parallel into one BYTE per pixel (row stride Wc = W rounded up to the strip width; round 4 -- a 16-bit word with the
+// moves spelled out until round 3: a byte per pixel lets a full-height strip of the frame sit in LDS next to the edge bitmap):
+//   bits 0-1 choice when travelling forward (RIGHT on a horizontal pixel, DOWN on a vertical one): 0 / 1 = the two diagonals,
+//            2 = straight, 3 = the border breaks the walk;  bits 2-3 the same when travelling backward (LEFT / UP);
+//   bit 4 horizontal pixel, bit 5 walkable (g > 0).
+// The move (dx + 1) | (dy + 1) << 2 of (pixel type, sense, choice) comes out of a 64-bit constant on the scalar unit (ED_MOVES).
 constexpr int ED_TILE = 128;
-constexpr int ED_STOP = 5;
-constexpr int ED_HORIZ = 1 << 8, ED_LIVE = 1 << 9;
+constexpr int ED_STOP = 3;
+constexpr int ED_HORIZ = 1 << 4, ED_LIVE = 1 << 5;
 
 __device__ __forceinline__ int ed_pick(int g1, int g2, int g3) {   // g1, g3 diagonals, g2 straight
   g1 &= 255; g2 &= 255; g3 &= 255;
@@ -242,7 +245,20 @@ __device__ __forceinline__ int ed_pick(int g1, int g2, int g3) {   // g1, g3 dia
   if (g3 >= g2 && g3 >= g1) return 1;
   return 2;
 }
-__device__ __forceinline__ int ed_move(int dx, int dy) { return (dx + 1) | ((dy + 1) << 2); }
+__host__ __device__ constexpr int ed_move(int dx, int dy) { return (dx + 1) | ((dy + 1) << 2); }
+// entry (h, F, c) at bit 4 * (8 h + 4 F + c): horizontal pixel -> dx = +-1, dy = -1 / +1 / 0; vertical pixel -> dy = +-1, dx = +1 / -1 / 0
+constexpr unsigned long long ed_moves() {
+  unsigned long long t = 0;
+  for (int h = 0; h < 2; ++h)
+    for (int F = 0; F < 2; ++F)
+      for (int c = 0; c < 3; ++c) {
+        const int s = F ? 1 : -1;
+        const int mv = h ? ed_move(s, c == 0 ? -1 : (c == 1 ? 1 : 0)) : ed_move(c == 0 ? 1 : (c == 1 ? -1 : 0), s);
+        t |= (unsigned long long)mv << (4 * (8 * h + 4 * F + c));
+      }
+  return t;
+}
+constexpr unsigned long long ED_MOVES = ed_moves();
 
 __global__ __launch_bounds__(256) void k_ed_code(EdBatch B) {
   const int n = blockIdx.y;
@@ -257,42 +273,33 @@ __global__ __launch_bounds__(256) void k_ed_code(EdBatch B) {
     const bool horiz = B.dir[(size_t)n * W * H + i] == 255;
     int f = ED_STOP, b = ED_STOP;
     if (horiz) {
-      if (!(x == W - 1 || y == 0 || y == H - 1)) {   // RIGHT: (x+1,y-1) | (x+1,y+1) | (x+1,y)
-        const int c = ed_pick(g[i - W + 1], g[i + 1], g[i + W + 1]);
-        f = ed_move(1, c == 0 ? -1 : (c == 1 ? 1 : 0));
-      }
-      if (!(x == 0 || y == 0 || y == H - 1)) {       // LEFT: (x-1,y-1) | (x-1,y+1) | (x-1,y)
-        const int c = ed_pick(g[i - W - 1], g[i - 1], g[i + W - 1]);
-        b = ed_move(-1, c == 0 ? -1 : (c == 1 ? 1 : 0));
-      }
+      if (!(x == W - 1 || y == 0 || y == H - 1)) f = ed_pick(g[i - W + 1], g[i + 1], g[i + W + 1]);   // RIGHT: (x+1,y-1) | (x+1,y+1) | (x+1,y)
+      if (!(x == 0 || y == 0 || y == H - 1)) b = ed_pick(g[i - W - 1], g[i - 1], g[i + W - 1]);       // LEFT: (x-1,y-1) | (x-1,y+1) | (x-1,y)
     } else {
-      if (!(x == 0 || x == W - 1 || y == H - 1)) {   // DOWN: (x+1,y+1) | (x-1,y+1) | (x,y+1)
-        const int c = ed_pick(g[i + W + 1], g[i + W], g[i + W - 1]);
-        f = ed_move(c == 0 ? 1 : (c == 1 ? -1 : 0), 1);
-      }
-      if (!(x == 0 || x == W - 1 || y == 0)) {       // UP: (x+1,y-1) | (x-1,y-1) | (x,y-1)
-        const int c = ed_pick(g[i - W + 1], g[i - W], g[i - W - 1]);
-        b = ed_move(c == 0 ? 1 : (c == 1 ? -1 : 0), -1);
-      }
+      if (!(x == 0 || x == W - 1 || y == H - 1)) f = ed_pick(g[i + W + 1], g[i + W], g[i + W - 1]);   // DOWN: (x+1,y+1) | (x-1,y+1) | (x,y+1)
+      if (!(x == 0 || x == W - 1 || y == 0)) b = ed_pick(g[i - W + 1], g[i - W], g[i - W - 1]);       // UP: (x+1,y-1) | (x-1,y-1) | (x,y-1)
     }
-    code = ED_LIVE | (horiz ? ED_HORIZ : 0) | f | (b << 4);
+    code = ED_LIVE | (horiz ? ED_HORIZ : 0) | f | (b << 2);
   }
-  B.code[((size_t)n * H + y) * B.Wc + x] = (uint16_t)code;
+  B.code[((size_t)n * H + y) * B.Wc + x] = (uint8_t)code;
 }
 
 // Walk state shared by the whole wave: every lane computes the same (uniform) walk.
-// LDS: edge bitmap of the frame (1 bit / pixel) + a 128 x 128 tile of routing words around the walker, reloaded
-// cooperatively when the walker leaves it -- one global latency per ~80 steps instead of two per step.
+// LDS: edge bitmap of the frame (1 bit / pixel) + a STRIP of routing bytes around the walker, 128 columns wide and HS rows high
+// (round 4: HS = the whole frame height when it fits beside the bitmap -- 61 KB for 480 rows -- so that only a walk that
+// leaves the strip SIDEWAYS, or the scan of the anchors moving on, asks for a reload: 138 per frame on the benchmark's stream
+// against 1 455 reloads of the 128 x 128 tile of 16-bit words of round 3, measured with a counter in the round-3 kernel),
+// reloaded cooperatively by the four waves of the work-group.
 // The travel state is four bits S = lastWasHorizontal | lastWasForward << 1 | (x > lastX) << 2 | (y > lastY) << 3
 // (lastDirection / lastX / lastY of edline_detector.cpp:196-215 only ever enter through these predicates); whether the
 // walk goes forward on the current pixel is a 16-entry truth table per pixel type.
 struct EdWalker {
-  const uint16_t* code;  // frame's routing words
+  const uint8_t* code;   // frame's routing bytes
   unsigned* bits;        // LDS edge bitmap
-  uint16_t* tile;        // LDS tile
-  unsigned* ring;        // LDS: the last <= 64 pixels of the current part (x | y << 16)
-  int W, H, Wc;
-  int tx0, ty0;          // tile origin; tx0 < 0 = nothing loaded
+  uint8_t* tile;         // LDS strip [HS][128]
+  unsigned* ring;        // LDS: request block of the strip loads
+  int W, H, Wc, HS;
+  int tx0, ty0;          // strip origin; tx0 < 0 = nothing loaded
   unsigned nSteps, nLoads, nWalks;
 };
 
@@ -307,33 +314,36 @@ constexpr unsigned ed_truth(bool horizPixel) {
 }
 constexpr unsigned ED_TRUTH = ed_truth(false) | (ed_truth(true) << 16);
 
-// One quarter of a tile (32 of its 128 rows): a tile row is 256 B = 16 lanes x 16 B, one instruction moves four rows, eight
-// loads in flight.  The four waves of the work-group take a quarter each (k_ed_route).
-constexpr int ED_ROUTE_WAVES = ED_TILE / 32;
-__device__ __forceinline__ void ed_tile_rows(const EdWalker& wk, int tx, int ty, int b, int lane) {
-  const int sub = lane >> 4, col = (lane & 15) * 8;
-  const uint16_t* src = wk.code + (size_t)(ty + sub) * wk.Wc + tx + col;
-  uint16_t* dst = wk.tile + sub * ED_TILE + col;
-  uint4 v[8];
+// One wave's share of a strip load: a strip row is 128 B = 8 lanes x 16 B, one instruction of a wave moves 8 rows, the four
+// waves of the work-group 32; HS / 32 such rounds, eight loads in flight per wave.
+constexpr int ED_ROUTE_WAVES = 4;
+__device__ __forceinline__ void ed_tile_rows(const EdWalker& wk, int tx, int ty, int wave, int lane) {
+  const int sub = lane >> 3, col = (lane & 7) * 16;
+  const int rounds = wk.HS >> 5;
+  for (int r0 = 0; r0 < rounds; r0 += 8) {
+    uint4 v[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int row = ty + sub + 4 * (8 * b + k);
-    v[k] = row < wk.H ? *(const uint4*)(src + (size_t)4 * (8 * b + k) * wk.Wc) : make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < 8; ++k) {
+      const int lr = 32 * (r0 + k) + 8 * wave + sub;      // row inside the strip
+      const int row = ty + lr;
+      v[k] = (r0 + k < rounds && row < wk.H) ? *(const uint4*)(wk.code + (size_t)row * wk.Wc + tx + col) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int lr = 32 * (r0 + k) + 8 * wave + sub;
+      if (r0 + k < rounds) *(uint4*)(wk.tile + lr * ED_TILE + col) = v[k];
+    }
   }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) *(uint4*)(dst + 4 * (8 * b + k) * ED_TILE) = v[k];
 }
-// The walker (wave 0) asks for a tile: command and origin to LDS, barrier A (the three helper waves wait there), every wave
-// loads its quarter, barrier B.  Between B and the next A the helpers touch nothing.
+// The walker (wave 0) asks for a strip: command and origin to LDS, barrier A (the three helper waves wait there), every wave
+// loads its rows, barrier B.  Between B and the next A the helpers touch nothing.
 __device__ __forceinline__ void ed_tile_load(EdWalker& wk, int x, int y, unsigned S) {
-  // centred on the walker: the two walks of an anchor leave in opposite directions and the next anchor of the scan sits two
-  // rows further down, so a tile placed AHEAD of the direction of travel (rounds 1-2) was thrown away by the very next walk
-  // (~1500 reloads per frame); centred, a tile serves all walks shorter than 64 pixels around a run of anchors
-  int tx = x - ED_TILE / 2, ty = y - ED_TILE / 2;
+  // centred on the walker (columns; rows only when the strip is lower than the frame)
+  int tx = x - ED_TILE / 2, ty = y - wk.HS / 2;
   (void)S;
-  tx &= ~7;
+  tx &= ~15;
   tx = max(0, min(tx, wk.Wc - ED_TILE));
-  ty = max(0, min(ty, wk.H - ED_TILE));
+  ty = max(0, min(ty, wk.H - wk.HS));       // (HS >= H: 0)
   tx = __builtin_amdgcn_readfirstlane(tx); ty = __builtin_amdgcn_readfirstlane(ty);
   if (threadIdx.x == 0) { wk.ring[0] = 1u; wk.ring[1] = (unsigned)tx; wk.ring[2] = (unsigned)ty; }
   __syncthreads();   // A
@@ -361,14 +371,14 @@ __device__ __forceinline__ int ed_walk(EdWalker& wk, int x, int y, unsigned S, u
   int n = 0;
   int pxy = 0;                   // lane (i & 63) holds pixel i of the current block of 64
   for (;;) {
-    if ((unsigned)(x - wk.tx0) >= (unsigned)ED_TILE || (unsigned)(y - wk.ty0) >= (unsigned)ED_TILE || wk.tx0 < 0)
+    if ((unsigned)(x - wk.tx0) >= (unsigned)ED_TILE || (unsigned)(y - wk.ty0) >= (unsigned)wk.HS || wk.tx0 < 0)
       ed_tile_load(wk, x, y, S);
     // window origin: one pixel behind the walker, six ahead, +-3 across the direction of travel; kept inside the tile
     int wx0, wy0;
     if (S & 1) { wx0 = (S & 2) ? x - 1 : x - 6; wy0 = y - 3; }
     else { wy0 = (S & 2) ? y - 1 : y - 6; wx0 = x - 3; }
     wx0 = __builtin_amdgcn_readfirstlane(max(wk.tx0, min(wx0, wk.tx0 + ED_TILE - 8)));
-    wy0 = __builtin_amdgcn_readfirstlane(max(wk.ty0, min(wy0, wk.ty0 + ED_TILE - 8)));
+    wy0 = __builtin_amdgcn_readfirstlane(max(wk.ty0, min(wy0, wk.ty0 + wk.HS - 8)));
     const int qx = wx0 + lx, qy = wy0 + ly;
     const bool inb = qx < W && qy < wk.H;
     const int idx = __mul24(qy, W) + qx;
@@ -390,10 +400,11 @@ __device__ __forceinline__ int ed_walk(EdWalker& wk, int x, int y, unsigned S, u
         if (o < cap) { px[o] = (unsigned)pxy & 0xffff; py[o] = (unsigned)pxy >> 16; }
       }
       const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wcode, li);
-      const unsigned h = (w >> 8) & 1;
+      const unsigned h = (w >> 4) & 1;
       const unsigned F = (ED_TRUTH >> (h * 16 + S)) & 1;
-      const unsigned mv = (w >> (F ? 0 : 4)) & 15;
-      if (mv == ED_STOP) { done = true; break; }
+      const unsigned ch = (w >> (F ? 0 : 2)) & 3;
+      if (ch == ED_STOP) { done = true; break; }
+      const unsigned mv = (unsigned)(ED_MOVES >> (4 * (8 * h + 4 * F + ch))) & 15;
       // (v_readfirstlane: the compiler's uniformity analysis loses the walker's state through the loops; one hint per value
       // keeps all of the arithmetic above on the scalar unit)
       x = __builtin_amdgcn_readfirstlane(x + (int)(mv & 3) - 1);
@@ -424,9 +435,9 @@ __global__ __launch_bounds__(64 * ED_ROUTE_WAVES) void k_ed_route(EdBatch B) {
   EdWalker wk;
   wk.code = B.code + (size_t)n * H * B.Wc;
   wk.bits = ed_sm;
-  wk.tile = (uint16_t*)(ed_sm + ((nWords + 3) & ~3));
-  wk.ring = (unsigned*)(wk.tile + ED_TILE * ED_TILE);
-  wk.W = W; wk.H = H; wk.Wc = B.Wc;
+  wk.tile = (uint8_t*)(ed_sm + ((nWords + 3) & ~3));
+  wk.ring = (unsigned*)(wk.tile + (size_t)B.routeHS * ED_TILE);
+  wk.W = W; wk.H = H; wk.Wc = B.Wc; wk.HS = B.routeHS;
   wk.tx0 = -1; wk.ty0 = 0;
   wk.nSteps = wk.nLoads = wk.nWalks = 0;
   const long long t0 = __builtin_readcyclecounter();
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(64 * ED_ROUTE_WAVES) void k_ed_route(EdBatch B) {
       const int code = __shfl(mcode, k, 64);
       const int idx = y * W + x;
       if ((wk.bits[idx >> 5] >> (idx & 31)) & 1) continue;
-      const unsigned h = (code >> 8) & 1;
+      const unsigned h = (code >> 4) & 1;
       wk.nWalks += 2;
       // first part (RIGHT / DOWN) into the scratch arrays, second part (LEFT / UP) directly behind the slot of the
       // (reversed) first part: its element 0 is the anchor again

@@ -160,8 +160,17 @@ int vpl_fe_create(vpl_fe_ctx** out, int device, int max_images, int width, int h
   AL(c->d_sorted, N * B.maxLines); AL(c->d_sortedCnt, N);
 #undef AL
   // k_ed_route keeps the frame's edge bitmap and one tile of routing codes in LDS
-  c->routeSmem = (size_t)(((((size_t)width * height + 31) >> 5) + 3) & ~(size_t)3) * 4 + ED_TILE * ED_TILE * 2 + 64 * 4;
-  if (e == hipSuccess && c->routeSmem > 159 * 1024) e = hipErrorInvalidValue;   // frames above ~1.2 Mpixel
+  {
+    // edge bitmap + routing strip [HS][128] bytes + request block; HS = the frame height rounded up to 32 when that fits into
+    // 159 KB, else what is left (at least 128 rows: frames above ~1.1 Mpixel are refused)
+    const size_t bits = (size_t)(((((size_t)width * height + 31) >> 5) + 3) & ~(size_t)3) * 4;
+    int hs = (height + 31) / 32 * 32;
+    while (hs > 128 && bits + (size_t)hs * ED_TILE + 64 * 4 > 159 * 1024) hs -= 32;
+    // (rows of the strip past the frame are zero-filled by the loader)
+    B.routeHS = hs;
+    c->routeSmem = bits + (size_t)hs * ED_TILE + 64 * 4;
+  }
+  if (e == hipSuccess && c->routeSmem > 159 * 1024) e = hipErrorInvalidValue;   // frames above ~1.1 Mpixel
   static size_t route_max = 0;   // per kernel, not per context: never lowered by a later, smaller context
   if (e == hipSuccess && c->routeSmem > 48 * 1024 && c->routeSmem > route_max) {
     e = hipFuncSetAttribute((const void*)k_ed_route, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->routeSmem);
