@@ -4,7 +4,7 @@
 // Prints one JSON object: median wall-clock milliseconds of upload / solve (+ synchronize) / download and of the whole
 // call, and next to them the DEVICE time of each leg (hipEvents on the context's stream: vpl_ctx_leg_times) from a second
 // series of calls with leg timing on -- a leg whose wall clock is far above its device time is waiting on the host side
-// (runtime, driver), not on the GPU.  Built and run by tests/test_gpu_latency.py and by bench.py.
+// (runtime, driver), not on the GPU.  Built and run by tests/test_zz_gpu_latency.py and by bench.py.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
