@@ -195,8 +195,9 @@ inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL,
     if (nks >= maxKS) return false;
     tab[4 * nks] = g; tab[4 * nks + 1] = id[0] | id[1] << 16; tab[4 * nks + 2] = id[2] | id[3] << 16; tab[4 * nks + 3] = 0;
     grp.push_back(g);
-    // weight = matrix-core instructions of the entry, up to a factor: 6 tiles narrow, 15 wide (x 4 K-steps for lines)
-    wgt.push_back(((g & 32) ? 4 : 1) * (mixed ? ((g & 64) ? 5 : 2) : 1));
+    // weight ~ time of the entry: 6 tile products narrow; wide = five passes of five products, six loads and transforms each
+    // (x 4 K-steps for lines)
+    wgt.push_back(((g & 32) ? 4 : 1) * (mixed ? ((g & 64) ? 10 : 2) : 1));
     ++nks;
     return true;
   };
@@ -267,9 +268,15 @@ inline int pack_schur_ksteps(int nP, const int* ps_list, const int* cnt, int nL,
   struct Inc { int wv, ci; long when; };
   std::vector<Inc> inc;
   for (int wv = 0; wv < NWV; ++wv) {
-    std::sort(mine[wv].begin(), mine[wv].end());
+    // table order; WIDE chunks last: a wide chunk holds its ticket from the adds of its first pass to those of its fifth, so it
+    // should be the last one anybody waits for
+    std::sort(mine[wv].begin(), mine[wv].end(), [&](int a, int b) {
+      const bool wa = (grp[chunks[a].k0] & 64) != 0, wb = (grp[chunks[b].k0] & 64) != 0;
+      if (wa != wb) return wb;
+      return a < b;
+    });
     long done = 0;
-    for (int ci : mine[wv]) { done += chunks[ci].w; inc.push_back(Inc{wv, ci, done}); }
+    for (int ci : mine[wv]) { done += chunks[ci].w; inc.push_back(Inc{wv, ci, (grp[chunks[ci].k0] & 64) ? total + done : done}); }
   }
   std::vector<int> order(inc.size());
   for (size_t i = 0; i < inc.size(); ++i) order[i] = (int)i;
