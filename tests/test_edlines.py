@@ -137,3 +137,33 @@ def test_gpu_edlines_parameters_and_degenerate_frames():
         if len(lo):
             assert np.abs(canon(out[i])[:, 4:7] - canon(lo)[:, 4:7]).max() < 1e-9
     fe.close()
+
+
+@pytest.mark.gpu
+def test_gpu_edlines_other_frame_sizes():
+    """Frame sizes around the routing strip's limits (round 4): 1024 x 768 (edge bitmap 98 KB: the strip of routing bytes is
+    lower than the frame and is reloaded vertically as well), 752 x 480 (full-height strip), 160 x 120 and 70 x 50 (strip
+    higher / wider than the frame).  Every stage and the line set against the oracle, with and without the pre-blur."""
+    base = IMGS[0]
+    for (W, H) in ((1024, 768), (160, 120), (70, 50)):
+        ys = (np.arange(H) * base.shape[0] / H).astype(int)
+        xs = (np.arange(W) * base.shape[1] / W).astype(int)
+        a = base[ys][:, xs]                                   # nearest-neighbour resize of the real frame
+        b = np.ascontiguousarray(a[::-1, ::-1])
+        imgs = np.stack([a, b])
+        fe = v.frontend.FrontendContext(device=0, max_images=2, width=W, height=H, max_lines=2048)
+        p = v.frontend.default_param()
+        p.minLineLen = 15
+        for smoothed in (True, False):
+            out = fe.detect_batch(imgs, p, smoothed=smoothed)
+            for i in range(2):
+                lo, st = o.edlines(imgs[i], min_len=15, want_stages=True, smoothed=smoothed)
+                sg = fe.debug_stage(i)
+                for k in ("dx", "dy", "g", "dir", "anchors", "sid", "chain_x", "chain_y"):
+                    assert np.array_equal(sg[k], st[k]), (W, H, smoothed, i, k)
+                assert len(out[i]) == len(lo), (W, H, smoothed, i)
+                if len(lo):
+                    assert np.abs(canon(out[i])[:, 4:7] - canon(lo)[:, 4:7]).max() < 1e-9
+        if (W, H) == (1024, 768):
+            assert len(lo) > 50 and fe.route_stats(0)["tile_loads"] > 0      # strip loads happened
+        fe.close()
