@@ -31,6 +31,9 @@ def test_bench_prints_one_contract_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     assert "traffic_source" in r and "committed" in r["traffic_source"]          # the PMC bytes are NOT collected in this run
+    # the dominant kernel is a single kernel by total time (the three-kernel step competes with its longest member)
+    assert r["kernel"] in r["per_kernel"] and "dominant_by" in r
+    assert r["kernel"] == "k_lin" or r["per_kernel"]["k_lin"]["ms_per_solve"] < r["per_kernel"]["k_step"]["ms_per_solve"]
     assert "binding" in r and "fp64" in r
     if r["fp64"] is not None:
         assert r["fp64"]["unit"] == "TFLOP/s" and r["fp64"]["peak"] == 78.6 and 0 < r["fp64"]["frac"] < 1
