@@ -308,6 +308,168 @@ __device__ __forceinline__ int psd_pivoted_cholesky_wave(double* A, int n, int l
   return rank;
 }
 
+// The same factorisation for 48 < n <= NMAX = 2 NH by FOUR waves with HALF COLUMNS in registers (round 4: the reference's
+// steady-state kept block has 75 dims; a whole 76-entry column per lane does not fit the register file next to what the
+// compiler needs around it -- DESIGN.md section 8 (2)).  Wave w: column group w & 1 (columns 64 (w & 1) + lane), row half w >> 1
+// (rows NH (w >> 1) .. + NH - 1).  Every lane keeps the diagonal entry of its column (both halves update it with the same
+// arithmetic), the top-half lanes the rhs entry.  Pivot step k:
+//   A  waves 0 and 1 find the largest live diagonal of their columns (first lane on ties) and write (value, index, rhs entry)
+//      into slot k & 1 of `meta`; EVERY wave then arrives at counter A and waits until all four have: everybody has finished
+//      step k - 1 (its reads of the previous column and candidates), and the candidates of step k are visible.  The winner is
+//      the larger value, column group 0 on ties = the lower index (the one-wave rule);
+//   B  the two lanes that own the winning column write its scaled halves into `col`, their waves arrive at counter B; every
+//      wave waits for the two;
+//   C  every lane reads its own entry l_j and, broadcast, the NH entries of its row half, and updates.
+// The counters only grow (relaxed LDS atomics + work-group fences).  A wait gives up after 2^24 polls and the call returns
+// -1 instead of hanging the device.  The other waves of the work-group wait at the barrier behind the loop.  Same arithmetic
+// per entry and same pivots as the other versions.  Lo: n x ld + NMAX + 24 doubles of scratch.
+template <int NH>
+__device__ __forceinline__ int psd_pivoted_cholesky_wave4(double* A, int n, int ld, int* perm, int* iflag, double rel_tol, double abs_tol,
+                                                          double* c, double* Lo, int* phase /* 4 ints of LDS */,
+                                                          long long* stamps = nullptr) {
+  constexpr int NMAX = 2 * NH;
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6;
+  double* col = Lo + n * ld;             // NMAX: the winning column, scaled
+  double* meta = col + NMAX;             // [2 slots][2 groups][4]: value, global index, rhs entry; [16], [17]: tail counts
+  if (tid < 4) phase[tid] = 0;
+  if (tid == 4) iflag[1] = 0;
+  __syncthreads();
+  double cj = 0.0;
+  int gcol = 0, hf = 1;
+  if (wv < 4) {
+    const int cg = wv & 1, r0 = NH * (wv >> 1);
+    hf = wv >> 1;
+    gcol = 64 * cg + lane;
+    double a[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) a[i] = (r0 + i < n && gcol < n) ? A[(r0 + i) * ld + gcol] : 0.0;
+    double diag = gcol < n ? A[gcol * ld + gcol] : -1.0;
+    cj = (c && hf == 0 && gcol < n) ? c[gcol] : 0.0;
+    bool alive = gcol < n;
+    int rank = n;
+    double tol = 0.0;
+    bool dead = false;                   // a wait timed out
+    // phase[0]: arrivals at A (every wave, once per step); phase[1]: arrivals at B (the two waves that own the winning column);
+    // phase[2]: the tail of the top-half waves.  Counters only grow; one LDS word is polled per wait.
+#ifdef VPL_STAMPS
+    long long st_wait[2] = {0, 0}, st_b = 0, st_c = 0;
+#endif
+    auto wait_cnt = [&](int which, int v) {
+#ifdef VPL_STAMPS
+      const long long t0 = __builtin_readcyclecounter();
+#endif
+      int polls = 0;
+      while (!dead && __hip_atomic_load(&phase[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v)
+        if (++polls > (1 << 24)) dead = true;
+#ifdef VPL_STAMPS
+      if (which < 2) st_wait[which] += __builtin_readcyclecounter() - t0;
+#endif
+    };
+    auto arrive = [&](int which) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) __hip_atomic_fetch_add(&phase[which], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    for (int k = 0; k < n; ++k) {
+      // A: candidates of the two column groups (top-half waves), slot k & 1
+      if (hf == 0) {
+        const double best = alive ? diag : 0.0;
+        double mx = best;
+        mx = fmax(mx, dpp_shr_f64<0x111>(mx));
+        mx = fmax(mx, dpp_shr_f64<0x112>(mx));
+        mx = fmax(mx, dpp_shr_f64<0x114>(mx));
+        mx = fmax(mx, dpp_shr_f64<0x118>(mx));
+        const double pw = fmax(fmax(readlane_f64(mx, 15), readlane_f64(mx, 31)), fmax(readlane_f64(mx, 47), readlane_f64(mx, 63)));
+        const unsigned long long hit = __ballot(alive && diag == pw);
+        const int pl = hit ? __builtin_ctzll(hit) : 0;
+        if (lane == pl) {
+          double* mm = meta + 8 * (k & 1) + 4 * cg;
+          mm[0] = (hit && pw > 0.0) ? pw : 0.0;     // (a group without a live positive diagonal offers 0)
+          mm[1] = (double)gcol;
+          mm[2] = cj;
+        }
+      }
+      arrive(0);
+      wait_cnt(0, 4 * (k + 1));
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (dead) break;
+      const double* mk = meta + 8 * (k & 1);
+      const double p0 = mk[0], p1 = mk[4];
+      const int win = p1 > p0 ? 1 : 0;
+      const double piv = win ? p1 : p0;
+      const int p = (int)(win ? mk[5] : mk[1]);
+      const double cjp = win ? mk[6] : mk[2];
+      if (k == 0) tol = fmax(abs_tol, fmax((double)n * 2.220446049250313e-16, rel_tol) * piv);
+      if (!(piv > tol)) { rank = k; break; }
+      // 1 / sqrt(pivot) by v_rsq_f64 + two Newton steps, sqrt(pivot) = pivot / sqrt(pivot): ~10 dependent instructions on the
+      // critical path of every wave where an IEEE sqrt and divide are ~45 (as k_chol's chains do; the results agree with the
+      // correctly rounded ones to an ulp -- the other versions of this factorisation keep sqrt() and the division)
+      double inv = __builtin_amdgcn_rsq(piv);
+      inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+      inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+      const double lkk = piv * inv;
+      // B: the two lanes of column p write its halves (everybody is past step k - 1: the wait above)
+      if (gcol == p) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) col[r0 + i] = a[i] * inv;
+        if (p >= r0 && p < r0 + NH) col[p] = lkk;
+      }
+      if (cg == win) arrive(1);          // (the wave holds column p: wave-uniform)
+      wait_cnt(1, 2 * (k + 1));
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (dead) break;
+      // C: update
+      const double lj = gcol < n ? col[gcol] : 0.0;
+      const bool upd = alive && gcol != p;
+      const double ljm = upd ? lj : 0.0;
+#pragma unroll
+      for (int i = 0; i < NH; ++i) a[i] -= col[r0 + i] * ljm;     // (uniform addresses: broadcast reads)
+      if (upd) diag -= lj * lj;
+      if (hf == 0) {
+        if (gcol < n) Lo[gcol * ld + k] = lj;
+        if (c) {
+          const double yk = cjp * inv;
+          if (upd) cj -= lj * yk;
+          if (gcol == p) cj = yk;          // column p keeps y_k: stored at position k below
+        }
+        if (gcol == p) perm[k] = p;
+      }
+      if (gcol == p) alive = false;
+    }
+    // positions rank..n-1: the indices that were never pivots, ascending -- column group 0 first (top-half waves)
+    if (hf == 0) {
+      const unsigned long long mask = __ballot(alive);
+      if (lane == 0) meta[16 + cg] = (double)__popcll(mask);
+      arrive(2);
+      wait_cnt(2, 2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (!dead) {
+        const int before = __popcll(mask & ((1ull << lane) - 1ull)) + (cg ? (int)meta[16] : 0);
+        if (alive) perm[rank + before] = gcol;
+      }
+    }
+    if (dead && lane == 0) iflag[1] = 1;
+    if (tid == 0) iflag[0] = rank;
+#ifdef VPL_STAMPS
+    if (stamps && lane == 0 && wv < 4) { stamps[2 * wv] = st_wait[0]; stamps[2 * wv + 1] = st_wait[1]; }
+#endif
+  }
+  __syncthreads();                       // every wave is past its last read of col
+  if (c && hf == 0 && gcol < n) col[gcol] = cj;   // y_k sits in column perm[k]
+  __syncthreads();
+  if (iflag[1]) return -1;
+  const int rank = iflag[0];
+  // L(t, k) = Lo(perm[t], k), t >= k, k < rank; everything else zero
+  for (int it = tid; it < n * n; it += T) {
+    const int t = it / n, k = it - t * n;
+    A[t * ld + k] = (k < rank && t >= k) ? Lo[perm[t] * ld + k] : 0.0;
+  }
+  if (c)
+    for (int k = tid; k < n; k += T) c[k] = k < rank ? col[perm[k]] : 0.0;
+  __syncthreads();
+  return rank;
+}
+
 __device__ __forceinline__ int psd_spectral_factor(double* A, int n, int ld, int* perm, double* lam, double* red, int* iflag,
                                    double rel_tol, double* Lo /* n x ld scratch */) {
   const int tid = threadIdx.x, T = blockDim.x;
@@ -427,7 +589,7 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   int* dmap = perm + (n < 16 ? 16 : n) + (n & 1);   // nd
   int* lst = dmap + nd + (nd & 1);       // 2 x LOFF
   const int LOFF = L.loff;
-  __shared__ int s_np0, s_nl0, s_flag[4];
+  __shared__ int s_np0, s_nl0, s_flag[4], s_phase[4];
 
   // dense order: [sb_0 (9), pose_0 (6) | kept blocks in canonical order]  (the reference moves the
   // pose-like marginalised blocks behind the landmarks in descending index order, :291-309)
@@ -751,8 +913,25 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   // end the factorisation; the trailing block is treated as zero.
   VPL_STAMP(B, w, 35);
   // (the dense pre-marginalisation matrix is not needed any more: its space is the one-wave version's scratch)
-  const int rank = n <= 48 ? psd_pivoted_cholesky_wave<48>(G, n, ldm, perm, s_flag, kMargNoiseRel, kMargEps, bv, Ad)
-                           : psd_pivoted_cholesky(G, n, ldm, perm, red, s_flag, kMargNoiseRel, kMargEps, bv, lam);
+  // kept blocks of up to 48 dims: one wave, whole columns in registers; up to 76 (the reference's steady state is 75): four
+  // waves with half columns (round 4); the work-group version remains for 77..80 and behind VPL_MARG_WG_FACTOR (A/B runs)
+  int rank;
+#ifdef VPL_MARG_WG_FACTOR
+  constexpr bool use_wave4 = false;
+#else
+  constexpr bool use_wave4 = T >= 256;
+#endif
+  if (n <= 48) rank = psd_pivoted_cholesky_wave<48>(G, n, ldm, perm, s_flag, kMargNoiseRel, kMargEps, bv, Ad);
+  else if (use_wave4 && n <= 76) {
+    #ifdef VPL_STAMPS
+    rank = psd_pivoted_cholesky_wave4<38>(G, n, ldm, perm, s_flag, kMargNoiseRel, kMargEps, bv, Ad, s_phase, B.dbg + (size_t)w * 64 + 40);
+#else
+    rank = psd_pivoted_cholesky_wave4<38>(G, n, ldm, perm, s_flag, kMargNoiseRel, kMargEps, bv, Ad, s_phase);
+#endif
+    // a hand-shake that timed out (never observed) leaves G and bv as they were -- the columns live in registers until the
+    // routine's last pass: the work-group version takes over
+    if (rank < 0) rank = psd_pivoted_cholesky(G, n, ldm, perm, red, s_flag, kMargNoiseRel, kMargEps, bv, lam);
+  } else rank = psd_pivoted_cholesky(G, n, ldm, perm, red, s_flag, kMargNoiseRel, kMargEps, bv, lam);
   VPL_STAMP(B, w, 36);
   double* J0 = B.mg_J0 + (size_t)w * MAXKEEP * MAXKEEP;
   double* r0 = B.mg_r0 + (size_t)w * MAXKEEP;
