@@ -308,26 +308,26 @@ __device__ __forceinline__ int psd_pivoted_cholesky_wave(double* A, int n, int l
   return rank;
 }
 
-// The same factorisation for 48 < n <= NMAX = 2 NH by FOUR waves with HALF COLUMNS in registers (round 4: the reference's
+// The same factorisation for 48 < n <= NMAX = NQ x NH by 2 NQ waves with column SLICES in registers (round 4: the reference's
 // steady-state kept block has 75 dims; a whole 76-entry column per lane does not fit the register file next to what the
-// compiler needs around it -- DESIGN.md section 8 (2)).  Wave w: column group w & 1 (columns 64 (w & 1) + lane), row half w >> 1
-// (rows NH (w >> 1) .. + NH - 1).  Every lane keeps the diagonal entry of its column (both halves update it with the same
-// arithmetic), the top-half lanes the rhs entry.  Pivot step k:
-//   A  waves 0 and 1 find the largest live diagonal of their columns (first lane on ties) and write (value, index, rhs entry)
-//      into slot k & 1 of `meta`; EVERY wave then arrives at counter A and waits until all four have: everybody has finished
-//      step k - 1 (its reads of the previous column and candidates), and the candidates of step k are visible.  The winner is
-//      the larger value, column group 0 on ties = the lower index (the one-wave rule);
-//   B  the two lanes that own the winning column write its scaled halves into `col`, their waves arrive at counter B; every
-//      wave waits for the two;
-//   C  every lane reads its own entry l_j and, broadcast, the NH entries of its row half, and updates.
+// compiler needs around it -- DESIGN.md section 8 (2)).  Wave w: column group w & 1 (columns 64 (w & 1) + lane), row slice
+// w >> 1 (rows NH (w >> 1) .. + NH - 1); k_marg<512> uses NQ = 4 slices of 19 rows on its eight waves.  Every lane keeps the
+// diagonal entry of its column (all slices update it with the same arithmetic), the lanes of slice 0 the rhs entry.  Pivot step k:
+//   A  the two waves of slice 0 find the largest live diagonal of their columns (first lane on ties) and write (value, index,
+//      rhs entry) into slot k & 1 of `meta`; EVERY wave then arrives at counter A and waits until all have: everybody has
+//      finished step k - 1 (its reads of the previous column and candidates), and the candidates of step k are visible.  The
+//      winner is the larger value, column group 0 on ties = the lower index (the one-wave rule);
+//   B  the NQ lanes that own the winning column write its scaled slices into `col`, their waves arrive at counter B; every
+//      wave waits for them;
+//   C  every lane reads its own entry l_j and, broadcast, the NH entries of its row slice, and updates.
 // The counters only grow (relaxed LDS atomics + work-group fences).  A wait gives up after 2^24 polls and the call returns
-// -1 instead of hanging the device.  The other waves of the work-group wait at the barrier behind the loop.  Same arithmetic
-// per entry and same pivots as the other versions.  Lo: n x ld + NMAX + 24 doubles of scratch.
-template <int NH>
+// -1 instead of hanging the device.  Same pivots and same arithmetic per entry as the other versions, except 1 / sqrt(pivot)
+// (hardware estimate + two Newton steps).  Lo: n x ld + NMAX + 24 doubles of scratch.
+template <int NH, int NQ>
 __device__ __forceinline__ int psd_pivoted_cholesky_wave4(double* A, int n, int ld, int* perm, int* iflag, double rel_tol, double abs_tol,
                                                           double* c, double* Lo, int* phase /* 4 ints of LDS */,
                                                           long long* stamps = nullptr) {
-  constexpr int NMAX = 2 * NH;
+  constexpr int NMAX = NQ * NH;     // NQ row slices of NH rows: 2 NQ waves
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6;
   double* col = Lo + n * ld;             // NMAX: the winning column, scaled
   double* meta = col + NMAX;             // [2 slots][2 groups][4]: value, global index, rhs entry; [16], [17]: tail counts
@@ -336,9 +336,9 @@ __device__ __forceinline__ int psd_pivoted_cholesky_wave4(double* A, int n, int 
   __syncthreads();
   double cj = 0.0;
   int gcol = 0, hf = 1;
-  if (wv < 4) {
+  if (wv < 2 * NQ) {
     const int cg = wv & 1, r0 = NH * (wv >> 1);
-    hf = wv >> 1;
+    hf = wv >> 1;      // row slice; slice 0 holds the candidates, the rhs and writes the factor
     gcol = 64 * cg + lane;
     double a[NH];
 #pragma unroll
@@ -390,7 +390,7 @@ __device__ __forceinline__ int psd_pivoted_cholesky_wave4(double* A, int n, int 
         }
       }
       arrive(0);
-      wait_cnt(0, 4 * (k + 1));
+      wait_cnt(0, 2 * NQ * (k + 1));
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       if (dead) break;
       const double* mk = meta + 8 * (k & 1);
@@ -415,7 +415,7 @@ __device__ __forceinline__ int psd_pivoted_cholesky_wave4(double* A, int n, int 
         if (p >= r0 && p < r0 + NH) col[p] = lkk;
       }
       if (cg == win) arrive(1);          // (the wave holds column p: wave-uniform)
-      wait_cnt(1, 2 * (k + 1));
+      wait_cnt(1, NQ * (k + 1));
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       if (dead) break;
       // C: update
@@ -919,14 +919,14 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
 #ifdef VPL_MARG_WG_FACTOR
   constexpr bool use_wave4 = false;
 #else
-  constexpr bool use_wave4 = T >= 256;
+  constexpr bool use_wave4 = T >= 512;   // eight waves: two column groups x four row slices
 #endif
   if (n <= 48) rank = psd_pivoted_cholesky_wave<48>(G, n, ldm, perm, s_flag, kMargNoiseRel, kMargEps, bv, Ad);
   else if (use_wave4 && n <= 76) {
     #ifdef VPL_STAMPS
-    rank = psd_pivoted_cholesky_wave4<38>(G, n, ldm, perm, s_flag, kMargNoiseRel, kMargEps, bv, Ad, s_phase, B.dbg + (size_t)w * 64 + 40);
+    rank = psd_pivoted_cholesky_wave4<19, 4>(G, n, ldm, perm, s_flag, kMargNoiseRel, kMargEps, bv, Ad, s_phase, B.dbg + (size_t)w * 64 + 40);
 #else
-    rank = psd_pivoted_cholesky_wave4<38>(G, n, ldm, perm, s_flag, kMargNoiseRel, kMargEps, bv, Ad, s_phase);
+    rank = psd_pivoted_cholesky_wave4<19, 4>(G, n, ldm, perm, s_flag, kMargNoiseRel, kMargEps, bv, Ad, s_phase);
 #endif
     // a hand-shake that timed out (never observed) leaves G and bv as they were -- the columns live in registers until the
     // routine's last pass: the work-group version takes over
