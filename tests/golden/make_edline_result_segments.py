@@ -8,7 +8,9 @@ its own, followed by two 10-pixel arrows from its centre (normal (255,0,0) BGR, 
 Later lines overdraw earlier lines and arrows.
 
 What is recovered (data, not source): for every colour that forms a thin straight stripe of fully covered pixels --
-the segment's two end points, the number of stripe pixels, and the colour; plus a label image of the picture
+the segment's two end points, the number of stripe pixels, the colour, and list_index: the position of that line in
+the reference's output list (the colours are rand() % 256 triples after srand(time(0)); the one seed that explains them
+was found with find_srand_seed.c, and it explains all 258); plus a label image of the picture
 (-1 = the grey frame's own pixel, -2 = painted with a blend or an arrow, >= 0 = fully covered by stripe i).  Run in
 the build container only (reads /root/reference); the result is committed as tests/golden/edline_result_segments.npz.
 
@@ -92,12 +94,41 @@ def pt_seg(p, sg):
     return float(np.linalg.norm(p - (a + t * v)))
 
 
+SRAND_SEED = 1612579976      # the demo's srand(time(0)), found by find_srand_seed.c from the stripes' colours
+
+
+def glibc_rand(seed, n):
+    """the first n values of glibc rand() after srand(seed) (TYPE_3 additive feedback generator)"""
+    seed = seed or 1
+    r = [0] * (344 + n)
+    r[0] = seed
+    for i in range(1, 31):
+        r[i] = (16807 * r[i - 1]) % 2147483647
+    for i in range(31, 34):
+        r[i] = r[i - 31]
+    for i in range(34, 344 + n):
+        r[i] = (r[i - 31] + r[i - 3]) & 0xFFFFFFFF
+    return [x >> 1 for x in r[344:]]
+
+
+def list_positions(colour_rgb):
+    """stripe k -> i, the position of its line in the reference's output list: the demo colours line i with the i-th
+    triple of rand() % 256 (test_edline_detector.cpp:52-59; Scalar(r, g, b) is B, G, R)"""
+    rnd = glibc_rand(SRAND_SEED, 3 * len(colour_rgb))
+    where = {(rnd[3 * i + 2] % 256, rnd[3 * i + 1] % 256, rnd[3 * i] % 256): i for i in range(len(colour_rgb))}
+    assert len(where) == len(colour_rgb)
+    pos = np.array([where.get(tuple(int(v) for v in c), -1) for c in colour_rgb], np.int32)
+    assert (pos >= 0).all() and len(set(pos.tolist())) == len(pos), "the seed does not explain every stripe"
+    return pos
+
+
 def main():
     frame = np.load(os.path.join(HERE, "mh04_1.npy"))
     segs, labels = recover(os.path.join(REF, "edline_result.png"), frame)
     out = os.path.join(HERE, "edline_result_segments.npz")
+    colour = segs[:, 5:8].astype(np.uint8)
     np.savez_compressed(out, segments=segs[:, :4], pixels=segs[:, 4].astype(np.int32),
-                        colour_rgb=segs[:, 5:8].astype(np.uint8), labels=labels)
+                        colour_rgb=colour, labels=labels, list_index=list_positions(colour))
     print("recovered %d segments, %d painted pixels -> %s" % (len(segs), int((labels != -1).sum()), out))
     return 0
 

@@ -11,6 +11,7 @@ same frame (tests/golden/mh04_1.npy) and must
   * have both end points of (nearly) every line within 1.5 px of a recovered stripe's (242 of 258) -- the others are within
     2.5 px (the end cap of cv::line reaches 0 - 2 px beyond the end point, 1 is assumed) or belong to stripes that later
     drawing covers at one end (then the missing stretch is painted in another colour).
+  * list its lines in the reference's order up to the interleaving its parallel loop produces (list_index).
 The same checks FAIL without the Gaussian pre-blur and with the other published rounding of OpenCV's fixed-point kernel
 (the last test), i.e. the picture discriminates at the level of the blur's 8.8 taps.
 """
@@ -29,7 +30,7 @@ PARAM = dict(grad_th=30, anchor_th=5, scan=2, min_len=25, fit_err=1.8)   # test_
 def fx():
     z = np.load(os.path.join(HERE, "golden", "edline_result_segments.npz"))
     frame = np.load(os.path.join(HERE, "golden", "mh04_1.npy"))
-    return dict(seg=z["segments"], labels=z["labels"], frame=frame)
+    return dict(seg=z["segments"], labels=z["labels"], frame=frame, list_index=z["list_index"])
 
 
 def drawn(lines):
@@ -130,6 +131,42 @@ def test_end_points_match_the_recovered_stripes(fx):
         lab = labels[ys[out], xs[out]]
         assert (lab != -1).all(), (i, p)
         assert (lab != j).all(), (i, p)
+
+
+def fewest_increasing_runs(seq):
+    """= length of the longest strictly decreasing subsequence"""
+    import bisect
+    tails = []
+    for v in seq:
+        k = bisect.bisect_left(tails, -int(v))
+        if k == len(tails):
+            tails.append(-int(v))
+        else:
+            tails[k] = -int(v)
+    return len(tails)
+
+
+def test_list_order_is_an_interleaving_of_the_oracles_order(fx):
+    """The demo colours line i of the detector's output with the i-th rand() triple after srand(time(0)); the seed is
+    recoverable from the colours (tests/golden/find_srand_seed.c: one seed fits, and it explains all 258 stripes), so
+    the picture also holds every line's POSITION in the reference's list (list_index).  The reference emits lines from
+    cv::parallel_for_ stripes of the edge list under a lock (edline_detector.cpp:1081-1083, 1165-1167, 1195): its list is
+    an interleaving of a few in-order runs of the serial order.  The oracle's list is the serial order: read in the
+    reference's order it falls into 3 increasing runs (a random order of 254 needs about 30)."""
+    lines = o.edlines(fx["frame"], smoothed=False, **PARAM)
+    D = end_distance(drawn(lines), fx["seg"])
+    stripe = D.argmin(1)
+    good = D.min(1) <= 1.5
+    assert good.sum() >= 240 and len(set(stripe[good])) == good.sum()
+    assert sorted(fx["list_index"]) == list(range(len(lines)))
+    position = fx["list_index"][stripe[good]]                 # oracle line (in oracle order) -> place in the reference's list
+    oracle_index = np.nonzero(good)[0]
+    in_reference_order = oracle_index[np.argsort(position)]
+    assert fewest_increasing_runs(in_reference_order) <= 3
+    rng = np.random.default_rng(1)
+    assert min(fewest_increasing_runs(rng.permutation(in_reference_order)) for _ in range(20)) >= 18
+    # and the first line of either list is the same one
+    assert in_reference_order[0] == 0 and position.min() == 0
 
 
 def test_the_picture_discriminates_the_blur(fx):

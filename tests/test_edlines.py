@@ -117,6 +117,9 @@ def test_gpu_edlines_stages_and_lines_match_oracle():
         assert np.abs(a[:, :4] - b[:, :4]).max() < 1e-3       # endpoints (float32 in the reference's Line)
         assert np.abs(a[:, 4:7] - b[:, 4:7]).max() < 1e-9     # line equation (double)
         assert np.abs(a[:, 9] - b[:, 9]).max() < 1e-3
+        # and in the SAME ORDER, the serial order of the reference's loop over edge chains, which the reference-held
+        # pictures pin up to the interleaving of its parallel_for (test_edline_reference_picture.py, list_index)
+        assert np.abs(lg[:, :4] - lo[:, :4]).max() < 1e-3
     fe.close()
 
 
