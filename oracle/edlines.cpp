@@ -27,8 +27,12 @@
 // test_edline_detector.cpp (mh04/imgs/1.png, {5, 1, 30, 5, 2, 25, 1.8}, smoothed = false).  The segments recovered from
 // that picture (tests/golden/make_edline_result_segments.py -> tests/golden/edline_result_segments.npz) are checked
 // against this restatement in tests/test_edline_reference_picture.py: same number of lines, every pixel of every
-// restated line painted in the picture, every painted pixel of the picture explained by a restated line or its arrows.
-// Nothing else of the front-end has a reference-held expected output.
+// restated line painted in the picture, every painted pixel of the picture explained by a restated line or its arrows,
+// and -- the picture's colours being rand() triples whose srand(time(0)) seed tests/golden/find_srand_seed.c recovers --
+// the ORDER of the list: the reference's is an interleaving of 3 in-order runs of the one produced here (its
+// cv::parallel_for_ stripes push lines under a lock).  line_matching/data/line_matching_result.png (frames 5 | 10,
+// LineFilter(3.0), colours after srand(0)) pins the same for two more frames and says which lines LineFilter keeps
+// (tests/test_line_matching_reference_picture.py).  Nothing else of the front-end has a reference-held expected output.
 #include <array>
 #include <cmath>
 #include <cfloat>
@@ -389,8 +393,9 @@ struct Fitter {
 };
 }  // namespace
 
-// EDLineDetectorParallel::operator() over all chains, sequentially (the reference's thread order is not
-// deterministic: lines are compared as a set)
+// EDLineDetectorParallel::operator() over all chains, sequentially: the serial order of the reference's loop.  (The
+// reference's own list is an interleaving of in-order runs of this order -- parallel_for_ stripes under a lock,
+// edline_detector.cpp:1081-1083, 1195 -- which both reference pictures confirm, see the header.)
 void ed_fit(const unsigned* xC, const unsigned* yC, const unsigned* sId, int nEdges, const uint8_t* dir, const short* dx,
             const short* dy, int W, int H, const EDParam& P, std::vector<EDLine>& lines) {
   Fitter F{xC, yC, dir, dx, dy, W, H, P.minLineLen, P.lineFitErrThreshold,
