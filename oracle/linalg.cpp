@@ -41,13 +41,17 @@ bool inverse_lu(const MatX& A, MatX& Ainv) {
   const int n = A.r;
   MatX LU = A;
   std::vector<int> piv(n);
+  bool singular = false;
   for (int i = 0; i < n; ++i) piv[i] = i;
   for (int k = 0; k < n; ++k) {
     int p = k;
     double best = std::fabs(LU(k, k));
     for (int i = k + 1; i < n; ++i)
       if (std::fabs(LU(i, k)) > best) { best = std::fabs(LU(i, k)); p = i; }
-    if (best == 0.0) return false;
+    // an exactly singular column: Eigen's PartialPivLU (partial_lu_impl::unblocked_lu) notes the zero pivot, leaves the
+    // column unscaled and goes on; the inverse then divides by it and comes out as inf / NaN.  The same here (it was a
+    // `return false` that left Ainv empty: a landmark block without information made the caller read through a null matrix)
+    if (best == 0.0) { singular = true; continue; }
     if (p != k) {
       for (int j = 0; j < n; ++j) std::swap(LU(k, j), LU(p, j));
       std::swap(piv[k], piv[p]);
@@ -75,7 +79,7 @@ bool inverse_lu(const MatX& A, MatX& Ainv) {
     }
     for (int i = 0; i < n; ++i) Ainv(i, c) = col[i];
   }
-  return true;
+  return !singular;
 }
 
 // Cyclic Jacobi on the full symmetric matrix.  Converges to machine precision;

@@ -10,6 +10,13 @@ namespace orc {
 // the reference's absolute 1e-8 (marginalization_factor.cpp:349-357) -- the cut the device's pivoted Cholesky makes
 // (csrc/ba_marg.h, kMargNoiseRel); tests/test_gpu_chain.py uses it to measure what that deviation does over a long chain.
 double g_marg_rel_eps = 0.0;
+// TEST SWITCH (0 = as the reference writes the product).  2: the inner sums of both Schur complements accumulate in long double and
+// are rounded once.  1: the inner sums of the last Schur complement A = Arr - (Arm Amm^+) Amr
+// (marginalization_factor.cpp:345) run from the last term to the first -- the same numbers, another rounding.  Entries of
+// the IMU rows reach 5e14 (bias random walk), the kept block's weak eigenvalues sit near 1e-8: tools/fuzz_parity.py uses
+// the switch to tell windows whose prior is decided by that rounding (Eigen's blocked products round differently again)
+// from a wrong device.
+int g_marg_reverse_sums = 0;
 int g_marg_threads = 1;   // NUM_THREADS of marginalization_factor.h:13 is 4; 1 = the same sums without threads
 
 // marginalization_factor.cpp:3-69
@@ -177,6 +184,11 @@ void MarginalizationInfo::marginalize() {
     for (int i = 0; i < n1; ++i) {
       for (int j = 0; j < n1; ++j) {
         double s = 0;
+        if (g_marg_reverse_sums == 2) {   // test switch: the sum in extended precision, rounded once
+          long double sl = 0;
+          for (int k = 0; k < m1; ++k) sl += (long double)tempA(i, k) * Ar(k, m1 + j);
+          s = (double)sl;
+        } else
         for (int k = 0; k < m1; ++k) s += tempA(i, k) * Ar(k, m1 + j);
         A2(i, j) = Ar(m1 + i, m1 + j) - s;
       }
@@ -216,7 +228,12 @@ void MarginalizationInfo::marginalize() {
   for (int i = 0; i < n2; ++i) {
     for (int j = 0; j < n2; ++j) {
       double s = 0;
-      for (int k = 0; k < m2; ++k) s += tempB(i, k) * A(k, m2 + j);
+      if (!g_marg_reverse_sums) for (int k = 0; k < m2; ++k) s += tempB(i, k) * A(k, m2 + j);
+      else if (g_marg_reverse_sums == 2) {
+        long double sl = 0;
+        for (int k = 0; k < m2; ++k) sl += (long double)tempB(i, k) * A(k, m2 + j);
+        s = (double)sl;
+      } else for (int k = m2 - 1; k >= 0; --k) s += tempB(i, k) * A(k, m2 + j);   // test switch: the same sum, last term first
       A3(i, j) = A(m2 + i, m2 + j) - s;
     }
     double s = 0;

@@ -18,6 +18,7 @@
 namespace orc {
 
 extern double g_marg_rel_eps;   // test switch, see marginalization.cpp
+extern int g_marg_reverse_sums;   // test switch, see marginalization.cpp
 extern int g_marg_threads;   // threads of the A, b assembly (ThreadsConstructA); set through orc_set_marg_threads
 
 

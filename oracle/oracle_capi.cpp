@@ -157,6 +157,9 @@ void orc_set_marg_threads(int n) { g_marg_threads = n < 1 ? 1 : n; }
 // test switch: relative truncation of the kept block's spectrum (0 = the reference's absolute 1e-8), see marginalization.cpp
 void orc_set_marg_truncation(double rel) { g_marg_rel_eps = rel > 0.0 ? rel : 0.0; }
 
+// test switch: summation order of the last Schur complement of the marginalisation, see marginalization.cpp
+void orc_set_marg_reverse_sums(int mode) { g_marg_reverse_sums = mode; }
+
 // windows fanned over `threads` host threads (cpu_baseline leg of bench.py)
 int orc_solve_windows(int n, vpl_window* w, const vpl_ba_options* opt, vpl_prior* priors_out, vpl_solve_report* reps,
                       int threads) {

@@ -1,0 +1,37 @@
+"""Randomised shapes against the oracle (tools/fuzz_parity.py, a short run of it): counts of points and lines from 0 to the
+context's capacity, track lengths 2..11 trimmed per track, dropped tracks, untriangulated lines, every marginalisation mode,
+extrinsic fixed or free, 1..8 iterations, several shapes in one batch, and half of the batches solved again one keyframe on
+with the prior of the first solve (each side carrying its own).
+
+What the full sweeps of round 4 gave (3 seeds, 1 512 windows, gpurun_out/r4_fuzz*.log, summary in profiles/r4/README.md):
+* without an incoming prior: 1 120 windows, every one inside BASELINE.json's bar (1e-4 m, 1e-6 rad, the oracle's iteration and
+  accepted-step counts) except three that do not determine their states (the oracle moves as far from itself when its
+  initial positions are shifted by 1e-10 m);
+* behind a prior of its own making: 392 windows, 15 outside the bar by more than ten times the oracle's distance from
+  itself -- windows with few features whose prior has eigenvalues next to the reference's 1e-8 cut
+  (marginalization_factor.cpp:349-357) while the IMU rows of the marginalisation carry entries of 5e14: which of those
+  directions the reference keeps is decided by rounding of the Schur complement (reversing ONE of its inner sums in the oracle
+  moves such a window by 5e-5 m), and the device's pivoted Cholesky decides otherwise.  With the SAME prior on both sides every
+  one of them agrees to 1e-9 m (tools/dbg_fuzz_case.py).  DESIGN.md section 7.
+"""
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+
+
+@pytest.mark.gpu
+def test_random_shapes_against_the_oracle():
+    import fuzz_parity
+    lines = []
+    res = fuzz_parity.run(14, 8, 11, out=lines.append)
+    tail = "\n".join(l for l in lines if "MISS" in l or "REFUSED" in l or "fuzz_parity" in l)
+    assert res["total_first"] == 14 * 8
+    assert res["miss_first"] == 0, tail
+    # chained windows: see the header -- a few per cent of weakly determined ones may leave the bar; more would be a regression
+    chained = res["total"] - res["total_first"]
+    assert chained >= 16
+    assert res["miss"] - res["miss_first"] <= max(2, chained // 10), tail

@@ -226,3 +226,19 @@ def test_long_tracks_give_the_steady_state_prior():
             prior = q
             assert rep.prior_n == want, (graft, k, rep.prior_n)
     assert v.workload.steady_point_obs(cfg) == 54 * 6 + 6 * 11
+
+
+def test_landmark_block_without_information_does_not_stop_the_marginalisation():
+    """A line that starts in frame 0 and is seen twice has one 2-row factor in the marginalisation for its 4 degrees of
+    freedom: the landmark block is singular.  Eigen's MatrixXd::inverse() (PartialPivLU, marginalization_factor.cpp:311) notes
+    the zero pivot and returns inf / NaN; the restatement used to return an empty matrix and read through it (found by
+    tools/fuzz_parity.py).  The window is outside the contract of vpl_window (lines pass LINE_MIN_OBS = 5, parameters.h:23);
+    what is asserted is that the oracle comes back."""
+    opt = v.default_options()
+    opt.num_iterations = 1
+    cfg = v.workload.config(17, 128, False)
+    cfg.track_len = 2
+    w = v.workload.generate(v.workload.seed_for(6, 6005), cfg, 0.0)      # (segmentation fault before the fix)
+    o.preintegrate_windows([w], opt)
+    pri, rep = o.solve_window(w, opt)
+    assert rep.iterations == 1 and pri.n > 0
