@@ -253,6 +253,13 @@ void ed_route(const short* g, const uint8_t* dir, int W, int H, const unsigned* 
     edge[idx] = 0;   // the anchor is un-marked so that the second walk starts on it (:326, :535)
     wk.walk(x, y, horiz ? LeftDir : UpDir, sx, sy);
     if ((int)(fx.size() + sx.size()) < minLineLen + 1) continue;   // short edge dropped (its pixels stay marked)
+    // The reference's buffers hold W H / 5 pixels per part and W H / 100 edges (:92-93, :113-118); beyond that it writes past
+    // them and reports "Edge drawing Error" afterwards (:655-665).  Defined here (and on the device, k_ed_route): an edge that
+    // does not fit is dropped like a short one.  Frames of noise with a small minLineLen get there (tools/fuzz_frontend.py).
+    {
+      const size_t cap = (size_t)W * H / 5, capEdges = cap / 20;
+      if (sId.size() >= capEdges || xC.size() + fx.size() + sx.size() - 1 > 2 * cap || fx.size() > cap) continue;
+    }
     sId.push_back((unsigned)xC.size());
     for (int k = (int)fx.size() - 1; k >= 0; --k) { xC.push_back(fx[k]); yC.push_back(fy[k]); }   // first part reversed
     for (size_t k = 1; k < sx.size(); ++k) { xC.push_back(sx[k]); yC.push_back(sy[k]); }          // second part without the anchor

@@ -170,3 +170,35 @@ def test_gpu_edlines_other_frame_sizes():
         if (W, H) == (1024, 768):
             assert len(lo) > 50 and fe.route_stats(0)["tile_loads"] > 0      # strip loads happened
         fe.close()
+
+
+def test_more_edges_than_the_reference_buffers_hold():
+    """Noise with a small minLineLen produces more edge chains than maxNumOfEdge = W H / 100 (edline_detector.cpp:92-93, :117): the
+    reference writes past its buffers and reports the error afterwards (:655-659).  Here (oracle and device alike) an edge that
+    does not fit is dropped; the oracle used to hand more chain starts to the caller than the caller's buffer held (found by
+    tools/fuzz_frontend.py)."""
+    W, H = 333, 200
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (H, W)).astype(np.float64)
+    for ax in (0, 1):                                  # 3-tap box blur, borders repeated: noise turned into small blobs
+        pad = np.concatenate([np.take(a, [0], ax), a, np.take(a, [-1], ax)], ax)
+        a = (np.take(pad, range(0, pad.shape[ax] - 2), ax) + np.take(pad, range(1, pad.shape[ax] - 1), ax)
+             + np.take(pad, range(2, pad.shape[ax]), ax)) / 3.0
+    img = np.ascontiguousarray((255 * (a - a.min()) / (a.max() - a.min())).astype(np.uint8))
+    lines, st = o.edlines(img, grad_th=16, anchor_th=2, scan=2, min_len=8, want_stages=True)
+    cap_edges = (W * H // 5) // 20
+    assert len(st["sid"]) - 1 == cap_edges            # the buffer is full, not overrun (more chains were found)
+    assert st["sid"][-1] == len(st["chain_x"]) <= 2 * (W * H // 5)
+
+
+@pytest.mark.gpu
+def test_gpu_frontend_random_sizes_contents_parameters():
+    """a short run of tools/fuzz_frontend.py (its header lists what is drawn): every stage, the line lists in order, LineFilter
+    and the matches identical to the oracle.  Round 4's sweeps: 260 trials over three seeds, no difference
+    (gpurun_out/r4_fuzzfe*.log)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(HERE), "tools", "fuzz_frontend.py")
+    r = subprocess.run([sys.executable, tool, "24", "17"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "24 trials" in r.stdout
