@@ -35,3 +35,17 @@ def test_random_shapes_against_the_oracle():
     chained = res["total"] - res["total_first"]
     assert chained >= 16
     assert res["miss"] - res["miss_first"] <= max(2, chained // 10), tail
+
+
+@pytest.mark.gpu
+def test_random_shapes_through_the_map_maintenance_calls():
+    """a short run of tools/fuzz_map.py: vpl_ba_triangulate_lines, vpl_ba_only_line_opt (+ removeLineOutlier),
+    vpl_ba_triangulate_points and vpl_ba_slide_window on windows of random shape (0..256 points, 0..128 lines, track lengths
+    1..11, tracks born in the newest frame, unset depths, untriangulated lines, both marginalisation modes) against the oracle
+    with the bars of tests/test_line_map.py / tests/test_slide_window.py.  Round 4's sweeps: 3 x 40 batches of 6 windows, no
+    difference (gpurun_out/r4_fuzzmap*.log)."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(HERE), "tools", "fuzz_map.py")
+    r = subprocess.run([sys.executable, tool, "10", "6", "23"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "10 batches" in r.stdout
