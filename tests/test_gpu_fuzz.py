@@ -49,3 +49,15 @@ def test_random_shapes_through_the_map_maintenance_calls():
     r = subprocess.run([sys.executable, tool, "10", "6", "23"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "10 batches" in r.stdout
+
+
+@pytest.mark.gpu
+def test_random_maps_tiles_and_line_sets_through_preparation_and_vanishing_points():
+    """a short run of tools/fuzz_frontend2.py: cv::remap + CLAHE on frame sizes that are no multiple of 4 or of the tile grid,
+    with maps that leave the frame, clip limits 0.5..40 and tile grids 1..12 x 1..12; vanishing points on Manhattan scenes,
+    random segments, parallel lines, one to three lines.  Bit for bit.  Round 4's sweeps: 220 trials, no difference."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(HERE), "tools", "fuzz_frontend2.py")
+    r = subprocess.run([sys.executable, tool, "16", "29"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "16 trials" in r.stdout
