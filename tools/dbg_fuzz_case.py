@@ -1,5 +1,5 @@
 """Diagnostic (GPU box): one batch of tools/fuzz_parity.py again, the chained stage with the priors swapped between the sides.
-    python tools/dbg_fuzz_case.py <batch> [seed=1] [per=8]"""
+    python tools/dbg_fuzz_case.py <batch> [seed=1] [per=8] [second_new]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -29,7 +29,14 @@ for b in range(target + 1):
     pg, rg = ctx.solve_windows(wg, opt)
     keep = (Prior * per)(); C.memmove(keep, pg, C.sizeof(keep))
     pcs = [o.solve_window(wc[i], opt)[0] for i in range(per)]
-    w2 = [f.draw_window(np.random.default_rng(7000 + 100 * b + i), 1000 * b + 500 + i, 0.37 * (b * per + i) + 0.1)[0] for i in range(per)]
+    second_new = len(sys.argv) > 4 and sys.argv[4] == "second_new"
+    if second_new:     # stage 2 of the sweep: the same frames again behind the prior, MARGIN_SECOND_NEW
+        w2 = [f.draw_window(np.random.default_rng(9000 + 100 * b + i), 1000 * b + 700 + i, 0.37 * (b * per + i))[0] for i in range(per)]
+        opt0 = opt
+        opt = v.default_options()
+        opt.num_iterations, opt.estimate_extrinsic, opt.marginalization_flag = opt0.num_iterations, opt0.estimate_extrinsic, v.MARGIN_SECOND_NEW
+    else:
+        w2 = [f.draw_window(np.random.default_rng(7000 + 100 * b + i), 1000 * b + 500 + i, 0.37 * (b * per + i) + 0.1)[0] for i in range(per)]
     o.preintegrate_windows(w2, opt)
     def run_dev(priors):
         g = [w.copy() for w in w2]

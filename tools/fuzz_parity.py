@@ -1,7 +1,7 @@
 """Randomised parity sweep (GPU box): the HIP solve against the oracle on windows whose SHAPE is drawn at random --
 counts of points / lines, VP observations on or off, track lengths 2..11 (lines 5..11) trimmed per track, tracks dropped, lines marked
 untriangulated, every marginalisation mode, extrinsic fixed or free, 1..8 iterations, with and without a prior from a preceding
-window, several shapes in ONE batch.  Prints one line per window and a summary.
+window (one keyframe on with MARGIN_OLD; the same frames again with MARGIN_SECOND_NEW), several shapes in ONE batch.  Prints one line per window and a summary.
 
 The bar is BASELINE.json's: 1e-4 m / 1e-6 rad and the oracle's iteration / accepted-step counts.  Shapes drawn at random include
 windows that do not determine their states to that accuracy (one point and five lines; a prior whose weak eigenvalues sit
@@ -155,6 +155,36 @@ def run(nb, per, seed, out=print):
                     e = pose_err(c2r, c2[i])
                     sb = (max(sb[0], e[0]), max(sb[1], e[1]))
                 line = report(b, i, ("chained",), opt, 1, g2[i], c2[i], rg2[i], rc, pg2[i], pc,
+                              (max(sa[0] - 1e-10 * np.sqrt(3.0), sb[0]) + 1e-10 * np.sqrt(3.0), max(sa[1], sb[1])), out)
+                total += 1; bad += line[0]; ill += line[3]; worst = [max(worst[0], line[1]), max(worst[1], line[2])]
+        if opt.marginalization_flag == v.MARGIN_OLD and not chained:
+            # MARGIN_SECOND_NEW behind a prior: the same frames again (another draw of the noise and of the tracks) with the
+            # prior of the first solve; the second-newest frame leaves (estimator.cpp:1385-1453)
+            opt3 = v.default_options()
+            opt3.num_iterations, opt3.estimate_extrinsic = opt.num_iterations, opt.estimate_extrinsic
+            opt3.marginalization_flag = v.MARGIN_SECOND_NEW
+            w3 = []
+            for i in range(per):
+                w, _ = draw_window(np.random.default_rng(9000 + 100 * b + i), 1000 * b + 700 + i, 0.37 * (b * per + i))
+                w3.append(w)
+            o.preintegrate_windows(w3, opt3)
+            keep = (Prior * per)()
+            C.memmove(keep, pg, C.sizeof(keep))
+            g3, c3 = [w.copy() for w in w3], [w.copy() for w in w3]
+            for i in range(per):
+                g3[i].prior = keep[i] if keep[i].n > 0 else None
+                c3[i].prior = pcs[i] if pcs[i].n > 0 else None
+            pg3, rg3 = ctx.solve_windows(g3, opt3)
+            for i in range(per):
+                pc, rc = o.solve_window(c3[i], opt3)
+                sa, sb = (0.0, 0.0), (0.0, 0.0)
+                c3s = shifted(w3[i]); c3s.prior = pcs_s[i] if pcs_s[i].n > 0 else None
+                o.solve_window(c3s, opt3); sa = pose_err(c3s, c3[i])
+                for prv in pcs_r[i]:
+                    c3r = w3[i].copy(); c3r.prior = prv if prv.n > 0 else None
+                    o.solve_window(c3r, opt3)
+                    e = pose_err(c3r, c3[i]); sb = (max(sb[0], e[0]), max(sb[1], e[1]))
+                line = report(b, i, ("second-new",), opt3, 2, g3[i], c3[i], rg3[i], rc, pg3[i], pc,
                               (max(sa[0] - 1e-10 * np.sqrt(3.0), sb[0]) + 1e-10 * np.sqrt(3.0), max(sa[1], sb[1])), out)
                 total += 1; bad += line[0]; ill += line[3]; worst = [max(worst[0], line[1]), max(worst[1], line[2])]
     ctx.close()
