@@ -8,6 +8,6 @@ import vplines_slam_amd._build as b; b.build_hip(verbose=False, force=True)"
   for k in 1 2; do
     timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/ab.json 2>/dev/null
     python -c "
-import json; d=json.load(open('gpurun_out/ab.json')); k=d['kernels_ms_per_step']; print('[$V]', round(d['value']), 'k_solve', round(k['k_solve'],4), 'k_lin', round(k['k_lin'],4), 'k_cost', round(k['k_cost'],4))"
+import json; d=json.load(open('gpurun_out/ab.json')); k=d['kernels_ms_per_step']; print('[$V]', round(d['value']), ' '.join('%s %.4f' % (n, t) for n, t in sorted(k.items(), key=lambda x: -x[1])[:9]))"
   done
 done

@@ -667,7 +667,13 @@ inline size_t schur_smem(int maxP, int maxL, int ntc = 5) {
 constexpr int DN = 90;                       // dense dims (rhs row = DN)
 constexpr int DNT = 6;                       // 16x16 tiles per dimension of the dense system (96 >= 91)
 constexpr int DNAP = DNT * (DNT + 1) / 2 * 256;   // tile-major lower storage (5376 doubles)
+#ifdef VPL_CHOL_OCC3                         // A/B switch: three work-groups per CU (53 KB of LDS, 168 registers)
+constexpr int XLD = 66;
+constexpr int CHOL_MIN_WAVES = 3;
+#else
 constexpr int XLD = 72;                      // row stride of the chains' X rows in LDS (64 lanes + 8)
+constexpr int CHOL_MIN_WAVES = 2;
+#endif
 constexpr int XROWS_A = 36, XROWS_B = 48;    // 4 x 9 rows ; 5 x 9 rows padded to a multiple of 4
 
 __device__ __forceinline__ int chain_frame(int ch, int b) { return ch == 0 ? 1 + b : 10 - b; }
@@ -1158,7 +1164,7 @@ __device__ __forceinline__ void chol_body(const DevBatch& B, const int w, double
   VPL_STAMP(B, w, 13);
 }
 #undef Xs
-__global__ __launch_bounds__(CHOL_THREADS, 2) void k_chol(DevBatch B) {
+__global__ __launch_bounds__(CHOL_THREADS, CHOL_MIN_WAVES) void k_chol(DevBatch B) {
   extern __shared__ double sm[];
   chol_body(B, ordered_window(B), sm);
 }
