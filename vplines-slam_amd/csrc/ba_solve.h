@@ -1135,7 +1135,10 @@ __device__ __forceinline__ void cost_body(const DevBatch& B, const int w) {
 }
 // two workgroups per CU (4 waves per SIMD, <= 128 VGPRs): the kernel is a latency chain per lane, occupancy is what helps
 // (0.327 -> 0.283 ms per step against one workgroup per CU at 136 VGPRs)
-__global__ __launch_bounds__(COST_THREADS, 4) void k_cost(DevBatch B) {
+#ifndef VPL_COST_WAVES
+#define VPL_COST_WAVES 4          // A/B switch, as VPL_BACK_WAVES
+#endif
+__global__ __launch_bounds__(COST_THREADS, VPL_COST_WAVES) void k_cost(DevBatch B) {
   const int w = ordered_window(B);
   cost_body(B, w);
   // order of the next iteration: windows that will linearise / factor again go to the front of the list, the others (step

@@ -1425,7 +1425,10 @@ __device__ __forceinline__ void back_body(const DevBatch& B, const int w, double
     tr->num_invalid = 0;
   }
 }
-__global__ __launch_bounds__(BACK_THREADS, 2) void k_back(DevBatch B) {
+#ifndef VPL_BACK_WAVES
+#define VPL_BACK_WAVES 2          // A/B switch: waves per SIMD the register allocation of k_back is held to
+#endif
+__global__ __launch_bounds__(BACK_THREADS, VPL_BACK_WAVES) void k_back(DevBatch B) {
   extern __shared__ double sm[];
   back_body(B, ordered_window(B), sm);
 }
