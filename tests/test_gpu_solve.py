@@ -755,3 +755,43 @@ def test_mixed_track_lengths_take_the_narrow_view_and_match_the_oracle():
         assert rep_w[i].iterations == rep_g[i].iterations and rep_w[i].num_successful_steps == rep_g[i].num_successful_steps
         dp, dr = pose_err(wg[i], ww[i])
         assert dp <= 1e-7 and dr <= 1e-8, (i, dp, dr)
+
+
+def test_nan_among_the_inputs_fails_that_window_as_ceres_does_and_no_other(gpu_ctx):
+    """A NaN in an observation, a depth, a state or an IMU sample: ceres rejects the initial point ("Initial residual and
+    Jacobian evaluation failed"), Solve returns FAILURE with an empty iteration list, and optimizationwithLine goes on to
+    double2vector2 and the marginalisation with the states as they were.  The device reports the same (termination 2,
+    iterations = accepted steps = -1, costs 0), leaves that window's states where the oracle leaves them, and the clean
+    windows of the batch are solved as if the others were not there."""
+    opt = v.default_options()
+    cfg = v.workload.config(40, 12, True)
+    kinds = ("point_obs", "line_obs", "clean", "inv_depth", "imu", "pose")
+    ws = []
+    for i, what in enumerate(kinds):
+        w = v.workload.generate(v.workload.seed_for(3, 7 + i), cfg, 0.1 * i)
+        if what == "imu":
+            w.extra["imu_samples"][3, 2, 1] = np.nan
+        ws.append(w)
+    o.preintegrate_windows(ws, opt)
+    ws[0].point_obs[5, 0] = np.nan
+    ws[1].line_obs[7, 2] = np.nan
+    ws[3].inv_depth[3] = np.nan
+    ws[5].pose[4, 1] = np.nan
+    wg, wc = [w.copy() for w in ws], [w.copy() for w in ws]
+    pri_g, rep_g = gpu_ctx.solve_windows(wg, opt)
+    for i, what in enumerate(kinds):
+        pri_c, rep_c = o.solve_window(wc[i], opt)
+        got = (rep_g[i].iterations, rep_g[i].num_successful_steps, rep_g[i].termination)
+        assert got == (rep_c.iterations, rep_c.num_successful_steps, rep_c.termination), what
+        if what == "clean":
+            assert rep_c.iterations == opt.num_iterations and rep_c.termination == 0
+            dp, dr = pose_err(wg[i], wc[i])
+            assert dp <= POS_TOL and dr <= ROT_TOL
+            continue
+        assert (rep_c.iterations, rep_c.num_successful_steps, rep_c.termination) == (-1, -1, 2), what
+        assert rep_g[i].initial_cost == 0.0 and rep_g[i].final_cost == 0.0
+        assert np.array_equal(np.isfinite(wg[i].pose), np.isfinite(wc[i].pose)), what
+        fin = np.isfinite(wc[i].pose)
+        assert np.abs(wg[i].pose[fin] - wc[i].pose[fin]).max() <= 1e-12, what
+        assert np.allclose(wg[i].speed_bias, wc[i].speed_bias, rtol=0, atol=1e-12, equal_nan=True), what
+        assert pri_g[i].n == pri_c.n

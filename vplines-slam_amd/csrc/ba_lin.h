@@ -1072,6 +1072,14 @@ __device__ __forceinline__ void lin_body(const DevBatch& B, const int w, double*
     tr->x_cost = cost;
     if (tr->iter == 0) tr->initial_cost = cost;
     tr->fresh_lin = 1;
+    // A NaN / inf among the inputs: ceres' evaluator rejects the initial point ("Initial residual and Jacobian evaluation
+    // failed", trust_region_minimizer.cc IterationZero) and Solve returns FAILURE with an empty iteration list -- the
+    // reference goes on to double2vector2 and the marginalisation with the states as they were.  Reported the same way:
+    // termination 2, iterations = successful steps = -1 (size of the list - 1), costs 0; every later kernel of the solve
+    // leaves a window whose status is set.
+    if (tr->iter == 0 && tr->num_successful == 0 && !isfinite(cost)) {
+      tr->status = 2; tr->iter = -1; tr->num_successful = -1; tr->x_cost = 0.0; tr->initial_cost = 0.0;
+    }
   }
 }
 template <int MODE>
