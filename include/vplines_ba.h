@@ -222,6 +222,12 @@ int vpl_line_orth_plus(vpl_ctx* ctx, int n, const double* x, const double* delta
  *   upload  : host windows -> device SoA        (PCIe, not in the timed region)
  *   solve   : everything on device, no host round trip, asynchronous on the stream
  *   download: device -> host windows / priors / reports
+ * Refusals (VPL_E_INVALID / VPL_E_CAPACITY, message in vpl_last_error): more windows / points / observations / lines than the
+ * context was created for, a track that leaves the window, a point track of one observation, an unknown marginalization_flag,
+ * a prior of impossible size.  A refusal that comes after the upload has begun to rewrite the batch leaves the context WITHOUT
+ * a batch: solve / download / reset_state return VPL_E_INVALID until the next successful upload.
+ * A window with a NaN / inf among its inputs is not refused: its solve fails as ceres fails it (report: termination 2,
+ * iterations = num_successful_steps = -1, costs 0; states untouched), the other windows of the batch are unaffected.
  */
 int vpl_ba_upload(vpl_ctx* ctx, int n_windows, const vpl_window* windows, const vpl_ba_options* opt);
 /* The next windows of a sequence: as vpl_ba_upload, but window i takes the prior that the context's PREVIOUS solve left for

@@ -795,3 +795,79 @@ def test_nan_among_the_inputs_fails_that_window_as_ceres_does_and_no_other(gpu_c
         assert np.abs(wg[i].pose[fin] - wc[i].pose[fin]).max() <= 1e-12, what
         assert np.allclose(wg[i].speed_bias, wc[i].speed_bias, rtol=0, atol=1e-12, equal_nan=True), what
         assert pri_g[i].n == pri_c.n
+
+
+def test_refusals_of_the_boundary_leave_the_context_usable():
+    """What vpl_ba_upload refuses (include/vplines_ba.h: VPL_E_INVALID / VPL_E_CAPACITY with a message), each followed by a solve
+    that must still work: more windows than the context holds, more points / point observations / lines than it holds, a
+    track that leaves the window, a point seen once, an unknown marginalisation flag, a prior with impossible sizes, a solve
+    or download with nothing uploaded."""
+    from vplines_slam_amd.capi import Prior
+    opt = v.default_options()
+    ctx = v.Context(device=0, max_windows=2, max_points=64, max_point_obs=400, max_lines=16, max_line_obs=100)
+    with pytest.raises(RuntimeError):
+        ctx.solve()                                       # nothing uploaded
+    with pytest.raises(RuntimeError):
+        ctx.download()
+
+    def good(i=0, P=40, L=12):
+        w = v.workload.generate(v.workload.seed_for(3, 50 + i), v.workload.config(P, L, True), 0.1 * i)
+        o.preintegrate_windows([w], opt)
+        return w
+
+    def still_works():
+        w = good(9)
+        c = w.copy()
+        _, rg = ctx.solve_windows([w], opt)
+        _, rc = o.solve_window(c, opt)
+        assert rg[0].iterations == rc.iterations and pose_err(w, c)[0] <= POS_TOL
+
+    cases = []
+    cases.append(("three windows", lambda: [good(0), good(1), good(2)], opt))
+    cases.append(("more points than max_points", lambda: [good(0, P=80)], opt))
+    def long_tracks():       # 64 tracks of 6 observations = 384 fit into the context's 400; tracks of 8 do not
+        cfg = v.workload.config(64, 4, True)
+        cfg.track_len = 8
+        w = v.workload.generate(v.workload.seed_for(3, 77), cfg, 0.0)
+        o.preintegrate_windows([w], opt)
+        return [w]
+    cases.append(("more point observations than max_point_obs", long_tracks, opt))
+    cases.append(("more lines than max_lines", lambda: [good(0, L=20)], opt))
+
+    def leaves_window(w):
+        w.point_start[3] = 9
+        w.point_nobs[3] = 6
+    cases.append(("track leaves the window", lambda: [_with(good(0), leaves_window)], opt))
+
+    def seen_once(w):
+        n = w.point_nobs.copy()
+        off = np.concatenate([[0], np.cumsum(n)])
+        keep = np.ones(len(w.point_obs), bool)
+        keep[off[2] + 1:off[3]] = False
+        w.point_obs = w.point_obs[keep]
+        w.point_nobs[2] = 1
+    cases.append(("point seen once", lambda: [_with(good(0), seen_once)], opt))
+    bad_flag = v.default_options()
+    bad_flag.marginalization_flag = 7
+    cases.append(("unknown marginalisation flag", lambda: [good(0)], bad_flag))
+
+    def bad_prior(w):
+        p = Prior()
+        p.n, p.n_blocks = 500, 3
+        w.prior = p
+    cases.append(("prior of 500 dims", lambda: [_with(good(0), bad_prior)], opt))
+    for name, make, op in cases:
+        ws = make()
+        with pytest.raises(RuntimeError):
+            ctx.solve_windows(ws, op)
+        if name in ("track leaves the window", "point seen once", "prior of 500 dims"):
+            # refused half way: the context holds no batch now (it must not solve the new size on the old device data)
+            with pytest.raises(RuntimeError):
+                ctx.solve()
+        still_works()
+    ctx.close()
+
+
+def _with(w, f):
+    f(w)
+    return w

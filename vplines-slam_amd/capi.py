@@ -246,6 +246,7 @@ class Context:
         if stream is not None:
             self.set_stream(stream)
         self._cw = None
+        self._windows = []
 
     def close(self):
         if self.h:
@@ -386,6 +387,8 @@ class Context:
 
     def download(self):
         n = len(self._windows)
+        if n == 0 or self._cw is None:
+            self._check(self.lib.vpl_ba_download(self.h, 0, None, None, None), "vpl_ba_download")   # (refused: nothing uploaded)
         priors = (Prior * n)()
         reports = (SolveReport * n)()
         self._check(self.lib.vpl_ba_download(self.h, n, self._cw, priors, reports), "vpl_ba_download")

@@ -182,6 +182,7 @@ struct vpl_ctx {
   // results into the caller's arrays) of the call that was enqueued last; run by vpl_ba_collect or by the next call that
   // touches the batch
   std::function<int()> pending;
+  bool upload_open = false;                      // an upload has started to rewrite the host tables of the batch and has not finished
   bool prior_resident = false;                   // the last solve / marginalisation of the uploaded batch left its priors in mg_* (vpl_ba_upload_chained)
   int prior_resident_nW = 0;
   double odo_ms[3] = {0, 0, 0};                  // vpl_ba_debug_odometry_ms
@@ -652,7 +653,20 @@ int vpl_line_orth_plus(vpl_ctx* c, int n, const double* x, const double* delta, 
 }
 
 // ---- window batch: upload / solve / download ------------------------------------------------------------
+static int upload_body(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt, bool all_lines, bool chained);
+// An upload that is refused half way (a track outside the window in the third window, a prior of impossible size) has already
+// rewritten part of the batch's host tables and its size: the context then holds NO batch -- solve / download / reset return
+// VPL_E_INVALID until the next successful upload -- instead of running the new size on the old device data.  A refusal before
+// anything was touched (too many windows, unknown flag, no resident prior for a chained upload) leaves the previous batch as it was.
 static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt, bool all_lines, bool chained = false) {
+  const int rc = upload_body(c, nW, win, opt, all_lines, chained);
+  if (c) {
+    if (rc != VPL_OK && c->upload_open) { c->nW = 0; c->prior_resident = false; }
+    c->upload_open = false;
+  }
+  return rc;
+}
+static int upload_body(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_options* opt, bool all_lines, bool chained) {
   if (!c || !win || !opt || nW < 1) return VPL_E_INVALID;
   if (nW > c->maxW) return fail(c, VPL_E_CAPACITY, "more windows than max_windows");
   if (opt->marginalization_flag != VPL_MARGIN_OLD && opt->marginalization_flag != VPL_MARGIN_SECOND_NEW &&
@@ -668,6 +682,7 @@ static int upload_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl_ba_o
   c->prior_resident = false;
   if (c->leg_timing) HIPCHK(c, hipEventRecord(c->leg_ev[0], c->stream));
   drop_graph(c);
+  c->upload_open = true;
   c->opt = *opt;
   c->nW = nW;
   DevBatch& B = c->B;
