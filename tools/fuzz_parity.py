@@ -7,7 +7,8 @@ The bar is BASELINE.json's: 1e-4 m / 1e-6 rad and the oracle's iteration / accep
 windows that do not determine their states to that accuracy (one point and five lines; a prior whose weak eigenvalues sit
 next to the reference's 1e-8 cut while the IMU rows of the marginalisation carry entries of 5e14): there the ORACLE does not
 reproduce itself under changes that are rounding and nothing else.  Every window is therefore solved by the oracle four times:
-as drawn; with the initial positions of the frames moved by 1e-10 m each (at random); and with the products of the
+as drawn; with the initial positions of the frames moved by 1e-10 m each and every inverse depth and Pluecker coordinate
+by 1e-10 of itself (at random); and with the products of the
 marginalisation's Schur complements summed differently (oracle/marginalization.cpp, g_marg_reverse_sums: 1 = the last one's
 inner sums backwards, 2 = both accumulated in long double and rounded once: the same terms, another rounding -- for a
 chained window the first solve runs with the switch and hands its prior on).  `sens` is the largest distance of a variant
@@ -198,7 +199,14 @@ def shifted(w, d=1e-10):
     """every frame's initial position moved by its own offset of up to d per axis (a common offset would be a gauge
     motion: the answer moves with it and nothing is learnt)"""
     s = w.copy()
-    s.pose[:, :3] += d * np.random.default_rng(12345).uniform(-1.0, 1.0, (NF, 3))
+    r = np.random.default_rng(12345)
+    s.pose[:, :3] += d * r.uniform(-1.0, 1.0, (NF, 3))
+    # ... and the landmarks by the same relative amount: a window whose lines are barely determined keeps its poses to 1e-9
+    # through several iterations while the line parameters (and with them the cost, then an accept / reject decision) drift
+    if len(s.inv_depth):
+        s.inv_depth *= 1.0 + d * r.uniform(-1.0, 1.0, len(s.inv_depth))
+    if len(s.line_plk):
+        s.line_plk *= 1.0 + d * r.uniform(-1.0, 1.0, s.line_plk.shape)
     return s
 
 
