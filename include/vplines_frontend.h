@@ -74,6 +74,10 @@ int vpl_fe_kernel_times(vpl_fe_ctx* ctx, int* count, const char** names, double*
 /* three-phase form (inputs resident in HBM while timing) */
 int vpl_edlines_upload(vpl_fe_ctx* ctx, int n_images, const uint8_t* images /* [n][H][W] */);
 int vpl_edlines_detect(vpl_fe_ctx* ctx, const vpl_edline_param* param);   /* enqueue; asynchronous */
+/* The reference collects lines in a std::vector; here a frame holds max_lines_per_image of them (vpl_fe_create).  A frame in
+ * which the detector found more is refused: VPL_E_CAPACITY with the frame and its count in vpl_fe_last_error -- from this call
+ * and from vpl_match_download when the match took its lines from the detector (vpl_match_from_detected); `lines` / `counts`
+ * are written all the same (the lines that arrived first, in no defined selection). */
 int vpl_edlines_download(vpl_fe_ctx* ctx, int n_images, vpl_line* lines /* [n][max_lines] */, int* counts /* [n] */);
 
 /* EDline(image, lines, smoothed) with the flag as an argument.  smoothed == 0: the Gaussian pre-blur of EdgeDrawing

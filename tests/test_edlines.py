@@ -202,3 +202,28 @@ def test_gpu_frontend_random_sizes_contents_parameters():
     r = subprocess.run([sys.executable, tool, "24", "17"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "24 trials" in r.stdout
+
+
+@pytest.mark.gpu
+def test_gpu_more_lines_than_the_table_holds_is_refused():
+    """the reference's line list is a std::vector; the device's table has max_lines_per_image rows per frame.  A frame with more
+    lines is refused at the download (which lines were kept is not defined), for the detector and for a match fed from it;
+    the context goes on working."""
+    fe = v.frontend.FrontendContext(device=0, max_images=2, width=752, height=480, max_lines=64)
+    fe.match_reserve(1, 4096)
+    with pytest.raises(RuntimeError, match="lines found"):
+        fe.detect_batch(np.stack(IMGS))                    # ~230 lines per frame
+    fe.upload(np.stack(IMGS))
+    fe.detect()
+    fe.match_from_detected([(0, 1)])
+    fe.match_run()
+    fe.synchronize()
+    with pytest.raises(RuntimeError, match="lines found"):
+        fe.match_download()
+    p = v.frontend.default_param()
+    p.minLineLen = 120                                      # few long lines: fits
+    out = fe.detect_batch(np.stack(IMGS), p)
+    for i in range(2):
+        lo = o.edlines(IMGS[i], min_len=120)
+        assert 0 < len(lo) <= 64 and len(out[i]) == len(lo)
+    fe.close()

@@ -33,6 +33,7 @@ struct vpl_fe_ctx {
   uint8_t* d_blur = nullptr;          // [maxN][H][W] copy of the blurred frames (vpl_fe_keep_blurred; tests)
   vpl_line* d_sorted = nullptr;       // [maxN][maxLines] the detected lines in the reference's order (k_ed_sort_lines)
   int* d_sortedCnt = nullptr;         // [maxN]
+  bool matchFromDetected = false;     // the pending match took its lines from the detector's table (overflow is checked at its download)
   // image preparation (remap + CLAHE)
   uint8_t *d_raw = nullptr, *d_mid = nullptr, *d_lut = nullptr;
   float *d_mapx = nullptr, *d_mapy = nullptr;
@@ -413,6 +414,20 @@ int vpl_edlines_debug_blurred(vpl_fe_ctx* c, int img, uint8_t* out) {
   return VPL_OK;
 }
 
+// The detector's line table holds max_lines_per_image lines per frame; the reference's std::vector has no such limit.  A frame
+// with more lines keeps the ones that arrived first (the order of arrival is not defined), so the result is refused, loudly,
+// wherever it reaches the host: found[i] = lines the detector found in frame i.
+static int lines_overflow_check(vpl_fe_ctx* c, int n) {
+  std::vector<int> found(n);
+  FECHK(c, hipMemcpyAsync(found.data(), c->B.nLines, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  FECHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; ++i)
+    if (found[i] > c->maxLines)
+      return fe_fail(c, VPL_E_CAPACITY, "frame " + std::to_string(i) + ": " + std::to_string(found[i]) + " lines found, max_lines_per_image is " +
+                                            std::to_string(c->maxLines));
+  return VPL_OK;
+}
+
 int vpl_edlines_download(vpl_fe_ctx* c, int n, vpl_line* lines, int* counts) {
   if (!c || n != c->n || !lines || !counts) return VPL_E_INVALID;
   FECHK(c, hipSetDevice(c->device));
@@ -422,7 +437,7 @@ int vpl_edlines_download(vpl_fe_ctx* c, int n, vpl_line* lines, int* counts) {
   FECHK(c, hipMemcpyAsync(counts, c->d_sortedCnt, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   FECHK(c, hipMemcpyAsync(lines, c->d_sorted, (size_t)n * ML * sizeof(vpl_line), hipMemcpyDeviceToHost, c->stream));
   FECHK(c, hipStreamSynchronize(c->stream));
-  return VPL_OK;
+  return lines_overflow_check(c, n);
 }
 
 int vpl_edlines_detect_batch_ex(vpl_fe_ctx* c, int n, const uint8_t* images, const vpl_edline_param* p, int smoothed,
@@ -569,6 +584,7 @@ int vpl_match_upload(vpl_fe_ctx* c, int n_pairs, const int* ref_image, const int
     return VPL_E_INVALID;
   if (n_pairs > c->maxPairs) return fe_fail(c, VPL_E_CAPACITY, "more pairs than max_pairs");
   if (c->n < 1) return fe_fail(c, VPL_E_INVALID, "no images uploaded");
+  c->matchFromDetected = false;
   for (int i = 0; i < n_pairs; ++i) {
     if (ref_image[i] < 0 || ref_image[i] >= c->n || cur_image[i] < 0 || cur_image[i] >= c->n)
       return fe_fail(c, VPL_E_INVALID, "pair names an image that was not uploaded");
@@ -600,6 +616,7 @@ int vpl_match_from_detected(vpl_fe_ctx* c, int n_pairs, const int* ref_image, co
   for (int i = 0; i < n_pairs; ++i)
     if (ref_image[i] < 0 || ref_image[i] >= c->n || cur_image[i] < 0 || cur_image[i] >= c->n)
       return fe_fail(c, VPL_E_INVALID, "pair names an image that was not uploaded");
+  c->matchFromDetected = true;
   FECHK(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
   const size_t P = n_pairs;
@@ -653,6 +670,7 @@ int vpl_match_download(vpl_fe_ctx* c, int n_pairs, int* r2c, int* matched) {
   FECHK(c, hipMemcpyAsync(nref.data(), c->d_nRef, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
   FECHK(c, hipMemcpyAsync(buf.data(), c->M.r2c, buf.size() * 4, hipMemcpyDeviceToHost, c->stream));
   FECHK(c, hipStreamSynchronize(c->stream));
+  if (c->matchFromDetected) { const int ro = lines_overflow_check(c, c->n); if (ro) return ro; }
   for (int i = 0; i < n_pairs; ++i)
     if (valid[i] < 0) return fe_fail(c, VPL_E_CAPACITY, "pair " + std::to_string(i) + ": more key points than max_kps");
   for (int i = 0; i < n_pairs; ++i) {
