@@ -188,8 +188,11 @@ constexpr int LOPT_THREADS = 256;
 
 // cost (with the Cauchy loss) and, if H, the corrected normal equations of one line at orth `o`:
 // H (packed lower 4x4, 10), g (4).  ceres Corrector with rho'' <= 0: residual and Jacobian scaled by sqrt(rho').
+// G lanes share a line: lane `sub` takes the observations sub, sub + G, ... and the sums are folded over the lanes with xor
+// shuffles, so that every lane of the line holds the same cost, H and g (a + b == b + a bit for bit).
+template <int G>
 __device__ inline double lopt_eval(const DevBatch& B, int w, size_t li, const double* xp, const double* xe, const double* o,
-                                   double* H, double* g) {
+                                   double* H, double* g, int sub) {
   const int s = B.ln_start[li], no = B.ln_nobs[li];
   const double* ob0 = B.ln_obs + ((size_t)w * B.maxLO + B.ln_off[li]) * 8;
   double cost = 0.0;
@@ -199,7 +202,7 @@ __device__ inline double lopt_eval(const DevBatch& B, int w, size_t li, const do
 #pragma unroll
     for (int k = 0; k < 4; ++k) g[k] = 0.0;
   }
-  for (int k = 0; k < no; ++k) {
+  for (int k = sub; k < no; k += G) {
     const LineCtx c = line_ctx(xp + 7 * (s + k), xe, o);
     double r[2], jel[6];
     line_factor_res(c, ob0 + 8 * k, B.opt.sqrt_info_line, r, H ? jel : nullptr);
@@ -224,6 +227,16 @@ __device__ inline double lopt_eval(const DevBatch& B, int w, size_t li, const do
       }
     }
   }
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) {
+    cost += __shfl_xor(cost, m, 64);
+    if (H) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) H[k] += __shfl_xor(H[k], m, 64);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] += __shfl_xor(g[k], m, 64);
+    }
+  }
   return cost;
 }
 
@@ -243,8 +256,12 @@ __device__ inline double block_max(double v, double* red) {
   return red[16];
 }
 
+// G = lanes per line (1, 2 or 4; G * max_lines <= LOPT_THREADS): the latency of a call is the chain of factor evaluations of
+// one line, 2 x up to 11 per iteration on one lane with G = 1 (180 us for a window of the sequence test; round 4).
+template <int G>
 __global__ __launch_bounds__(LOPT_THREADS) void k_line_opt(DevBatch B) {
   const int w = blockIdx.x, tid = threadIdx.x;
+  const int ln = tid / G, sub = tid % G;
   const int nL = B.nL[w];
   __shared__ double xp[84], red[18];
   TrState* tr = &B.tr[w];
@@ -255,8 +272,9 @@ __global__ __launch_bounds__(LOPT_THREADS) void k_line_opt(DevBatch B) {
   for (int i = tid; i < 84; i += LOPT_THREADS) xp[i] = i < 77 ? B.pose[(size_t)w * 77 + i] : B.ex[(size_t)w * 7 + (i - 77)];
   __syncthreads();
   const double* xe = xp + 77;
-  const bool live = tid < nL;
-  const size_t li = (size_t)w * B.maxL + (live ? tid : 0);
+  const bool live = ln < nL;
+  const bool lead = live && sub == 0;     // the lane whose copy of the line's scalars enters the block sums
+  const size_t li = (size_t)w * B.maxL + (live ? ln : 0);
   double x[4] = {0, 0, 0, 0}, H[10], g[4], sc[4] = {1, 1, 1, 1}, diag[4] = {1, 1, 1, 1};
   if (live)
     for (int k = 0; k < 4; ++k) x[k] = B.orth[li * 4 + k];
@@ -264,8 +282,8 @@ __global__ __launch_bounds__(LOPT_THREADS) void k_line_opt(DevBatch B) {
   for (int k = 0; k < 4; ++k) g[k] = 0.0;
 
   // ---- iteration 0: evaluate, Jacobi scaling, gradient max norm ----
-  double c0 = live ? lopt_eval(B, w, li, xp, xe, x, H, g) : 0.0;
-  double x_cost = block_sum(c0, red);
+  double c0 = live ? lopt_eval<G>(B, w, li, xp, xe, x, H, g, sub) : 0.0;
+  double x_cost = block_sum(lead ? c0 : 0.0, red);
   const double initial_cost = x_cost;
   if (live)
     for (int a = 0; a < 4; ++a) sc[a] = 1.0 / (1.0 + sqrt(H[tri(a, a)]));
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(LOPT_THREADS) void k_line_opt(DevBatch B) {
   };
   double gmax = grad_max();
   double xn2 = 0.0;
-  if (live) for (int a = 0; a < 4; ++a) xn2 += x[a] * x[a];
+  if (lead) for (int a = 0; a < 4; ++a) xn2 += x[a] * x[a];
   double x_norm = sqrt(block_sum(xn2, red));
 
   // ceres LevenbergMarquardtStrategy state (levenberg_marquardt_strategy.cc)
@@ -349,8 +367,8 @@ __global__ __launch_bounds__(LOPT_THREADS) void k_line_opt(DevBatch B) {
         mcc = -(sg + 0.5 * sHs);
       }
     }
-    const double anyfail = block_sum((double)fail, red);
-    const double model_cost_change = block_sum(mcc, red);
+    const double anyfail = block_sum(lead ? (double)fail : 0.0, red);
+    const double model_cost_change = block_sum(lead ? mcc : 0.0, red);
     reuse_diagonal = true;   // ComputeStep (a failed solve leaves it as it was: the next attempt recomputes nothing else)
     if (anyfail > 0.0 || !(model_cost_change > 0.0)) {
       if (anyfail > 0.0) reuse_diagonal = false;
@@ -365,11 +383,11 @@ __global__ __launch_bounds__(LOPT_THREADS) void k_line_opt(DevBatch B) {
       double delta[4];
       for (int a = 0; a < 4; ++a) delta[a] = step[a] * sc[a];
       line_orth_plus(x, delta, cand);
-      cc = lopt_eval(B, w, li, xp, xe, cand, nullptr, nullptr);
+      cc = lopt_eval<G>(B, w, li, xp, xe, cand, nullptr, nullptr, sub);
       for (int a = 0; a < 4; ++a) sn2 += (x[a] - cand[a]) * (x[a] - cand[a]);
     }
-    const double cand_cost = block_sum(cc, red);
-    const double step_norm = sqrt(block_sum(sn2, red));
+    const double cand_cost = block_sum(lead ? cc : 0.0, red);
+    const double step_norm = sqrt(block_sum(lead ? sn2 : 0.0, red));
     // a tolerance fires before the iteration is recorded (ceres: the summary of the terminating iteration is never pushed)
     if (step_norm <= 1e-8 * (x_norm + 1e-8)) { status = 1; --iter; break; }
     if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { status = 1; --iter; break; }
@@ -377,13 +395,13 @@ __global__ __launch_bounds__(LOPT_THREADS) void k_line_opt(DevBatch B) {
     if (rho > 1e-3) {
       if (live) {
         for (int a = 0; a < 4; ++a) x[a] = cand[a];
-        c0 = lopt_eval(B, w, li, xp, xe, x, H, g);
+        c0 = lopt_eval<G>(B, w, li, xp, xe, x, H, g, sub);
       } else {
         c0 = 0.0;
       }
-      x_cost = block_sum(c0, red);
+      x_cost = block_sum(lead ? c0 : 0.0, red);
       xn2 = 0.0;
-      if (live) for (int a = 0; a < 4; ++a) xn2 += x[a] * x[a];
+      if (lead) for (int a = 0; a < 4; ++a) xn2 += x[a] * x[a];
       x_norm = sqrt(block_sum(xn2, red));
       gmax = grad_max();
       last_successful = true;
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(LOPT_THREADS) void k_line_opt(DevBatch B) {
       reuse_diagonal = true;
     }
   }
-  if (live)
+  if (lead)
     for (int k = 0; k < 4; ++k) B.orth[li * 4 + k] = x[k];
   if (tid == 0) {
     tr->iter = iter;

@@ -1316,7 +1316,12 @@ static int only_line_opt_impl(vpl_ctx* c, int nW, vpl_window* win, const vpl_ba_
   const dim3 grid(nW);
   hipStream_t s = c->stream;
   { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(PREP_THREADS), prep_smem(c->maxPriorN), s, B, std::min(c->maxPriorN, PREP_NMAX)); }
-  { KTimer t(c, "k_line_opt"); hipLaunchKernelGGL(k_line_opt, grid, dim3(LOPT_THREADS), 0, s, B); }
+  {
+    KTimer t(c, "k_line_opt");
+    if (4 * c->maxL <= LOPT_THREADS) hipLaunchKernelGGL(k_line_opt<4>, grid, dim3(LOPT_THREADS), 0, s, B);
+    else if (2 * c->maxL <= LOPT_THREADS) hipLaunchKernelGGL(k_line_opt<2>, grid, dim3(LOPT_THREADS), 0, s, B);
+    else hipLaunchKernelGGL(k_line_opt<1>, grid, dim3(LOPT_THREADS), 0, s, B);
+  }
   { KTimer t(c, "k_gauge"); hipLaunchKernelGGL(k_gauge, grid, dim3(128), 0, s, B); }
   HIPCHK(c, hipGetLastError());
   const size_t W = nW;
