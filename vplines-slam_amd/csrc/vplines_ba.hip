@@ -166,6 +166,7 @@ struct vpl_ctx {
   bool layout_valid = false;
   bool force_general = false;                    // VPL_BA_GENERAL=1: every window takes k_solve (A/B runs, tests of the general path)
   bool schur_mostly_wide = false;                // more than 35 % of the landmark elimination's weight sits in wide entries: k_schur<5>
+  bool schur_never_wide = false;                 // VPL_BA_SCHUR_WIDE=-1: k_schur_mixed whatever the share of wide entries (A/B runs)
   bool schur_wide_all = false;                   // VPL_BA_SCHUR_WIDE=1: round 3's k_schur<5> for batches with long tracks (A/B runs, tests)
   std::vector<std::string> kname_store;
   // host-side marg structure of the uploaded windows
@@ -470,7 +471,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   vpl_ba_default_options(&c->opt);
   if (const char* gv = std::getenv("VPL_BA_GRAPH")) c->use_graph = std::atoi(gv) != 0;
   if (const char* gv = std::getenv("VPL_BA_GENERAL")) c->force_general = std::atoi(gv) != 0;
-  if (const char* gv = std::getenv("VPL_BA_SCHUR_WIDE")) c->schur_wide_all = std::atoi(gv) != 0;
+  if (const char* gv = std::getenv("VPL_BA_SCHUR_WIDE")) { c->schur_wide_all = std::atoi(gv) > 0; c->schur_never_wide = std::atoi(gv) < 0; }
   *out = c;
   return VPL_OK;
 }
@@ -1386,7 +1387,7 @@ static void launch_solve(vpl_ctx* c, int w0, int nw, hipStream_t s) {
     // back-substitution + dogleg + candidate.
     { KTimer t(c, "k_schur");
       if (B.WS + 2 <= 48) hipLaunchKernelGGL(k_schur<3>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 3), s, B);
-      else if (c->schur_wide_all || c->schur_mostly_wide) hipLaunchKernelGGL(k_schur<5>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 5), s, B);
+      else if (c->schur_wide_all || (c->schur_mostly_wide && !c->schur_never_wide)) hipLaunchKernelGGL(k_schur<5>, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 5), s, B);
       // rows wider than 6 frames: narrow view for the entries of short tracks, all tiles for the flagged ones (round 4)
       else hipLaunchKernelGGL(k_schur_mixed, grid, dim3(SCHUR_THREADS), schur_smem(B.maxP, B.maxL, 3), s, B); }
     ++B.launch;
