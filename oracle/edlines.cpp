@@ -417,7 +417,11 @@ void ed_fit(const unsigned* xC, const unsigned* yC, const unsigned* sId, int nEd
         if (lineFitErr <= P.lineFitErrThreshold) break;
         offS += 2;   // SkipEdgePoint
       }
-      if (lineFitErr > P.lineFitErrThreshold) break;
+      // The reference tests `lineFitErr > threshold` (:996).  A run of minLineLen pixels with one and the same abscissa makes
+      // the normal equations singular and the error NaN: neither that test nor `<=` above is true, and the reference goes on
+      // with offS beyond the end of the chain -- it reads past the edge's pixels (found with the sanitizers over the shapes of
+      // tools/fuzz_frontend.py).  Defined here and on the device: a fit that did not succeed ends the chain.
+      if (!(lineFitErr <= P.lineFitErrThreshold)) break;
       const bool hz = F.horiz(offS);
       const unsigned offS_init = offS;
       bool bExtended = true, bFirstTry = true;

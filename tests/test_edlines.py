@@ -227,3 +227,30 @@ def test_gpu_more_lines_than_the_table_holds_is_refused():
         lo = o.edlines(IMGS[i], min_len=120)
         assert 0 < len(lo) <= 64 and len(out[i]) == len(lo)
     fe.close()
+
+
+SINGULAR_FIT = dict(grad_th=77, anchor_th=12, scan=1, min_len=12, fit_err=1.5655807874942627)
+
+
+def test_a_singular_initial_fit_ends_the_chain():
+    """tests/golden/edlines_singular_fit_33x400.npy (a frame of tools/fuzz_frontend.py, blurred noise): the last edge chain ends
+    in 12 pixels with one and the same abscissa, the 2 x 2 normal equations of the initial fit are singular, the fit error is
+    NaN.  The reference's loop (edline_detector.cpp:989-997) then leaves with offS two pixels on and extends a "line" from
+    beyond the end of the chain: a read past the edge's pixels (seen as a wild index under the address sanitizer).  Oracle and
+    device end the chain there."""
+    img = np.load(os.path.join(HERE, "golden", "edlines_singular_fit_33x400.npy"))
+    lines, st = o.edlines(img, smoothed=False, want_stages=True, **SINGULAR_FIT)
+    assert len(st["sid"]) - 1 == 99 and st["sid"][-1] == 2074 and len(lines) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_a_singular_initial_fit_ends_the_chain():
+    img = np.load(os.path.join(HERE, "golden", "edlines_singular_fit_33x400.npy"))
+    fe = v.frontend.FrontendContext(device=0, max_images=1, width=33, height=400, max_lines=256)
+    p = v.frontend.default_param()
+    p.gradientThreshold, p.anchorThreshold, p.scanIntervals = SINGULAR_FIT["grad_th"], SINGULAR_FIT["anchor_th"], SINGULAR_FIT["scan"]
+    p.minLineLen, p.lineFitErrThreshold = SINGULAR_FIT["min_len"], SINGULAR_FIT["fit_err"]
+    for _ in range(3):      # (whatever an earlier frame left behind the chain's end must not matter)
+        out = fe.detect_batch(img[None], p, smoothed=False)
+        assert len(out[0]) == 0
+    fe.close()

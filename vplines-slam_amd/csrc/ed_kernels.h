@@ -622,7 +622,10 @@ __global__ __launch_bounds__(64) void k_ed_fit(EdBatch B) {
         if (lineFitErr <= thr) break;
         offS += 2;
       }
-      if (lineFitErr > thr) break;
+      // (a run of minLineLen pixels with one and the same abscissa makes the 2 x 2 normal equations singular and the fit error
+      // NaN: neither `<= thr` above nor the reference's `> thr` here is true, and the reference goes on with offS beyond the end
+      // of the chain (edline_detector.cpp:989-997, :1011) -- a read past the edge's pixels.  A fit that did not succeed ends the chain.)
+      if (!(lineFitErr <= thr)) break;
       const bool hz = dir[yC[offS] * W + xC[offS]] == 255;
       const unsigned offS_init = offS;
       bool bExtended = true, bFirstTry = true;
