@@ -491,6 +491,8 @@ int orc_edlines(const uint8_t* img, int W, int H, int gradTh, int anchorTh, int 
   std::vector<unsigned> xC, yC, sId;
   ed_route(g.data(), dir.data(), W, H, ax.data(), ay.data(), nA, minLineLen, edge.data(), xC, yC, sId);
   const int nE = (int)sId.size() - 1;
+  // (capacity = size: a read one past the last chain pixel then lies outside the allocation, where a sanitizer build sees it)
+  xC.shrink_to_fit(); yC.shrink_to_fit(); sId.shrink_to_fit();
   EDParam P{gradTh, anchorTh, scan, minLineLen, fitErr};
   std::vector<EDLine> lines;
   ed_fit(xC.data(), yC.data(), sId.data(), nE, dir.data(), dx.data(), dy.data(), W, H, P, lines);
