@@ -470,10 +470,12 @@ __global__ __launch_bounds__(64 * ED_ROUTE_WAVES) void k_ed_route(EdBatch B) {
     }
     const int cnt = min(64, nA - i0);
     for (int k = 0; k < cnt; ++k) {
-      const int x = __shfl((int)mx, k, 64), y = __shfl((int)my, k, 64);
-      const int code = __shfl(mcode, k, 64);
+      // (read as scalars: the anchor test is a branch on a wave-uniform value, and the compiler should know)
+      const int x = __builtin_amdgcn_readlane((int)mx, k), y = __builtin_amdgcn_readlane((int)my, k);
+      const int code = __builtin_amdgcn_readlane(mcode, k);
       const int idx = y * W + x;
-      if ((wk.bits[idx >> 5] >> (idx & 31)) & 1) continue;
+      const unsigned bword = (unsigned)__builtin_amdgcn_readfirstlane((int)wk.bits[idx >> 5]);
+      if ((bword >> (idx & 31)) & 1) continue;
       const unsigned h = (code >> 4) & 1;
       wk.nWalks += 2;
       // first part (RIGHT / DOWN) into the scratch arrays, second part (LEFT / UP) directly behind the slot of the
