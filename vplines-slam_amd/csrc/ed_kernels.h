@@ -396,6 +396,9 @@ __device__ __forceinline__ int ed_walk(EdWalker& wk, int x, int y, unsigned S, u
       pxy = lane == (n & 63) ? (x | (y << 16)) : pxy;     // (compare + select: v_writelane would need two scalar operands)
       ++n;
       if ((n & 63) == 0) {
+        // (the empty statement keeps this block behind a scalar branch: merged with the lane test below it cost every step a
+        // vector add, a compare and a pair of exec-mask instructions)
+        asm volatile("" ::: "memory");
         const int o = n - 64 + lane;
         if (o < cap) { px[o] = (unsigned)pxy & 0xffff; py[o] = (unsigned)pxy >> 16; }
       }
@@ -468,8 +471,19 @@ __global__ __launch_bounds__(64 * ED_ROUTE_WAVES) void k_ed_route(EdBatch B) {
       mx = ax[i0 + lane]; my = ay[i0 + lane];
       mcode = wk.code[(size_t)my * B.Wc + mx];
     }
-    const int cnt = min(64, nA - i0);
-    for (int k = 0; k < cnt; ++k) {
+    // Most anchors lie on an edge that an earlier walk has drawn already: the 64 anchors of the trip test their bit at once
+    // (one LDS gather + a ballot); only those that were free then are looked at one by one, and tested again, because a walk
+    // of this trip may have reached them since.  (Bits are only ever set -- the anchor that is un-marked between its two walks
+    // is claimed again by the second one -- so an anchor that was marked stays marked.)
+    unsigned long long cand;
+    {
+      const int li = (int)my * W + (int)mx;
+      const unsigned bw = i0 + lane < nA ? wk.bits[li >> 5] : ~0u;
+      cand = __ballot(((bw >> (li & 31)) & 1u) == 0);
+    }
+    while (cand) {
+      const int k = __builtin_ctzll(cand);
+      cand &= cand - 1;
       // (read as scalars: the anchor test is a branch on a wave-uniform value, and the compiler should know)
       const int x = __builtin_amdgcn_readlane((int)mx, k), y = __builtin_amdgcn_readlane((int)my, k);
       const int code = __builtin_amdgcn_readlane(mcode, k);
