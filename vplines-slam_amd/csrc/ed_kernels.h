@@ -386,13 +386,16 @@ __device__ __forceinline__ int ed_walk(EdWalker& wk, int x, int y, unsigned S, u
     const unsigned bw = inb ? wk.bits[idx >> 5] : 0u;
     const unsigned long long live = __ballot(inb && (wcode & ED_LIVE) != 0);
     const unsigned long long vis0 = __ballot(((bw >> (idx & 31)) & 1u) != 0);
-    unsigned long long vmask = 0;
+    // one mask of the pixels the walk may still claim (walkable and not visited) instead of two tests per step; what was
+    // claimed in this window is what has left that mask
+    const unsigned long long free0 = live & ~vis0;
+    unsigned long long free = free0;
     bool done = false;
     for (;;) {
       const int li = (y - wy0) * 8 + (x - wx0);
       const unsigned long long bit = 1ull << li;
-      if (!(live & bit) || ((vis0 | vmask) & bit)) { done = true; break; }       // while (g > 0 && !edge)
-      vmask |= bit;
+      if (!(free & bit)) { done = true; break; }       // while (g > 0 && !edge)
+      free &= ~bit;
       pxy = lane == (n & 63) ? (x | (y << 16)) : pxy;     // (compare + select: v_writelane would need two scalar operands)
       ++n;
       if ((n & 63) == 0) {
@@ -416,6 +419,7 @@ __device__ __forceinline__ int ed_walk(EdWalker& wk, int x, int y, unsigned S, u
       n = __builtin_amdgcn_readfirstlane(n);
       if ((unsigned)(x - wx0) >= 8u || (unsigned)(y - wy0) >= 8u) break;         // left the window
     }
+    const unsigned long long vmask = free0 & ~free;
     if ((vmask >> lane) & 1ull) atomicOr(&wk.bits[idx >> 5], 1u << (idx & 31));
     if (done) break;
   }
