@@ -396,7 +396,10 @@ __device__ __forceinline__ int ed_walk(EdWalker& wk, int x, int y, unsigned S, u
       const unsigned long long bit = 1ull << li;
       if (!(free & bit)) { done = true; break; }       // while (g > 0 && !edge)
       free &= ~bit;
-      pxy = lane == (n & 63) ? (x | (y << 16)) : pxy;     // (compare + select: v_writelane would need two scalar operands)
+      {   // pxy[lane n & 63] = x | y << 16  (v_writelane takes one scalar register besides m0)
+        const int pv = x | (y << 16), pl = n & 63;
+        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(pxy) : "s"(pv), "s"(pl) : "m0");
+      }
       ++n;
       if ((n & 63) == 0) {
         // (the empty statement keeps this block behind a scalar branch: merged with the lane test below it cost every step a
