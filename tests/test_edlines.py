@@ -254,3 +254,29 @@ def test_gpu_a_singular_initial_fit_ends_the_chain():
         out = fe.detect_batch(img[None], p, smoothed=False)
         assert len(out[0]) == 0
     fe.close()
+
+
+@pytest.mark.gpu
+def test_gpu_half_height_routing_strip_gives_the_same_chains():
+    """Contexts that hold more frames than the device has CUs take a routing strip of at most half the LDS (256 rows for
+    752 x 480), so that two frames' walkers share a CU (14.9 k instead of 11.5 k frames/s with 512 frames in flight,
+    tools/fe_scale.py).  The strip then moves vertically too; forced here on a small context: same chains, same lines."""
+    imgs = np.stack(IMGS + [np.ascontiguousarray(IMGS[0][::-1])])
+    old = os.environ.get("VPL_FE_ROUTE_HS")
+    os.environ["VPL_FE_ROUTE_HS"] = "256"
+    try:
+        fe = v.frontend.FrontendContext(device=0, max_images=len(imgs), width=752, height=480, max_lines=1024)
+    finally:
+        if old is None:
+            del os.environ["VPL_FE_ROUTE_HS"]
+        else:
+            os.environ["VPL_FE_ROUTE_HS"] = old
+    out = fe.detect_batch(imgs)
+    for i in range(len(imgs)):
+        lo, st = o.edlines(imgs[i], want_stages=True)
+        sg = fe.debug_stage(i)
+        for k in ("anchors", "sid", "chain_x", "chain_y"):
+            assert np.array_equal(sg[k], st[k]), (i, k)
+        assert len(out[i]) == len(lo) and np.abs(out[i][:, :4] - lo[:, :4]).max() < 1e-3
+    assert fe.route_stats(0)["tile_loads"] > 143       # more strip loads than the full-height strip needs
+    fe.close()

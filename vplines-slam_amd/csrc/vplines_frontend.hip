@@ -167,6 +167,20 @@ int vpl_fe_create(vpl_fe_ctx** out, int device, int max_images, int width, int h
     const size_t bits = (size_t)(((((size_t)width * height + 31) >> 5) + 3) & ~(size_t)3) * 4;
     int hs = (height + 31) / 32 * 32;
     while (hs > 128 && bits + (size_t)hs * ED_TILE + 64 * 4 > 159 * 1024) hs -= 32;
+    // More frames in flight than the device has CUs: a strip of at most half the LDS lets TWO frames' walkers share a CU (the
+    // walk is one wave; the strip then moves vertically as well, which the helper waves make cheap) -- measured below.
+    {
+      int ncu = 0;
+      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+      const char* ev = std::getenv("VPL_FE_ROUTE_HS");
+      int want = ev ? std::atoi(ev) : 0;
+      if (!ev && ncu > 0 && max_images > ncu) {
+        want = hs;
+        while (want > 128 && bits + (size_t)want * ED_TILE + 64 * 4 > 79 * 1024) want -= 32;
+        if (bits + (size_t)want * ED_TILE + 64 * 4 > 79 * 1024) want = hs;      // does not fit twice anyway
+      }
+      if (want >= 32 && want < hs && want % 32 == 0) hs = want;
+    }
     // (rows of the strip past the frame are zero-filled by the loader)
     B.routeHS = hs;
     c->routeSmem = bits + (size_t)hs * ED_TILE + 64 * 4;
