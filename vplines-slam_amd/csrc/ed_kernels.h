@@ -619,7 +619,55 @@ __global__ __launch_bounds__(64) void k_ed_fit(EdBatch B) {
     };
     while (offE > offS + minLineLen) {
       double eq0 = 0, eq1 = 0, lineFitErr = 0;
+      bool firstTry = true;
       while (offE > offS + minLineLen) {
+        if (!firstTry) {
+          // The reference moves the start two pixels on after every failed initial fit and tries again (:989-995): 98 of 100
+          // attempts fail (5 670 attempts for 127 lines in a frame of the benchmark's stream), each a chain of dependent work
+          // for the whole wave.  After the first failure the next 64 starts are tried AT ONCE, one per lane: every lane runs
+          // the reference's arithmetic for its own start (integer sums, float normal equations, the error summed in pixel order),
+          // the first lane that succeeds is the start the reference would have reached.
+          const unsigned st = offS + 2u * lane;
+          const bool valid = offE > st + minLineLen;
+          double e_k = 0, q0 = 0, q1 = 0;
+          float a0 = 0, a1 = 0, a3 = 0, b0 = 0, b1 = 0;
+          if (valid) {
+            const bool hzk = dir[yC[st] * W + xC[st]] == 255;
+            double s_uu = 0, s_u = 0, s_uv = 0, s_v = 0;
+            for (unsigned i = 0; i < minLineLen; ++i) {
+              const unsigned x = xC[st + i], y = yC[st + i];
+              const double u = (double)(float)(hzk ? x : y), v = (double)(float)(hzk ? y : x);
+              s_uu += u * u; s_u += u; s_uv += u * v; s_v += v;
+            }
+            a0 = (float)s_uu; a1 = (float)s_u; a3 = (float)(double)minLineLen; b0 = (float)s_uv; b1 = (float)s_v;
+            const double coef = 1.0 / (double(a0) * double(a3) - double(a1) * double(a1));
+            q0 = coef * (double(a3) * double(b0) - double(a1) * double(b1));
+            q1 = coef * (double(a0) * double(b1) - double(a1) * double(b0));
+            double err = 0;
+            for (unsigned i = 0; i < minLineLen; ++i) {
+              const unsigned x = xC[st + i], y = yC[st + i];
+              const double u = (double)(hzk ? x : y), v = (double)(hzk ? y : x);
+              const double c = v - u * q0 - q1;
+              err += c * c;
+            }
+            e_k = sqrt(err);
+          }
+          const unsigned long long okm = __ballot(valid && e_k <= thr);
+          const int nvalid = __popcll(__ballot(valid));
+          if (okm) {
+            const int f = __builtin_ctzll(okm);
+            offS += 2u * (unsigned)f;
+            eq0 = ed_readlane_f64(q0, f); eq1 = ed_readlane_f64(q1, f); lineFitErr = ed_readlane_f64(e_k, f);
+            ATA0 = __shfl(a0, f, 64); ATA1 = __shfl(a1, f, 64); ATA2 = ATA1; ATA3 = __shfl(a3, f, 64);
+            ATV0 = __shfl(b0, f, 64); ATV1 = __shfl(b1, f, 64);
+            break;
+          }
+          // none of them: the last attempt's error is what the test behind the loop sees
+          lineFitErr = ed_readlane_f64(e_k, nvalid - 1);
+          offS += 2u * (unsigned)nvalid;
+          continue;
+        }
+        firstTry = false;
         const bool hz = dir[yC[offS] * W + xC[offS]] == 255;
         double s_uu, s_u, s_uv, s_v;
         sums(offS, offS + minLineLen, hz, s_uu, s_u, s_uv, s_v);
