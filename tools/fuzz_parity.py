@@ -138,11 +138,23 @@ def run(nb, per, seed, out=print):
             o.preintegrate_windows(w2, opt)
             keep = (Prior * per)()
             C.memmove(keep, pg, C.sizeof(keep))
+            # the device-resident hand-over first (vpl_ba_upload_chained needs the solve above to be the context's last upload):
+            # the same windows, the priors never leaving the device -- must give the bits of the host hand-over below
+            gd = [w.copy() for w in w2]
+            ctx.upload(gd, opt, chained=True)
+            ctx.solve()
+            ctx.synchronize()
+            ctx.download()
             g2, c2 = [w.copy() for w in w2], [w.copy() for w in w2]
             for i in range(per):
                 g2[i].prior = keep[i] if keep[i].n > 0 else None
                 c2[i].prior = pcs[i] if pcs[i].n > 0 else None
             pg2, rg2 = ctx.solve_windows(g2, opt)
+            for i in range(per):
+                if not (np.array_equal(gd[i].pose, g2[i].pose) and np.array_equal(gd[i].speed_bias, g2[i].speed_bias)):
+                    out("b%02d.1 w%d CHAINED UPLOAD differs from the host hand-over: %.3e <-- MISS" % (
+                        b, i, np.abs(gd[i].pose - g2[i].pose).max()))
+                    bad += 1
             for i in range(per):
                 pc, rc = o.solve_window(c2[i], opt)
                 c2s = shifted(w2[i])
