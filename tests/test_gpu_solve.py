@@ -247,6 +247,33 @@ def test_remove_line_outliers(gpu_ctx):
     assert rg[0].prior_n == 45 and rg[0].n_lines_removed == 0
 
 
+def test_marginalize_does_not_see_the_lines_an_earlier_solve_erased():
+    """vpl_ba_marginalize runs no solve, hence no removeLineOutlier pass: the erase flags its kernels read must be this
+    call's (none), not those the context's previous solve left on the device.  Found by tools/fuzz_sequence.py (a
+    solve_odometry with remove_line_outliers, then a marginalize of other windows: priors without those lines)."""
+    ws2, opt2 = make_windows(2, 120, 6, False, seed0=520)
+    opt2.remove_line_outliers = 1
+    bad = []
+    for w in ws2:
+        w2 = w.copy()
+        w2.line_obs[0::2, [1, 3]] += 0.08                          # every line an outlier (as in the test above)
+        w2.line_obs[1::2, [1, 3]] -= 0.08
+        bad.append(w2)
+    ctx = v.Context(device=0, max_windows=2)
+    _, rg = ctx.solve_windows(bad, opt2)
+    assert rg[0].n_lines_removed == 6 and rg[1].n_lines_removed == 6
+    opt = v.default_options()
+    after = ctx.marginalize([w.copy() for w in ws2], opt, v.MARGIN_OLD)
+    ctx.close()
+    fresh = v.Context(device=0, max_windows=2)
+    alone = fresh.marginalize([w.copy() for w in ws2], opt, v.MARGIN_OLD)
+    fresh.close()
+    for i in range(2):
+        assert after[0][i].n == alone[0][i].n > 0
+        assert bytes(after[0][i]) == bytes(alone[0][i])
+    assert np.array_equal(after[1], alone[1]) and np.array_equal(after[2], alone[2])
+
+
 def test_margin_second_new(gpu_ctx):
     """MARGIN_SECOND_NEW (estimator.cpp:1380-1447): A (MARGIN_OLD) -> prior P1 -> B (SECOND_NEW) -> P2 without pose 9
     -> C (SECOND_NEW again: P2 holds no pose[9], the prior passes through untouched)."""

@@ -1627,6 +1627,9 @@ static int marginalize_impl(vpl_ctx* c, int nW, const vpl_window* win, const vpl
   B.ord_it = 0; B.act = nullptr; B.launch = 0;
   const dim3 grid(nW);
   hipStream_t s = c->stream;
+  // no line of this call is erased (remove_line_outliers = 0 above): the flags k_lin<MARG> and k_marg read are written by
+  // k_gauge, which runs in a solve only -- without this they would be those of the batch the context solved before
+  HIPCHK(c, hipMemsetAsync(B.ln_removed, 0, (size_t)nW * B.maxL * sizeof(int), s));
   // k_prep: whitening matrices, q <- Quaterniond(R(q)) and the world orth of the lines (the vector2double() the reference
   // runs before it marginalises, estimator.cpp:1233), J0^T J0 of the incoming prior
   { KTimer t(c, "k_prep"); hipLaunchKernelGGL(k_prep, grid, dim3(PREP_THREADS), prep_smem(c->maxPriorN), s, B, std::min(c->maxPriorN, PREP_NMAX)); }
