@@ -8,7 +8,8 @@ Calls drawn: solve_windows; upload / solve / download, reset_state and the solve
 chained upload one keyframe on; marginalize, triangulate_lines, triangulate_points, only_line_opt, slide_window (synchronous,
 or enqueued and collected at once, or enqueued and left for the next call to settle); solve_odometry; an upload that is
 refused half-way (then solve and download must refuse too); a window with a NaN among its inputs; a solve whose priors
-are handed by the caller to the windows one keyframe on, marginalised and solved.
+are handed by the caller to the windows one keyframe on, marginalised and solved; the single-factor evaluators and manifold
+operations (which leave a call in flight as it is).
 
     python tools/fuzz_sequence.py [calls=120] [windows per context=6] [seed=1]
 Exit status 1 on the first difference.
@@ -26,7 +27,7 @@ import oracle_api as o
 import vplines_slam_amd as v
 from fuzz_parity import draw_window
 
-CALLS = ["solve", "solve", "twice", "chain", "marg", "tri_lines", "tri_points", "line_opt", "slide", "odometry", "refused", "nan", "prior"]
+CALLS = ["solve", "solve", "twice", "chain", "marg", "tri_lines", "tri_points", "line_opt", "slide", "odometry", "refused", "nan", "prior", "helpers"]
 
 
 def state(w):
@@ -89,6 +90,14 @@ def run_call(ctx, kind, ws, w2, opt, prm, pend):
         ctx.upload(w2, opt, chained=True); ctx.solve(); ctx.synchronize()
         p2, r2 = ctx.download()
         return lambda: s1 + solved(w2, p2, r2)
+    if kind == "helpers":
+        # the single-factor evaluators and the two manifold operations: they share the context's stream with a call that is
+        # still in flight, and must neither complete it nor disturb it
+        k = prm["helpers"]
+        out = [ctx.pose_plus(k["x"], k["dx"]).tobytes(), ctx.line_orth_plus(k["orth"], k["dorth"]).tobytes()]
+        for r, j in (ctx.projection_factor(k["proj"], k["pts"]), ctx.line_factor(k["linep"], k["lobs"]), ctx.vp_factor(k["linep"], k["vp"])):
+            out += [r.tobytes(), j.tobytes()]
+        return lambda: out
     if kind == "prior":
         # the host hand-over: the priors of one solve given to the windows one keyframe on, which are marginalised as they
         # stand and then solved (the calls after this one come without a prior again)
@@ -127,9 +136,11 @@ def run_call(ctx, kind, ws, w2, opt, prm, pend):
         p, lr, r = ctx.solve_odometry(ws, opt, 5.0)
         return lambda: solved(ws, p, r) + [rep(x) for x in lr]
     if kind == "refused":
-        bad = ws[-1]
-        if len(bad.point_nobs) == 0:
+        have = [w for w in ws if len(w.point_nobs)]
+        if not have:
+            ctx.synchronize()                            # (completes a call in flight, as every other kind does)
             return lambda: ["no point track to spoil"]
+        bad = have[-1]
         bad.point_nobs[len(bad.point_nobs) // 2] = 1     # a track the reference's filter would not have passed: CONTRACT
         said = []
         for what, f in (("upload", lambda: ctx.upload(ws, opt)), ("solve", ctx.solve), ("download", ctx.download)):
@@ -173,6 +184,15 @@ def main():
             ws[k].pose[int(rng.integers(0, 11)), int(rng.integers(0, 3))] = np.nan
         prm = dict(flag=int(rng.choice([v.MARGIN_OLD, v.MARGIN_SECOND_NEW])), untri=(rng.random(512) < 0.4).astype(np.int32),
                    unset=rng.random(512) < 0.5)
+        if kind == "helpers":
+            m = 37
+            q = rng.normal(size=(m, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+            pose = lambda: np.concatenate([rng.normal(0, 1, (m, 3)), q[rng.permutation(m)]], 1)
+            prm["helpers"] = dict(x=pose(), dx=rng.normal(0, 0.1, (m, 6)), orth=rng.normal(0, 1, (m, 4)), dorth=rng.normal(0, 0.1, (m, 4)),
+                                  proj=np.concatenate([pose(), pose(), pose(), rng.uniform(0.1, 1, (m, 1))], 1),
+                                  pts=np.concatenate([rng.normal(0, 0.3, (m, 2)), np.ones((m, 1)), rng.normal(0, 0.3, (m, 2)), np.ones((m, 1))], 1),
+                                  linep=np.concatenate([pose(), pose(), rng.normal(0, 1, (m, 4))], 1), lobs=rng.normal(0, 0.3, (m, 4)),
+                                  vp=rng.normal(0, 1, (m, 3)))
         enq = kind in ("marg", "tri_lines", "tri_points", "line_opt", "slide")
         pend = str(rng.choice(["sync", "collect", "leave"])) if enq else "sync"
         if only and c not in only:                       # (replay of a subset: the draws above keep the inputs the same)
@@ -188,7 +208,7 @@ def main():
         except (RuntimeError, AssertionError) as e:
             print(tag, "FAILED:", e)
             return 1
-        if waiting is not None:                          # the call before was left in flight: this one has settled it
+        if waiting is not None and kind != "helpers":    # the call before was left in flight: this one has settled it
             if waiting[1]() != waiting[2]:
                 print(waiting[0], "DIFFERS from the same call on a fresh context (collected by the next call, %s):" % kind, where(waiting[1](), waiting[2]))
                 return 1
