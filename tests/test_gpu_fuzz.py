@@ -68,7 +68,7 @@ def test_random_call_sequences_on_one_context_give_what_a_fresh_context_gives():
     """a short run of tools/fuzz_sequence.py: every entry point of the window solve and the map maintenance, drawn at random
     on ONE context (synchronous, enqueued and collected, enqueued and left for the next call; uploads refused half way; NaN
     windows; priors handed over by the caller and on the device; batches of 1..6 windows of random shape), each call bit for
-    bit what the same call gives on a context created for it alone.  Round 4: 1 100 calls over five seeds and context sizes
+    bit what the same call gives on a context created for it alone.  Round 4: 2 250 calls over ten seeds and context sizes
     2..12, no difference after the stale-erase-flag fix in vpl_ba_marginalize."""
     import subprocess
     tool = os.path.join(os.path.dirname(HERE), "tools", "fuzz_sequence.py")

@@ -9,7 +9,7 @@ chained upload one keyframe on; marginalize, triangulate_lines, triangulate_poin
 or enqueued and collected at once, or enqueued and left for the next call to settle); solve_odometry; an upload that is
 refused half-way (then solve and download must refuse too); a window with a NaN among its inputs; a solve whose priors
 are handed by the caller to the windows one keyframe on, marginalised and solved; the single-factor evaluators and manifold
-operations (which leave a call in flight as it is).
+operations (which leave a call in flight as it is).  The kernel / leg timers are switched on and off along the way.
 
     python tools/fuzz_sequence.py [calls=120] [windows per context=6] [seed=1]
 Exit status 1 on the first difference.
@@ -165,6 +165,7 @@ def main():
     force = dict((int(x.split(":")[0]), x.split(":")[1]) for x in os.environ.get("FUZZ_SEQ_PEND", "").split(",") if x)
     waiting = None                                       # (tag, results of the long-lived context, results of the fresh one)
     count = {}
+    timing = False
     for c in range(calls):
         kind = CALLS[int(rng.integers(0, len(CALLS)))]
         n = int(rng.integers(1, per + 1))
@@ -200,6 +201,12 @@ def main():
         pend = force.get(c, pend)
         tag = "call %d %s%s n=%d %s it%d ex%d flag%d" % (c, kind, {"sync": "", "collect": " (enqueued, collected)", "leave": " (enqueued, left in flight)"}[pend],
                                                       n, shapes, opt.num_iterations, opt.estimate_extrinsic, opt.marginalization_flag)
+        if rng.random() < 0.15 and waiting is None:      # the instrumentation switched on or off: same results
+            timing = not timing
+            ctx.enable_kernel_timing(timing)
+            ctx.lib.vpl_ctx_enable_leg_timing(ctx.h, 1 if timing else 0)
+            if not timing:
+                ctx.kernel_times()
         try:
             mine = run_call(ctx, kind, ws, w2, opt, prm, pend)
             fresh_ctx = v.Context(device=0, max_windows=per)
