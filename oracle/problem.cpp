@@ -193,7 +193,7 @@ struct Program {
       } else {
         *cost += 0.5 * sq;
       }
-      if (residuals) std::memcpy(&(*residuals)[row0[i]], r.data(), sizeof(double) * nres);
+      if (residuals && nres > 0) std::memcpy(&(*residuals)[row0[i]], r.data(), sizeof(double) * nres);   // (a prior without rows)
       if (gradient && jac)
         for (auto& jb : out->blocks)
           for (int rr = 0; rr < nres; ++rr)
