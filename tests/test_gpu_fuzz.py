@@ -20,6 +20,9 @@ import sys
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# the sweeps run with 0xA5 in the 64 bytes behind every device array; closing a context raises if a kernel wrote there
+# (vpl_ba_debug_guards / vpl_fe_debug_guards)
+GUARDED = dict(os.environ, VPL_DEBUG_GUARDS="1")
 sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
 
 
@@ -46,7 +49,7 @@ def test_random_shapes_through_the_map_maintenance_calls():
     difference (gpurun_out/r4_fuzzmap*.log)."""
     import subprocess
     tool = os.path.join(os.path.dirname(HERE), "tools", "fuzz_map.py")
-    r = subprocess.run([sys.executable, tool, "10", "6", "23"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, tool, "10", "6", "23"], capture_output=True, text=True, timeout=600, env=GUARDED)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "10 batches" in r.stdout
 
@@ -58,7 +61,7 @@ def test_random_maps_tiles_and_line_sets_through_preparation_and_vanishing_point
     random segments, parallel lines, one to three lines.  Bit for bit.  Round 4's sweeps: 220 trials, no difference."""
     import subprocess
     tool = os.path.join(os.path.dirname(HERE), "tools", "fuzz_frontend2.py")
-    r = subprocess.run([sys.executable, tool, "16", "29"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, tool, "16", "29"], capture_output=True, text=True, timeout=600, env=GUARDED)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "16 trials" in r.stdout
 
@@ -72,7 +75,7 @@ def test_random_call_sequences_on_one_context_give_what_a_fresh_context_gives():
     2..12, no difference after the stale-erase-flag fix in vpl_ba_marginalize."""
     import subprocess
     tool = os.path.join(os.path.dirname(HERE), "tools", "fuzz_sequence.py")
-    r = subprocess.run([sys.executable, tool, "48", "6", "1"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, tool, "48", "6", "1"], capture_output=True, text=True, timeout=600, env=GUARDED)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "48 calls" in r.stdout
 
@@ -85,6 +88,6 @@ def test_random_runs_of_the_device_resident_front_end_chain_on_long_lived_contex
     for bit against the oracle run stage by stage.  Round 4: 210 trials over four seeds, no difference."""
     import subprocess
     tool = os.path.join(os.path.dirname(HERE), "tools", "fuzz_frontend3.py")
-    r = subprocess.run([sys.executable, tool, "12", "5"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, tool, "12", "5"], capture_output=True, text=True, timeout=600, env=GUARDED)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "12 trials" in r.stdout

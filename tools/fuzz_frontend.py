@@ -144,6 +144,8 @@ def main():
                 if bool(ok[q]) != bool(oko) or (oko and not np.array_equal(r2c[q][:len(ro)], ro)):
                     print(tag, "pair", (0, j), "matches differ: ok %s/%s, %d / %d matched" % (ok[q], oko, int((r2c[q] >= 0).sum()), int((ro >= 0).sum()))); return 1
         print(tag, "lines", nl, "ok")
+    for fe in ctxs.values():                           # (VPL_DEBUG_GUARDS=1: close() checks the pads behind the device arrays)
+        fe.close()
     print("fuzz_frontend: %d trials, every stage, line list, LineFilter and match identical to the oracle" % trials)
     return 0
 

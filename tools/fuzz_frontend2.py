@@ -137,6 +137,8 @@ def main():
             if best != dbg["best_idx"] or not np.array_equal(vps[j], wv) or not np.array_equal(ids[j], wi):
                 print(tag, "case", j, "DIFFERS: winning hypothesis / VPs / line classes"); return 1
         print(tag, "ok")
+    for fe in ctxs.values():                           # (VPL_DEBUG_GUARDS=1: close() checks the pads behind the device arrays)
+        fe.close()
     print("fuzz_frontend2: %d trials: prepared frames, sphere grids, vanishing points and line classes identical to the oracle" % trials)
     return 0
 

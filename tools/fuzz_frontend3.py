@@ -130,6 +130,8 @@ def main():
                     return 1
                 done["pairs"] += 1; done["matched"] += int((np.asarray(ro) >= 0).sum()) if oko else 0
         print(tag, "lines", [len(l) for l in want], "ok")
+    for fe in ctxs.values():                           # (VPL_DEBUG_GUARDS=1: close() checks the pads behind the device arrays)
+        fe.close()
     print("fuzz_frontend3: %d trials of the device-resident chain on long-lived contexts %s: lines and matches identical to the oracle" % (trials, done))
     return 0
 

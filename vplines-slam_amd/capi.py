@@ -248,10 +248,18 @@ class Context:
         self._cw = None
         self._windows = []
 
+    def debug_guards(self):
+        """VPL_DEBUG_GUARDS=1 (set before the context is made): number of device arrays with a write behind their end"""
+        return int(self.lib.vpl_ba_debug_guards(self.h))
+
     def close(self):
         if self.h:
+            bad = self.debug_guards() if os.environ.get("VPL_DEBUG_GUARDS") == "1" else 0
+            msg = self.lib.vpl_last_error(self.h).decode() if bad else ""
             self.lib.vpl_ctx_destroy(self.h)
             self.h = C.c_void_p()
+            if bad:
+                raise RuntimeError("vpl_ba_debug_guards: %d arrays overrun; %s" % (bad, msg))
 
     def __del__(self):
         try:

@@ -146,6 +146,8 @@ struct vpl_ctx {
   int maxW = 0, maxP = 0, maxPO = 0, maxL = 0, maxLO = 0;
   DevBatch B;
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;   // payload of allocs[i]; 64 pad bytes follow (VPL_DEBUG_GUARDS=1: filled with 0xA5, vpl_ba_debug_guards)
+  bool guards = false;
   int nW = 0;
   vpl_ba_options opt;
   std::string err;
@@ -255,7 +257,9 @@ static hipError_t dalloc(vpl_ctx* c, T** p, size_t n) {
   hipError_t e = hipMalloc(&q, n * sizeof(T) + 64);
   if (e != hipSuccess) return e;
   e = hipMemset(q, 0, n * sizeof(T) + 64);
+  if (e == hipSuccess && c->guards) e = hipMemset((char*)q + n * sizeof(T), 0xA5, 64);
   c->allocs.push_back(q);
+  c->alloc_bytes.push_back(n * sizeof(T));
   *p = (T*)q;
   return e;
 }
@@ -357,6 +361,7 @@ int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, i
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device >= ndev) return VPL_E_NODEVICE;
   vpl_ctx* c = new vpl_ctx();
+  { const char* g = getenv("VPL_DEBUG_GUARDS"); c->guards = g && g[0] == '1'; }
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return VPL_E_NODEVICE; }
   c->maxW = max_windows;
@@ -1788,6 +1793,25 @@ int vpl_ba_debug_marg_Ab(vpl_ctx* c, int w, double* A, double* b) {
   HIPCHK(c, hipMemcpy(A, c->B.mg_A + (size_t)w * MAXKEEP * MAXKEEP, (size_t)n * n * 8, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(b, c->B.mg_b + (size_t)w * MAXKEEP, (size_t)n * 8, hipMemcpyDeviceToHost));
   return n;
+}
+
+// Debug aid of the randomised sweeps (tools/fuzz_*.py with VPL_DEBUG_GUARDS=1 in the environment when the context is made): the
+// 64 bytes behind every device array then hold 0xA5; returns how many arrays have had theirs written to (a kernel ran past the
+// end of an array), the first one named in vpl_last_error by its allocation index and size.
+int vpl_ba_debug_guards(vpl_ctx* c) {
+  if (!c) return VPL_E_INVALID;
+  if (!c->guards) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  int bad = 0;
+  unsigned char pad[64];
+  for (size_t i = 0; i < c->allocs.size(); ++i) {
+    HIPCHK(c, hipMemcpy(pad, (char*)c->allocs[i] + c->alloc_bytes[i], 64, hipMemcpyDeviceToHost));
+    bool hit = false;
+    for (int k = 0; k < 64; ++k) hit |= pad[k] != 0xA5;
+    if (hit && !bad++) c->err = "guard behind device array #" + std::to_string(i) + " (" + std::to_string(c->alloc_bytes[i]) + " bytes) overwritten";
+  }
+  return bad;
 }
 
 int vpl_ba_debug_stamps(vpl_ctx* c, int w, long long* out) {

@@ -47,6 +47,8 @@ struct vpl_fe_ctx {
   uint32_t* d_vpSeed = nullptr;
   int vpN = 0;
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;   // payload of allocs[i]; 64 pad bytes follow (VPL_DEBUG_GUARDS=1: 0xA5, vpl_fe_debug_guards)
+  bool guards = false;
   std::string err;
   bool timing = false;                                    // vpl_fe_enable_kernel_timing
   std::vector<std::pair<const char*, double>> ktimes;     // (kernel, ms) of the launches since timing was enabled
@@ -89,8 +91,11 @@ static hipError_t fe_alloc(vpl_fe_ctx* c, T** p, size_t n) {
   hipError_t e = hipMalloc(&q, n * sizeof(T) + 64);
   if (e != hipSuccess) return e;
   c->allocs.push_back(q);
+  c->alloc_bytes.push_back(n * sizeof(T));
   *p = (T*)q;
-  return hipMemset(q, 0, n * sizeof(T) + 64);
+  e = hipMemset(q, 0, n * sizeof(T) + 64);
+  if (e == hipSuccess && c->guards) e = hipMemset((char*)q + n * sizeof(T), 0xA5, 64);
+  return e;
 }
 
 extern "C" {
@@ -139,6 +144,7 @@ int vpl_fe_create(vpl_fe_ctx** out, int device, int max_images, int width, int h
   if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0 || device >= nd) return VPL_E_NODEVICE;
   if (hipSetDevice(device) != hipSuccess) return VPL_E_NODEVICE;
   vpl_fe_ctx* c = new vpl_fe_ctx();
+  { const char* g = getenv("VPL_DEBUG_GUARDS"); c->guards = g && g[0] == '1'; }
   c->device = device; c->maxN = max_images; c->W = width; c->H = height; c->maxLines = max_lines_per_image;
   EdBatch& B = c->B;
   std::memset(&B, 0, sizeof(B));
@@ -223,6 +229,23 @@ int vpl_fe_kernel_times(vpl_fe_ctx* c, int* count, const char** names, double* m
 }
 int vpl_fe_synchronize(vpl_fe_ctx* c) { if (!c) return VPL_E_INVALID; FECHK(c, hipStreamSynchronize(c->stream)); return VPL_OK; }
 const char* vpl_fe_last_error(const vpl_fe_ctx* c) { return c ? c->err.c_str() : "null context"; }
+// Debug aid of the randomised sweeps (VPL_DEBUG_GUARDS=1 when the context is made: the 64 bytes behind every device array hold
+// 0xA5): how many arrays have had theirs written to; the first is named in vpl_fe_last_error.
+int vpl_fe_debug_guards(vpl_fe_ctx* c) {
+  if (!c) return VPL_E_INVALID;
+  if (!c->guards) return 0;
+  FECHK(c, hipSetDevice(c->device));
+  FECHK(c, hipDeviceSynchronize());
+  int bad = 0;
+  unsigned char pad[64];
+  for (size_t i = 0; i < c->allocs.size(); ++i) {
+    FECHK(c, hipMemcpy(pad, (char*)c->allocs[i] + c->alloc_bytes[i], 64, hipMemcpyDeviceToHost));
+    bool hit = false;
+    for (int k = 0; k < 64; ++k) hit |= pad[k] != 0xA5;
+    if (hit && !bad++) c->err = "guard behind device array #" + std::to_string(i) + " (" + std::to_string(c->alloc_bytes[i]) + " bytes) overwritten";
+  }
+  return bad;
+}
 
 int vpl_edlines_upload(vpl_fe_ctx* c, int n, const uint8_t* images) {
   if (!c || !images || n < 1) return VPL_E_INVALID;

@@ -1,5 +1,6 @@
 """ctypes binding of include/vplines_frontend.h (EDLines extractor + KLT line matcher on the GPU)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -140,10 +141,18 @@ class FrontendContext:
             self._check(self.lib.vpl_fe_set_stream(self.h, C.c_void_p(stream)), "vpl_fe_set_stream")
         self.n = 0
 
+    def debug_guards(self):
+        """VPL_DEBUG_GUARDS=1 (set before the context is made): number of device arrays with a write behind their end"""
+        return int(self.lib.vpl_fe_debug_guards(self.h))
+
     def close(self):
         if self.h:
+            bad = self.debug_guards() if os.environ.get("VPL_DEBUG_GUARDS") == "1" else 0
+            msg = self.lib.vpl_fe_last_error(self.h).decode() if bad else ""
             self.lib.vpl_fe_destroy(self.h)
             self.h = C.c_void_p()
+            if bad:
+                raise RuntimeError("vpl_fe_debug_guards: %d arrays overrun; %s" % (bad, msg))
 
     def __del__(self):
         try:
