@@ -259,6 +259,8 @@ class Context:
             self.lib.vpl_ctx_destroy(self.h)
             self.h = C.c_void_p()
             if bad:
+                import sys
+                print("vpl_ba_debug_guards: %d arrays overrun; %s" % (bad, msg), file=sys.stderr)    # (also when closed by __del__)
                 raise RuntimeError("vpl_ba_debug_guards: %d arrays overrun; %s" % (bad, msg))
 
     def __del__(self):

@@ -152,6 +152,8 @@ class FrontendContext:
             self.lib.vpl_fe_destroy(self.h)
             self.h = C.c_void_p()
             if bad:
+                import sys
+                print("vpl_fe_debug_guards: %d arrays overrun; %s" % (bad, msg), file=sys.stderr)    # (also when closed by __del__)
                 raise RuntimeError("vpl_fe_debug_guards: %d arrays overrun; %s" % (bad, msg))
 
     def __del__(self):
