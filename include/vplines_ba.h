@@ -166,7 +166,8 @@ typedef struct vpl_ctx vpl_ctx; /* opaque: device buffers + stream for one GPU *
 int vpl_ctx_create(vpl_ctx** out, int device, int max_windows, int max_points, int max_point_obs,
                    int max_lines, int max_line_obs);
 void vpl_ctx_destroy(vpl_ctx* ctx);
-/* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = default stream). */
+/* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = default stream).  Work in flight on the stream used
+ * so far is completed first (an enqueued call is collected, the old stream synchronised). */
 int vpl_ctx_set_stream(vpl_ctx* ctx, void* hip_stream);
 const char* vpl_last_error(const vpl_ctx* ctx);
 

@@ -47,7 +47,7 @@ void vpl_edline_default_param(vpl_edline_param* p);   /* {5, 1, 30, 5, 2, 35, 1.
 
 int vpl_fe_create(vpl_fe_ctx** out, int device, int max_images, int width, int height, int max_lines_per_image);
 void vpl_fe_destroy(vpl_fe_ctx* ctx);
-int vpl_fe_set_stream(vpl_fe_ctx* ctx, void* hip_stream);
+int vpl_fe_set_stream(vpl_fe_ctx* ctx, void* hip_stream);   /* (work in flight on the stream used so far is completed first) */
 int vpl_fe_synchronize(vpl_fe_ctx* ctx);
 const char* vpl_fe_last_error(const vpl_fe_ctx* ctx);
 

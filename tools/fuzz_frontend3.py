@@ -5,7 +5,7 @@
 
 on ONE context per frame size that lives through all trials, with the number of frames (1 .. capacity), the pairs (any two
 frames, repeated frames, a frame paired with itself), the cut `max_lines`, the detector's and matcher's parameters, remap /
-CLAHE on or off and the LineFilter step drawn per trial -- so every trial runs on whatever the one before left in the frame
+CLAHE on or off, the LineFilter step and the stream (switched between trials and between two enqueued stages) drawn per trial -- so every trial runs on whatever the one before left in the frame
 batch, the line table, the pyramids and the matcher's buffers.  Held, bit for bit, to the oracle run stage by stage on the
 host (remap + CLAHE -> EDLines -> LineFilter -> Matching on the first `max_lines` lines of either frame).
 
@@ -19,6 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ctypes as C
+
 import numpy as np
 
 import oracle_api as o
@@ -34,6 +36,9 @@ def main():
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     ctxs = {}
+    import torch
+    keep = [torch.cuda.Stream(device=0) for _ in range(3)]
+    streams = [0] + [k.cuda_stream for k in keep]
     done = dict(pairs=0, matched=0, filtered=0, prepared=0)
     for t in range(trials):
         W, H = SIZES[int(rng.integers(0, len(SIZES)))]
@@ -82,6 +87,8 @@ def main():
         too_many = max(len(l) for l in found) > 1024
         want = [o.line_filter(l, dth) if dth is not None and len(l) else l for l in found]
         done["filtered"] += n if dth is not None else 0
+        if rng.random() < 0.2:
+            fe._check(fe.lib.vpl_fe_set_stream(fe.h, C.c_void_p(streams[int(rng.integers(0, len(streams)))])), "vpl_fe_set_stream")
         # ---- the device chain ----------------------------------------------------------------------------------------------
         matched = bool(pairs) and min(W, H) >= 64
         try:
@@ -92,6 +99,8 @@ def main():
             else:
                 fe.upload(raw)
             fe.detect(p, smoothed)
+            if rng.random() < 0.2:                       # the stream changed between two enqueued stages
+                fe._check(fe.lib.vpl_fe_set_stream(fe.h, C.c_void_p(streams[int(rng.integers(0, len(streams)))])), "vpl_fe_set_stream")
             if dth is not None:
                 fe.line_filter_detected(dth)
             if matched:

@@ -9,7 +9,8 @@ chained upload one keyframe on; marginalize, triangulate_lines, triangulate_poin
 or enqueued and collected at once, or enqueued and left for the next call to settle); solve_odometry; an upload that is
 refused half-way (then solve and download must refuse too); a window with a NaN among its inputs; a solve whose priors
 are handed by the caller to the windows one keyframe on, marginalised and solved; the single-factor evaluators and manifold
-operations (which leave a call in flight as it is).  The kernel / leg timers are switched on and off along the way.
+operations (which leave a call in flight as it is).  The kernel / leg timers are switched on and off and the
+context is moved between four streams along the way.
 
     python tools/fuzz_sequence.py [calls=120] [windows per context=6] [seed=1]
 Exit status 1 on the first difference.
@@ -159,6 +160,9 @@ def main():
     calls = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     per = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    import torch                                         # (initialised before the library's first HIP call)
+    keep = [torch.cuda.Stream(device=0) for _ in range(3)]
+    streams = [0] + [k.cuda_stream for k in keep]
     ctx = v.Context(device=0, max_windows=per)
     # replay aids: FUZZ_SEQ_ONLY="30,31,32" runs these calls alone, FUZZ_SEQ_PEND="31:sync" overrides how call 31 is issued
     only = set(int(x) for x in os.environ.get("FUZZ_SEQ_ONLY", "").split(",") if x)
@@ -207,6 +211,8 @@ def main():
             ctx.lib.vpl_ctx_enable_leg_timing(ctx.h, 1 if timing else 0)
             if not timing:
                 ctx.kernel_times()
+        if rng.random() < 0.12:                          # another stream, whatever is in flight (vpl_ctx_set_stream completes it)
+            ctx.set_stream(streams[int(rng.integers(0, len(streams)))])
         try:
             mine = run_call(ctx, kind, ws, w2, opt, prm, pend)
             fresh_ctx = v.Context(device=0, max_windows=per)

@@ -184,6 +184,12 @@ def load_hip_library():
     if not os.path.exists(path):
         raise RuntimeError("HIP extension %s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                            "there is no CPU fallback" % path)
+    # PyTorch ships a HIP runtime of its own: in a process that uses both, torch's must be the one that is loaded first (with
+    # /opt/rocm's loaded and initialised first, torch.cuda afterwards reports "No HIP GPUs are available" -- seen on the GPU box)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp = C.c_void_p
     lib.vpl_ba_default_options.argtypes = [C.POINTER(BaOptions)]
@@ -275,6 +281,7 @@ class Context:
             raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
 
     def set_stream(self, stream_ptr):
+        self._settle()
         self._check(self.lib.vpl_ctx_set_stream(self.h, C.c_void_p(stream_ptr)), "vpl_ctx_set_stream")
 
     def synchronize(self):

@@ -494,6 +494,15 @@ void vpl_ctx_destroy(vpl_ctx* c) {
 
 int vpl_ctx_set_stream(vpl_ctx* c, void* s) {
   if (!c) return VPL_E_INVALID;
+  // what is in flight on the stream so far is completed first (an enqueued call would otherwise be collected behind a
+  // synchronisation of the NEW stream, and a later download would not be ordered behind a solve on the old one)
+  const int rs = settle(c);
+  if (rs) return rs;
+  if (c->stream != (hipStream_t)s) {
+    HIPCHK(c, hipSetDevice(c->device));
+    (void)hipStreamSynchronize(c->stream);   // (an old stream the caller has destroyed already has nothing in flight)
+    (void)hipGetLastError();
+  }
   drop_graph(c);
   c->stream = (hipStream_t)s;
   return VPL_OK;

@@ -213,7 +213,16 @@ void vpl_fe_destroy(vpl_fe_ctx* c) {
   for (void* p : c->allocs) hipFree(p);
   delete c;
 }
-int vpl_fe_set_stream(vpl_fe_ctx* c, void* s) { if (!c) return VPL_E_INVALID; c->stream = (hipStream_t)s; return VPL_OK; }
+int vpl_fe_set_stream(vpl_fe_ctx* c, void* s) {
+  if (!c) return VPL_E_INVALID;
+  if (c->stream != (hipStream_t)s) {   // what was enqueued on the stream so far is completed first (downloads follow on the new one)
+    FECHK(c, hipSetDevice(c->device));
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+  }
+  c->stream = (hipStream_t)s;
+  return VPL_OK;
+}
 int vpl_fe_enable_kernel_timing(vpl_fe_ctx* c, int enable) {
   if (!c) return VPL_E_INVALID;
   c->timing = enable != 0;
