@@ -46,11 +46,20 @@ def pose_err(a, b, _=None):
     return dp, (2 * np.arccos(dots)).max()
 
 
+# FUZZ_CAPS="P,L": contexts of another capacity than the default 256 points / 128 lines (strides, LDS windows and the choice
+# between kernel variants depend on it); the shapes drawn stay within it and include it
+CAP_P, CAP_L = (int(x) for x in os.environ.get("FUZZ_CAPS", "256,128").split(","))
+
+
+def make_ctx(per):
+    return v.Context(device=0, max_windows=per, max_points=CAP_P, max_point_obs=CAP_P * 11, max_lines=CAP_L, max_line_obs=CAP_L * 11)
+
+
 def draw_window(rng, idx, t):
-    P = int(rng.choice([0, 1, 3, 17, 64, 150, 200, 256]))
-    L = int(rng.choice([0, 1, 5, 33, 80, 128]))
+    P = int(rng.choice([x for x in (0, 1, 3, 17, 64, 150, 200, 256) if x < CAP_P] + [CAP_P]))
+    L = int(rng.choice([x for x in (0, 1, 5, 33, 80, 128) if x < CAP_L] + [CAP_L]))
     if P == 0 and L == 0:
-        P = 40
+        P = min(40, CAP_P)
     vp = bool(rng.integers(0, 2))
     cfg = v.workload.config(P, L, vp)
     # the window holds the tracks that pass the reference's filters (include/vplines_ba.h): points with >= 2 observations,
@@ -93,7 +102,7 @@ def run(nb, per, seed, out=print):
     """-> dict(total, miss, ill, miss_first, total_first, worst_dp, worst_dr); *_first count the windows solved without an
     incoming prior (the chained ones depend on the marginalisation of the solve before)"""
     rng = np.random.default_rng(seed)
-    ctx = v.Context(device=0, max_windows=per)
+    ctx = make_ctx(per)
     bad = total = ill = bad0 = total0 = 0
     worst = [0.0, 0.0]                                # over the windows that determine their states
     for b in range(nb):

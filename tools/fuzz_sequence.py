@@ -22,11 +22,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ctypes as C
+
 import numpy as np
 
 import oracle_api as o
 import vplines_slam_amd as v
-from fuzz_parity import draw_window
+from fuzz_parity import draw_window, make_ctx
+from vplines_slam_amd.capi import Prior
 
 CALLS = ["solve", "solve", "twice", "chain", "marg", "tri_lines", "tri_points", "line_opt", "slide", "odometry", "refused", "nan", "prior", "helpers"]
 
@@ -50,6 +53,21 @@ def where(a, b):
         if x != y:
             if isinstance(x, tuple) and x and isinstance(x[0], bytes):
                 out.append("item %d: fields %s" % (k, [j for j, (p, q) in enumerate(zip(x, y)) if p != q]))
+            elif isinstance(x, bytes) and len(x) == len(y) == C.sizeof(Prior):
+                pa, pb = Prior.from_buffer_copy(x), Prior.from_buffer_copy(y)
+                if pa.n != pb.n:
+                    out.append("item %d: prior of %d / %d rows" % (k, pa.n, pb.n))
+                else:
+                    Ja, Jb = pa.J(), pb.J()
+                    d = np.abs(Ja - Jb)
+                    print("   ranks (rows of J0 that are not zero): %d / %d; first pivots (column of the first nonzero of each row): %s / %s" % (
+                        int((np.abs(Ja).max(1) > 0).sum()), int((np.abs(Jb).max(1) > 0).sum()),
+                        [int(np.nonzero(r)[0][0]) if np.any(r) else -1 for r in Ja], [int(np.nonzero(r)[0][0]) if np.any(r) else -1 for r in Jb]))
+                    print("   diag J^T J long-lived", np.array2string(np.diag(Ja.T @ Ja), precision=4))
+                    print("   diag J^T J fresh     ", np.array2string(np.diag(Jb.T @ Jb), precision=4))
+                    out.append("item %d: prior n=%d, J0 differs in %d entries (rows %s), max |dJ| %.3e of max |J| %.3e, max |dr| %.3e; J^T J rel diff %.2e" % (
+                        k, pa.n, int((d > 0).sum()), sorted(set(np.nonzero(d > 0)[0].tolist()))[:12], d.max(), np.abs(Jb).max(), np.abs(pa.r() - pb.r()).max(),
+                        np.abs(Ja.T @ Ja - Jb.T @ Jb).max() / max(1e-300, np.abs(Jb.T @ Jb).max())))
             elif isinstance(x, bytes) and len(x) == len(y) and len(x) % 4 == 0:
                 xa, ya = np.frombuffer(x, np.int32), np.frombuffer(y, np.int32)
                 d = np.nonzero(xa != ya)[0]
@@ -163,7 +181,7 @@ def main():
     import torch                                         # (initialised before the library's first HIP call)
     keep = [torch.cuda.Stream(device=0) for _ in range(3)]
     streams = [0] + [k.cuda_stream for k in keep]
-    ctx = v.Context(device=0, max_windows=per)
+    ctx = make_ctx(per)
     # replay aids: FUZZ_SEQ_ONLY="30,31,32" runs these calls alone, FUZZ_SEQ_PEND="31:sync" overrides how call 31 is issued
     only = set(int(x) for x in os.environ.get("FUZZ_SEQ_ONLY", "").split(",") if x)
     force = dict((int(x.split(":")[0]), x.split(":")[1]) for x in os.environ.get("FUZZ_SEQ_PEND", "").split(",") if x)
@@ -200,23 +218,45 @@ def main():
                                   vp=rng.normal(0, 1, (m, 3)))
         enq = kind in ("marg", "tri_lines", "tri_points", "line_opt", "slide")
         pend = str(rng.choice(["sync", "collect", "leave"])) if enq else "sync"
+        toggle = rng.random() < 0.15
+        move = int(rng.integers(0, len(streams))) if rng.random() < 0.12 else -1
         if only and c not in only:                       # (replay of a subset: the draws above keep the inputs the same)
             continue
         pend = force.get(c, pend)
         tag = "call %d %s%s n=%d %s it%d ex%d flag%d" % (c, kind, {"sync": "", "collect": " (enqueued, collected)", "leave": " (enqueued, left in flight)"}[pend],
                                                       n, shapes, opt.num_iterations, opt.estimate_extrinsic, opt.marginalization_flag)
-        if rng.random() < 0.15 and waiting is None:      # the instrumentation switched on or off: same results
+        if toggle and waiting is None:                   # the instrumentation switched on or off: same results
             timing = not timing
             ctx.enable_kernel_timing(timing)
             ctx.lib.vpl_ctx_enable_leg_timing(ctx.h, 1 if timing else 0)
             if not timing:
                 ctx.kernel_times()
-        if rng.random() < 0.12:                          # another stream, whatever is in flight (vpl_ctx_set_stream completes it)
-            ctx.set_stream(streams[int(rng.integers(0, len(streams)))])
+        if move >= 0:                                    # another stream, whatever is in flight (vpl_ctx_set_stream completes it)
+            ctx.set_stream(streams[move])
         try:
             mine = run_call(ctx, kind, ws, w2, opt, prm, pend)
-            fresh_ctx = v.Context(device=0, max_windows=per)
+            fresh_ctx = make_ctx(per)
             theirs = run_call(fresh_ctx, kind, ws, w2, opt, prm, "sync")()
+            if os.environ.get("FUZZ_SEQ_DUMP", "") == str(c):    # replay aid: the kept block (A, b) of window 0 before it is factored
+                got = []
+                for x in (ctx, fresh_ctx):
+                    A, bb = np.zeros(171 * 171), np.zeros(171)
+                    nn = x.lib.vpl_ba_debug_marg_Ab(x.h, 0, A.ctypes.data_as(C.POINTER(C.c_double)), bb.ctypes.data_as(C.POINTER(C.c_double)))
+                    got.append((nn, A[:nn * nn].reshape(nn, nn).copy(), bb[:nn].copy()))
+                (n1, A1, b1), (n2, A2, b2) = got
+                pc, rc = o.solve_window(ws[0].copy(), opt)
+                Jc = pc.J()
+                print("   oracle: prior n=%d, diag J^T J %s" % (pc.n, np.array2string(np.diag(Jc.T @ Jc), precision=4)))
+                print("   A row 0", np.array2string(A2[0], precision=6))
+                print("   A row 1", np.array2string(A2[1], precision=6))
+                print("   oracle J^T J row 1", np.array2string((Jc.T @ Jc)[1], precision=6))
+                print("   kept block: n %d / %d" % (n1, n2))
+                if n1 == n2:
+                    d = np.abs(A1 - A2)
+                    print("   A differs in %d entries, max %.3e of %.3e, rows %s; b differs max %.3e" % (
+                        int((d > 0).sum()), d.max(), np.abs(A2).max(), sorted(set(np.nonzero(d > 0)[0].tolist())), np.abs(b1 - b2).max()))
+                    print("   diag long-lived", np.array2string(np.diag(A1), precision=3))
+                    print("   diag fresh     ", np.array2string(np.diag(A2), precision=3))
             fresh_ctx.close()
         except (RuntimeError, AssertionError) as e:
             print(tag, "FAILED:", e)
