@@ -935,6 +935,10 @@ __device__ __forceinline__ void marg_body(const DevBatch& B, const int w, double
   VPL_STAMP(B, w, 36);
   double* J0 = B.mg_J0 + (size_t)w * MAXKEEP * MAXKEEP;
   double* r0 = B.mg_r0 + (size_t)w * MAXKEEP;
+  // (the block is cleared first: the loop below covers it only if perm is a permutation, and a column it leaves out must not
+  //  keep the prior of the batch the context solved before -- DESIGN.md section 6, the open item of round 4)
+  for (int it = tid; it < n * n; it += T) J0[it] = 0.0;
+  __syncthreads();
   for (int it = tid; it < n * n; it += T) {
     const int k = it / n, t = it % n;   // J0[k][perm[t]] = L[t][k]
     J0[k * n + perm[t]] = (k < rank && t >= k) ? G[t * ldm + k] : 0.0;
